@@ -1,0 +1,111 @@
+/* peppa_hip.h -- C ABI of the MI355X-native FaceAna hot path (libpeppa_hip.so).
+ *
+ * Drop-in boundary for the compute the reference delegates to onnxruntime / OpenCV / numpy
+ * (paths relative to the reference checkout 610265158/Peppa_Pig_Face_Landmark):
+ *
+ *   reference seam                                              entry point here
+ *   ----------------------------------------------------------  -------------------------------
+ *   ONNXEngine.__init__(onnx_f)      onnx_model_base.py:7-14     pf_create + pf_load_program
+ *   ONNXEngine.__call__(data) kps    onnx_model_base.py:17-27,   pf_landmark_forward
+ *                                    face_landmark.py:48
+ *   ONNXEngine.__call__(data) det    face_detector.py:29-31      pf_detector_forward
+ *   FaceDetector.__call__(image)     face_detector.py:23-42      pf_detect
+ *   FaceLandmark.__call__(img,boxes) face_landmark.py:33-64      pf_landmarks
+ *   FaceAna.run per frame (no track) facer.py:52-85, demo.py:83-86  pf_run_frames
+ *
+ * Conventions: every entry returns 0 on success, non-zero on failure (message via
+ * pf_last_error).  Plain pointers and sizes only.  `mem` says where caller buffers live:
+ * PF_MEM_HOST (numpy / malloc) or PF_MEM_DEVICE (HBM of the handle's device).  One handle = one
+ * device + one HIP stream; calls on a handle are serialised by the caller; handles on different
+ * devices are independent.  The library never falls back to the CPU.
+ */
+#ifndef PEPPA_HIP_H
+#define PEPPA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pf_handle pf_handle;
+
+enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1 };
+enum { PF_NET_LANDMARK = 0, PF_NET_DETECTOR = 1, PF_NET_SLOTS = 4 };
+enum { PF_INPUT_U8_NHWC = 0, PF_INPUT_F32_NCHW = 1 };
+enum { PF_DTYPE_F16 = 0, PF_DTYPE_F32 = 1 };
+
+/* library / build identification: "peppa-hip <version> gfx950" (or "... simt-emu" for the
+ * CPU test build of the same sources, which only tests/ may load) */
+const char* pf_version(void);
+
+/* Create an engine bound to HIP device `device_id` (one stream, no networks loaded yet). */
+int pf_create(int device_id, pf_handle** out);
+void pf_destroy(pf_handle* h);
+/* Last error message of the handle (or of pf_create when h == NULL). */
+const char* pf_last_error(pf_handle* h);
+/* Block until all work queued on the handle's stream has finished. */
+int pf_sync(pf_handle* h);
+
+/* Load a packed network program (built by peppa_pig_face_landmark_amd.graph) into `slot`
+ * and size its activation arena for up to `max_batch` items.  Replaces
+ * rt.InferenceSession(onnx_f) -- onnx_model_base.py:14. */
+int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int max_batch);
+
+/* Landmark regressor forward == session.run of kps_student.onnx (face_landmark.py:48):
+ * input  B crops, either uint8 NHWC [B][S][S][3] (channel order as given by the caller) or
+ *        float32 NCHW [B][3][S][S] already divided by 255 (face_landmark.py:44-47);
+ * output loc_fix [B][196] (x0,y0,...,x97,y97 normalised to the crop, model.py:549-552) and
+ *        score [B][98] (raw heat-map maximum, model.py:522). */
+int pf_landmark_forward(pf_handle* h, const void* input, int input_kind, int mem, int batch,
+                        float* loc_fix, float* score, int out_mem);
+
+/* Detector forward == session.run of yolov5n-0.5.onnx (face_detector.py:29-31):
+ * input float32 NCHW [1][3][384][640] RGB/255 or uint8 NHWC letterboxed RGB;
+ * output [rows][16] decoded rows (cx,cy,w,h,obj,10 landmark coords,cls), rows = 15120 at 384x640. */
+int pf_detector_forward(pf_handle* h, const void* input, int input_kind, int mem, int batch,
+                        float* rows_out, int out_mem);
+
+/* Debug / parity tap: copy activation tensor `tensor_id` of the program in `slot` (as left by
+ * the last forward of `batch` items) to host float32 NHWC [batch][H][W][C]. */
+int pf_read_tensor(pf_handle* h, int slot, int tensor_id, int batch, float* out_host, size_t out_elems);
+
+/* FaceDetector.__call__ (face_detector.py:23-42): BGR uint8 frame -> kept detections
+ * [n][16] in frame coordinates (cols 0:4 xyxy, col 4 score), at most max_n rows, in keep order. */
+int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+              float score_thres, float iou_thres, float* boxes, int max_n, int* n_out);
+
+/* FaceLandmark.__call__ (face_landmark.py:33-64): for each of n boxes (xyxy, float32 [n][4])
+ * crop (zero pad, square 1.4*w box), resize to the network size, run the regressor, map the
+ * landmarks back to frame coordinates.  kps [n][98][2], scores [n][98], valid[n] = 0 for boxes
+ * the reference rejects (w or h <= 20 px, face_landmark.py:76-77) -- those rows are left untouched. */
+int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 const float* boxes, int n, float* kps, float* scores, int* valid);
+
+/* Batched FaceAna.run()+reset() (facer.py:52-85 without tracking, demo.py:83-86) over F frames
+ * of identical size resident in `frames` ([F][H][W][3] BGR): detect -> NMS -> drop area <=
+ * min_face, keep top_k by area (facer.py:120-142) -> landmarks.  Outputs (host or device per
+ * out_mem): counts[F], boxes [F][top_k][4], kps [F][top_k][98][2], scores [F][top_k][98]. */
+int pf_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                  float score_thres, float iou_thres, float min_face, int top_k,
+                  int* counts, float* boxes, float* kps, float* scores, int out_mem);
+
+/* Same stages as pf_run_frames but detections are supplied by the caller (planted-candidate
+ * protocol): det_rows is the decoded detector output [F][rows][16] in letterboxed
+ * coordinates; everything downstream (xywh2xyxy, NMS, un-letterbox, top-k, landmarks) runs on
+ * the device.  det_rows == NULL means "run the detector network" (== pf_run_frames). */
+int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                          const float* det_rows, int rows, float score_thres, float iou_thres,
+                          float min_face, int top_k,
+                          int* counts, float* boxes, float* kps, float* scores, int out_mem);
+
+/* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream
+ * when profiling is enabled.  names: '\n'-separated kernel tags; ms: same order. */
+int pf_profile_enable(pf_handle* h, int on);
+int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int* counts, int cap, int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEPPA_HIP_H */

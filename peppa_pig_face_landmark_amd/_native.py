@@ -1,0 +1,229 @@
+"""ctypes binding of ``libpeppa_hip.so`` (C ABI: ``include/peppa_hip.h``).
+
+No torch, no onnxruntime: numpy arrays in, numpy arrays out.  There is deliberately no CPU
+fallback -- if the HIP library is missing or no GPU is visible, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+PF_MEM_HOST, PF_MEM_DEVICE = 0, 1
+PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
+PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "libpeppa_hip.so")
+
+_lib_cache = {}
+
+
+class PeppaHipError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    fp, ip = C.POINTER(C.c_float), C.POINTER(C.c_int)
+    lib.pf_version.restype = C.c_char_p
+    lib.pf_version.argtypes = []
+    lib.pf_create.argtypes = [i, C.POINTER(vp)]
+    lib.pf_destroy.argtypes = [vp]
+    lib.pf_destroy.restype = None
+    lib.pf_last_error.argtypes = [vp]
+    lib.pf_last_error.restype = C.c_char_p
+    lib.pf_sync.argtypes = [vp]
+    lib.pf_load_program.argtypes = [vp, i, vp, sz, i]
+    lib.pf_landmark_forward.argtypes = [vp, vp, i, i, i, vp, vp, i]
+    lib.pf_detector_forward.argtypes = [vp, vp, i, i, i, vp, i]
+    lib.pf_read_tensor.argtypes = [vp, i, i, i, fp, sz]
+    lib.pf_detect.argtypes = [vp, vp, i, i, i, i, f, f, fp, i, ip]
+    lib.pf_landmarks.argtypes = [vp, vp, i, i, i, i, fp, i, fp, fp, ip]
+    lib.pf_run_frames.argtypes = [vp, vp, i, i, i, i, f, f, f, i, vp, vp, vp, vp, i]
+    lib.pf_run_frames_planted.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
+    lib.pf_profile_enable.argtypes = [vp, i]
+    lib.pf_profile_fetch.argtypes = [vp, C.c_char_p, sz, fp, ip, i, ip]
+    for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
+                 "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
+                 "pf_profile_enable", "pf_profile_fetch"):
+        getattr(lib, name).restype = i
+    return lib
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the engine.  ``path`` defaults to the in-tree ``libpeppa_hip.so`` built by
+    ``__graft_entry__.build()`` / ``python -m peppa_pig_face_landmark_amd.build``."""
+    path = os.path.abspath(path or os.environ.get("PEPPA_HIP_LIBRARY", DEFAULT_LIBRARY))
+    if path in _lib_cache:
+        return _lib_cache[path]
+    if not os.path.exists(path):
+        raise PeppaHipError(
+            f"{path} not found: build it with `python -m peppa_pig_face_landmark_amd.build` "
+            "(hipcc --offload-arch=gfx950).  The engine has no CPU fallback.")
+    lib = _declare(C.CDLL(path))
+    _lib_cache[path] = lib
+    return lib
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return C.c_void_p(a)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    """One engine == one GPU + one HIP stream (``pf_handle``)."""
+
+    def __init__(self, device: int = 0, library: Optional[str] = None):
+        self.lib = load_library(library)
+        self.h = C.c_void_p()
+        if self.lib.pf_create(int(device), C.byref(self.h)) != 0:
+            msg = self.lib.pf_last_error(None)
+            raise PeppaHipError("pf_create failed: " + (msg.decode() if msg else "unknown"))
+        self.device = device
+        self._programs = {}
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def version(self) -> str:
+        return self.lib.pf_version().decode()
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.pf_last_error(self.h)
+            raise PeppaHipError(f"{what} failed: " + (msg.decode() if msg else "unknown"))
+
+    def sync(self):
+        self._check(self.lib.pf_sync(self.h), "pf_sync")
+
+    def load_program(self, slot: int, blob: bytes, max_batch: int):
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self.lib.pf_load_program(self.h, slot, C.cast(buf, C.c_void_p), len(blob), int(max_batch)),
+                    "pf_load_program")
+        self._programs[slot] = max_batch
+
+    # ---- network seams ------------------------------------------------------------------------
+    def landmark_forward(self, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """x: uint8 [B,S,S,3] or float32 [B,3,S,S] -> (loc_fix [B,196], score [B,98])."""
+        if x.dtype == np.uint8:
+            kind, batch = PF_INPUT_U8_NHWC, x.shape[0]
+        elif x.dtype == np.float32:
+            kind, batch = PF_INPUT_F32_NCHW, x.shape[0]
+        else:
+            raise TypeError("landmark input must be uint8 NHWC or float32 NCHW")
+        x = np.ascontiguousarray(x)
+        loc = np.empty((batch, 196), np.float32)
+        score = np.empty((batch, 98), np.float32)
+        self._check(self.lib.pf_landmark_forward(self.h, _ptr(x), kind, PF_MEM_HOST, batch, _ptr(loc), _ptr(score),
+                                                 PF_MEM_HOST), "pf_landmark_forward")
+        return loc, score
+
+    def landmark_forward_device(self, d_input: int, kind: int, batch: int, d_loc: int = 0, d_score: int = 0):
+        """Same on device pointers (bench): nothing crosses PCIe."""
+        self._check(self.lib.pf_landmark_forward(self.h, _ptr(d_input), kind, PF_MEM_DEVICE, batch,
+                                                 _ptr(d_loc) if d_loc else None, _ptr(d_score) if d_score else None,
+                                                 PF_MEM_DEVICE), "pf_landmark_forward")
+
+    def detector_forward(self, x: np.ndarray, rows: int = 15120) -> np.ndarray:
+        if x.dtype == np.uint8:
+            kind = PF_INPUT_U8_NHWC
+        elif x.dtype == np.float32:
+            kind = PF_INPUT_F32_NCHW
+        else:
+            raise TypeError("detector input must be uint8 NHWC or float32 NCHW")
+        x = np.ascontiguousarray(x)
+        batch = x.shape[0]
+        out = np.empty((batch, rows, 16), np.float32)
+        self._check(self.lib.pf_detector_forward(self.h, _ptr(x), kind, PF_MEM_HOST, batch, _ptr(out), PF_MEM_HOST),
+                    "pf_detector_forward")
+        return out
+
+    def read_tensor(self, slot: int, tensor_id: int, batch: int, shape_hwc) -> np.ndarray:
+        h, w, c = shape_hwc
+        out = np.empty((batch, h, w, c), np.float32)
+        self._check(self.lib.pf_read_tensor(self.h, slot, tensor_id, batch,
+                                            out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pf_read_tensor")
+        return out
+
+    # ---- pipeline seams -----------------------------------------------------------------------
+    def detect(self, image_bgr: np.ndarray, score_thres: float, iou_thres: float, max_n: int = 1024) -> np.ndarray:
+        img = np.ascontiguousarray(image_bgr)
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        boxes = np.empty((max_n, 16), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.pf_detect(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                       score_thres, iou_thres, boxes.ctypes.data_as(C.POINTER(C.c_float)), max_n,
+                                       C.byref(n)), "pf_detect")
+        return boxes[:n.value].copy()
+
+    def landmarks(self, image_bgr: np.ndarray, boxes: np.ndarray):
+        img = np.ascontiguousarray(image_bgr)
+        b = np.ascontiguousarray(np.asarray(boxes, np.float32)[:, :4])
+        n = b.shape[0]
+        kps = np.zeros((n, 98, 2), np.float32)
+        scores = np.zeros((n, 98), np.float32)
+        valid = np.zeros((n,), np.int32)
+        if n:
+            self._check(self.lib.pf_landmarks(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1],
+                                              img.strides[0], b.ctypes.data_as(C.POINTER(C.c_float)), n,
+                                              kps.ctypes.data_as(C.POINTER(C.c_float)),
+                                              scores.ctypes.data_as(C.POINTER(C.c_float)),
+                                              valid.ctypes.data_as(C.POINTER(C.c_int))), "pf_landmarks")
+        return kps, scores, valid.astype(bool)
+
+    def run_frames(self, frames: np.ndarray, score_thres: float, iou_thres: float, min_face: float, top_k: int,
+                   planted_rows: Optional[np.ndarray] = None):
+        fr = np.ascontiguousarray(frames)
+        assert fr.dtype == np.uint8 and fr.ndim == 4 and fr.shape[3] == 3
+        F, H, W, _ = fr.shape
+        counts = np.zeros((F,), np.int32)
+        boxes = np.zeros((F, top_k, 4), np.float32)
+        kps = np.zeros((F, top_k, 98, 2), np.float32)
+        scores = np.zeros((F, top_k, 98), np.float32)
+        if planted_rows is None:
+            rc = self.lib.pf_run_frames(self.h, _ptr(fr), PF_MEM_HOST, F, H, W, score_thres, iou_thres, min_face,
+                                        top_k, _ptr(counts), _ptr(boxes), _ptr(kps), _ptr(scores), PF_MEM_HOST)
+        else:
+            pr = np.ascontiguousarray(planted_rows, np.float32)
+            rc = self.lib.pf_run_frames_planted(self.h, _ptr(fr), PF_MEM_HOST, F, H, W, _ptr(pr), pr.shape[1],
+                                                score_thres, iou_thres, min_face, top_k, _ptr(counts), _ptr(boxes),
+                                                _ptr(kps), _ptr(scores), PF_MEM_HOST)
+        self._check(rc, "pf_run_frames")
+        return counts, boxes, kps, scores
+
+    def run_frames_device(self, d_frames: int, F: int, H: int, W: int, score_thres: float, iou_thres: float,
+                          min_face: float, top_k: int, d_planted: int = 0, rows: int = 0, d_counts: int = 0,
+                          d_boxes: int = 0, d_kps: int = 0, d_scores: int = 0):
+        rc = self.lib.pf_run_frames_planted(self.h, _ptr(d_frames), PF_MEM_DEVICE, F, H, W,
+                                            _ptr(d_planted) if d_planted else None, rows, score_thres, iou_thres,
+                                            min_face, top_k, _ptr(d_counts) if d_counts else None,
+                                            _ptr(d_boxes) if d_boxes else None, _ptr(d_kps) if d_kps else None,
+                                            _ptr(d_scores) if d_scores else None, PF_MEM_DEVICE)
+        self._check(rc, "pf_run_frames_planted")
+
+    # ---- profiling ----------------------------------------------------------------------------
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.pf_profile_enable(self.h, 1 if on else 0), "pf_profile_enable")
+
+    def profile_fetch(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        cnt = (C.c_int * 64)()
+        n = C.c_int(0)
+        self._check(self.lib.pf_profile_fetch(self.h, names, 4096, ms, cnt, 64, C.byref(n)), "pf_profile_fetch")
+        tags = [t for t in names.value.decode().split("\n") if t]
+        return {tags[k]: (float(ms[k]), int(cnt[k])) for k in range(n.value)}

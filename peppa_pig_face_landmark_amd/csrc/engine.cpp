@@ -1,0 +1,499 @@
+// peppa-hip engine: program executor + C ABI (include/peppa_hip.h).
+//
+// One pf_handle = one HIP device + one stream + up to PF_NET_SLOTS loaded network programs.
+// A program (pf_program.h) is executed as a straight-line sequence of fused-layer kernel launches
+// over a static activation arena; nothing is allocated on the hot path.
+#include "../../include/peppa_hip.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "k_conv_gemm.h"
+#include "k_layers.h"
+#include "k_prepost.h"
+#include "pf_program.h"
+
+
+namespace {
+
+struct Program {
+    bool loaded = false;
+    PfHeader hdr{};
+    std::vector<PfBufRec> bufs;
+    std::vector<PfTensorRec> tens;
+    std::vector<PfOpRec> ops;
+    char* d_const = nullptr;
+    char* d_arena = nullptr;
+    size_t arena_bytes = 0;
+    int max_batch = 0;
+    int esize = 2;
+
+    char* buf_ptr(int b) const { return d_arena + (size_t)bufs[b].offset_units * 256 * (size_t)max_batch; }
+    size_t buf_item_bytes(int b) const {
+        const int e = bufs[b].etype;
+        const size_t es = e == PF_ELEM_ACT ? (size_t)esize : (e == PF_ELEM_U8 ? 1 : 4);
+        return (size_t)bufs[b].elems_per_item * es;
+    }
+    char* tensor_ptr(int t) const { return buf_ptr(tens[t].buf) + (size_t)tens[t].coff * esize; }
+    const void* cptr(int off) const { return off < 0 ? nullptr : (const void*)(d_const + off); }
+};
+
+struct ProfEntry { double ms = 0; int count = 0; };
+
+}  // namespace
+
+struct pf_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Program prog[PF_NET_SLOTS];
+    std::string err;
+    // staging for host-side inputs / outputs
+    char* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    // pipeline scratch (k_prepost)
+    PipelineScratch pipe;
+    // profiling
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::vector<std::string> prof_order;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static std::string g_create_error;
+
+#define PF_FAIL(h, ...)                                   \
+    do {                                                  \
+        char _b[512];                                     \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);            \
+        (h)->err = _b;                                    \
+        return 1;                                         \
+    } while (0)
+
+#define PF_HIP(h, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) PF_FAIL(h, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// profiling helper: wraps one launch in an event pair when enabled
+struct ProfScope {
+    pf_handle* h;
+    const char* tag;
+    ProfScope(pf_handle* h_, const char* tag_) : h(h_), tag(tag_) {
+        if (h->profiling) (void)hipEventRecord(h->ev0, h->stream);
+    }
+    ~ProfScope() {
+        if (!h->profiling) return;
+        (void)hipEventRecord(h->ev1, h->stream);
+        (void)hipEventSynchronize(h->ev1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        auto it = h->prof.find(tag);
+        if (it == h->prof.end()) { h->prof_order.push_back(tag); it = h->prof.emplace(tag, ProfEntry()).first; }
+        it->second.ms += ms;
+        it->second.count += 1;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B) {
+    const int32_t* f = op.f;
+    const PfTensorRec& ti = p.tens[f[0]];
+    const PfTensorRec& to = p.tens[f[1]];
+    ConvGemmArgs a{};
+    a.in = p.tensor_ptr(f[0]);
+    a.wt = p.cptr(f[2]);
+    a.bias = (const float*)p.cptr(f[3]);
+    a.out = p.tensor_ptr(f[1]);
+    a.res = f[4] >= 0 ? p.tensor_ptr(f[4]) : nullptr;
+    a.resLd = f[4] >= 0 ? p.tens[f[4]].ld : 0;
+    a.gate = f[5] >= 0 ? (const float*)p.buf_ptr(f[5]) : nullptr;
+    a.fbias = f[6] >= 0 ? (const float*)p.buf_ptr(f[6]) : nullptr;
+    a.amax_val = f[17] >= 0 ? (float*)p.buf_ptr(f[17]) : nullptr;
+    a.amax_idx = f[18] >= 0 ? (int*)p.buf_ptr(f[18]) : nullptr;
+    a.B = B; a.inH = ti.H; a.inW = ti.W; a.inC = ti.C; a.inLd = ti.ld;
+    a.outH = to.H; a.outW = to.W; a.N = f[14]; a.Npad = f[13]; a.outLd = to.ld; a.outCs = f[16];
+    a.KH = f[7]; a.KW = f[8]; a.stride = f[9]; a.pad = f[10]; a.dil = f[11]; a.Cpad = f[12];
+    a.act = f[15]; a.amaxN = f[19]; a.store_out = f[20];
+    int cfg = f[21];
+    if (cfg < 0) cfg = a.Npad > 64 ? 0 : (a.Npad > 32 ? 1 : (a.Npad > 16 ? 2 : 3));
+    const int M = B * a.outH * a.outW;
+    static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256}, bn[PF_CONV_NCFG] = {128, 64, 32, 16};
+    if (a.amax_val && ((a.outH * a.outW) % bm[cfg]) != 0) PF_FAIL(h, "argmax conv: H*W=%d not a multiple of BM=%d", a.outH * a.outW, bm[cfg]);
+    dim3 grid(pf_div_up(M, bm[cfg]), pf_div_up(a.Npad, bn[cfg]));
+    ProfScope ps(h, a.KH == 1 ? (a.amax_val ? "conv1x1_argmax" : "conv1x1") : "conv3x3");
+    switch (cfg) {
+        case 0: PF_LAUNCH((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), h->stream, a); break;
+        case 1: PF_LAUNCH((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), h->stream, a); break;
+        case 2: PF_LAUNCH((conv_gemm_kernel<T, 256, 32, 4, 1>), grid, dim3(256), h->stream, a); break;
+        default: PF_LAUNCH((conv_gemm_kernel<T, 256, 16, 4, 1>), grid, dim3(256), h->stream, a); break;
+    }
+    return 0;
+}
+
+template <typename T>
+static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
+    Program& p = h->prog[slot];
+    constexpr int VE = PfVec<T>::N;
+    for (size_t oi = 0; oi < p.ops.size(); ++oi) {
+        const PfOpRec& op = p.ops[oi];
+        const int32_t* f = op.f;
+        switch (op.code) {
+            case PF_OP_STEM: {
+                const PfTensorRec& to = p.tens[f[1]];
+                StemArgs a{};
+                a.in = f[0] < 0 ? d_input : (const void*)p.tensor_ptr(f[0]);
+                a.in_f32_nchw = (f[0] < 0 && input_kind == PF_INPUT_F32_NCHW) ? 1 : 0;
+                a.wt = (const float*)p.cptr(a.in_f32_nchw ? f[5] : f[2]);
+                a.bias = (const float*)p.cptr(f[3]);
+                a.out = p.tensor_ptr(f[1]);
+                a.B = B; a.inH = p.hdr.in_h; a.inW = p.hdr.in_w;
+                a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.act = f[4];
+                ProfScope ps(h, "stem_conv");
+                PF_LAUNCH((stem_conv_kernel<T>), dim3(pf_div_up(B * to.H * to.W, 256)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_CONV:
+                if (launch_conv<T>(h, p, op, B)) return 1;
+                break;
+            case PF_OP_DW: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                const PfTensorRec& to = p.tens[f[1]];
+                DwArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.wt = p.cptr(f[2]); a.bias = (const float*)p.cptr(f[3]);
+                a.out = p.tensor_ptr(f[1]);
+                a.B = B; a.inH = ti.H; a.inW = ti.W; a.C = ti.C; a.inLd = ti.ld;
+                a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
+                a.K = f[4]; a.stride = f[5]; a.pad = f[6]; a.dil = f[7]; a.act = f[8];
+                const long long total = (long long)B * to.H * to.W * (ti.C / VE);
+                ProfScope ps(h, "dw_conv");
+                PF_LAUNCH((dw_conv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_UPCAT: {
+                const PfTensorRec& tl = p.tens[f[0]];
+                const PfTensorRec& tk = p.tens[f[1]];
+                const PfTensorRec& to = p.tens[f[2]];
+                UpcatArgs a{};
+                a.lo = p.tensor_ptr(f[0]); a.skip = p.tensor_ptr(f[1]); a.out = p.tensor_ptr(f[2]);
+                a.B = B; a.loH = tl.H; a.loW = tl.W; a.C1 = tl.C; a.loLd = tl.ld;
+                a.C2 = tk.C; a.skipLd = tk.ld; a.outLd = to.ld;
+                const long long total = (long long)B * to.H * to.W * ((tl.C + tk.C) / VE);
+                ProfScope ps(h, "upsample_concat");
+                PF_LAUNCH((upsample_concat_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_GAP: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                GapArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.out = (float*)p.buf_ptr(f[1]);
+                a.B = B; a.HW = ti.H * ti.W; a.C = ti.C; a.ld = ti.ld;
+                ProfScope ps(h, "gap");
+                PF_LAUNCH((gap_kernel<T>), dim3(pf_div_up(ti.C / VE, 8), B), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_FC: {
+                FcArgs a{};
+                a.x = (const float*)p.buf_ptr(f[0]); a.y = (float*)p.buf_ptr(f[1]);
+                a.wt = (const float*)p.cptr(f[2]); a.bias = (const float*)p.cptr(f[3]);
+                a.B = B; a.K = f[4]; a.N = f[5]; a.act = f[6];
+                a.scale2 = (const float*)p.cptr(f[7]); a.shift2 = (const float*)p.cptr(f[8]); a.act2 = f[9];
+                ProfScope ps(h, "fc");
+                PF_LAUNCH(fc_kernel, dim3(pf_div_up(a.N, 256), B), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_SCSE: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                const PfTensorRec& to = p.tens[f[1]];
+                ScseArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.out = p.tensor_ptr(f[1]);
+                a.cse = (const float*)p.buf_ptr(f[2]); a.sse_w = (const float*)p.cptr(f[3]);
+                memcpy(&a.sse_b, &f[4], 4);
+                a.B = B; a.HW = ti.H * ti.W; a.C = ti.C; a.ld = ti.ld; a.outLd = to.ld;
+                const int lpp = ti.C / VE;
+                if (lpp < 1 || lpp > 64 || (lpp & (lpp - 1))) PF_FAIL(h, "scse: C/VE=%d must be a power of two <= 64", lpp);
+                const long long total = (long long)B * a.HW;
+                ProfScope ps(h, "scse");
+                PF_LAUNCH((scse_kernel<T>), dim3((unsigned)((total + 256 / lpp - 1) / (256 / lpp))), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_HMDEC: {
+                const PfTensorRec& tf = p.tens[f[2]];
+                HmDecodeArgs a{};
+                a.amax_val = (const float*)p.buf_ptr(f[0]); a.amax_idx = (const int*)p.buf_ptr(f[1]);
+                a.feat = p.tensor_ptr(f[2]); a.off_wt = (const float*)p.cptr(f[3]); a.off_bias = (const float*)p.cptr(f[4]);
+                a.P = f[5]; a.nslots = f[6];
+                a.loc = (float*)p.buf_ptr(f[7]); a.score = (float*)p.buf_ptr(f[8]);
+                a.crop = h->pipe.d_crop_for_decode; a.kps = h->pipe.d_kps_for_decode;
+                a.B = B; a.H = tf.H; a.W = tf.W; a.C = tf.C; a.featLd = tf.ld;
+                ProfScope ps(h, "hm_decode");
+                PF_LAUNCH((hm_decode_kernel<T>), dim3(pf_div_up(B * a.P, 4)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_MAXPOOL: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                const PfTensorRec& to = p.tens[f[1]];
+                PoolArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.out = p.tensor_ptr(f[1]);
+                a.B = B; a.inH = ti.H; a.inW = ti.W; a.C = ti.C; a.inLd = ti.ld;
+                a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
+                const long long total = (long long)B * to.H * to.W * (ti.C / VE);
+                ProfScope ps(h, "maxpool");
+                PF_LAUNCH((maxpool2_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_COPY: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                const PfTensorRec& to = p.tens[f[1]];
+                CopyArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.out = p.tensor_ptr(f[1]);
+                a.B = B; a.inH = ti.H; a.inW = ti.W; a.C = ti.C; a.inLd = ti.ld; a.outLd = to.ld;
+                a.outCs = f[2]; a.up = f[3];
+                const long long total = (long long)B * ti.H * a.up * ti.W * a.up * (ti.C / VE);
+                ProfScope ps(h, "copy_channels");
+                PF_LAUNCH((copy_channels_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_DETDEC: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                DetDecArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.rows = (float*)p.buf_ptr(f[1]);
+                a.row0 = f[2]; memcpy(&a.stride, &f[3], 4); a.anchors = (const float*)p.cptr(f[4]);
+                a.nrows_total = f[5];
+                a.B = B; a.ny = ti.H; a.nx = ti.W; a.ld = ti.ld;
+                const long long total = (long long)B * 3 * ti.H * ti.W;
+                ProfScope ps(h, "detect_decode");
+                PF_LAUNCH((detect_decode_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                break;
+            }
+            default:
+                PF_FAIL(h, "unknown op code %d at op %zu", op.code, oi);
+        }
+    }
+    PF_HIP(h, hipGetLastError());
+    return 0;
+}
+
+static int run_program(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
+    Program& p = h->prog[slot];
+    if (!p.loaded) PF_FAIL(h, "no program loaded in slot %d", slot);
+    if (B < 1 || B > p.max_batch) PF_FAIL(h, "batch %d outside [1, %d]", B, p.max_batch);
+    return p.hdr.dtype == PF_DTYPE_F16 ? run_program_t<pf_half>(h, slot, d_input, input_kind, B)
+                                       : run_program_t<float>(h, slot, d_input, input_kind, B);
+}
+
+static int ensure_stage(pf_handle* h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return 0;
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    h->d_stage = nullptr;
+    h->stage_bytes = 0;
+    PF_HIP(h, hipMalloc((void**)&h->d_stage, bytes));
+    h->stage_bytes = bytes;
+    return 0;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* pf_version(void) { return "peppa-hip 0.1 " PF_BUILD_TAG; }
+
+int pf_create(int device_id, pf_handle** out) {
+    if (!out) return 1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device visible (the engine has no CPU fallback)"; return 1; }
+    if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return 1; }
+    if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return 1; }
+    pf_handle* h = new pf_handle();
+    h->device = device_id;
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        g_create_error = "stream/event creation failed";
+        delete h;
+        return 1;
+    }
+    *out = h;
+    return 0;
+}
+
+void pf_destroy(pf_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->prog) {
+        if (p.d_const) (void)hipFree(p.d_const);
+        if (p.d_arena) (void)hipFree(p.d_arena);
+    }
+    if (h->d_stage) (void)hipFree(h->d_stage);
+    h->pipe.release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* pf_last_error(pf_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int pf_sync(pf_handle* h) {
+    if (!h) return 1;
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int max_batch) {
+    if (!h) return 1;
+    if (slot < 0 || slot >= PF_NET_SLOTS) PF_FAIL(h, "slot %d out of range", slot);
+    if (!blob || bytes < sizeof(PfHeader)) PF_FAIL(h, "program blob too small");
+    if (max_batch < 1) PF_FAIL(h, "max_batch must be >= 1");
+    PF_HIP(h, hipSetDevice(h->device));
+    PfHeader hd;
+    memcpy(&hd, blob, sizeof(hd));
+    if (hd.magic != PF_PROGRAM_MAGIC) PF_FAIL(h, "bad program magic 0x%08x", hd.magic);
+    if (hd.version != PF_PROGRAM_VERSION) PF_FAIL(h, "program version %d, engine expects %d", hd.version, PF_PROGRAM_VERSION);
+    if (hd.dtype != PF_DTYPE_F16 && hd.dtype != PF_DTYPE_F32) PF_FAIL(h, "bad dtype %d", hd.dtype);
+    size_t off = sizeof(PfHeader);
+    const size_t need = off + (size_t)hd.n_bufs * sizeof(PfBufRec) + (size_t)hd.n_tensors * sizeof(PfTensorRec) +
+                        (size_t)hd.n_ops * sizeof(PfOpRec);
+    if (bytes < need) PF_FAIL(h, "program blob truncated (tables)");
+    Program& p = h->prog[slot];
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (p.d_const) { (void)hipFree(p.d_const); p.d_const = nullptr; }
+    if (p.d_arena) { (void)hipFree(p.d_arena); p.d_arena = nullptr; }
+    p.loaded = false;
+    p.hdr = hd;
+    p.esize = hd.dtype == PF_DTYPE_F16 ? 2 : 4;
+    const char* src = (const char*)blob;
+    p.bufs.resize(hd.n_bufs);
+    memcpy(p.bufs.data(), src + off, (size_t)hd.n_bufs * sizeof(PfBufRec)); off += (size_t)hd.n_bufs * sizeof(PfBufRec);
+    p.tens.resize(hd.n_tensors);
+    memcpy(p.tens.data(), src + off, (size_t)hd.n_tensors * sizeof(PfTensorRec)); off += (size_t)hd.n_tensors * sizeof(PfTensorRec);
+    p.ops.resize(hd.n_ops);
+    memcpy(p.ops.data(), src + off, (size_t)hd.n_ops * sizeof(PfOpRec)); off += (size_t)hd.n_ops * sizeof(PfOpRec);
+    off = (off + 255) / 256 * 256;
+    if (bytes < off + (size_t)hd.const_bytes) PF_FAIL(h, "program blob truncated (constants)");
+    // validate indices once so the hot path can trust them
+    for (const auto& t : p.tens)
+        if (t.buf < 0 || t.buf >= hd.n_bufs) PF_FAIL(h, "tensor references buffer %d", t.buf);
+    for (int b = 0; b < hd.n_bufs; ++b) {
+        const size_t units = (p.buf_item_bytes(b) + 255) / 256;
+        if ((size_t)p.bufs[b].offset_units + units > (size_t)hd.arena_units_per_item) PF_FAIL(h, "buffer %d outside the arena", b);
+    }
+    PF_HIP(h, hipMalloc((void**)&p.d_const, std::max<size_t>(hd.const_bytes, 256)));
+    PF_HIP(h, hipMemcpy(p.d_const, src + off, hd.const_bytes, hipMemcpyHostToDevice));
+    p.max_batch = max_batch;
+    p.arena_bytes = (size_t)hd.arena_units_per_item * 256 * (size_t)max_batch;
+    PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes));
+    PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
+    p.loaded = true;
+    return 0;
+}
+
+static int net_forward_common(pf_handle* h, int slot, const void* input, int input_kind, int mem, int batch,
+                              size_t in_item_bytes) {
+    PF_HIP(h, hipSetDevice(h->device));
+    const void* d_in = input;
+    if (mem == PF_MEM_HOST) {
+        if (ensure_stage(h, in_item_bytes * batch)) return 1;
+        PF_HIP(h, hipMemcpyAsync(h->d_stage, input, in_item_bytes * batch, hipMemcpyHostToDevice, h->stream));
+        d_in = h->d_stage;
+    }
+    return run_program(h, slot, d_in, input_kind, batch);
+}
+
+static int copy_out(pf_handle* h, const void* d_src, void* dst, size_t bytes, int out_mem) {
+    if (!dst) return 0;
+    PF_HIP(h, hipMemcpyAsync(dst, d_src, bytes, out_mem == PF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+
+int pf_landmark_forward(pf_handle* h, const void* input, int input_kind, int mem, int batch,
+                        float* loc_fix, float* score, int out_mem) {
+    if (!h) return 1;
+    Program& p = h->prog[PF_NET_LANDMARK];
+    if (!p.loaded) PF_FAIL(h, "landmark program not loaded");
+    const size_t px = (size_t)p.hdr.in_h * p.hdr.in_w * 3;
+    h->pipe.d_crop_for_decode = nullptr;
+    h->pipe.d_kps_for_decode = nullptr;
+    if (net_forward_common(h, PF_NET_LANDMARK, input, input_kind, mem, batch, input_kind == PF_INPUT_U8_NHWC ? px : px * 4)) return 1;
+    if (copy_out(h, p.buf_ptr(p.hdr.out_buf0), loc_fix, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf0), out_mem)) return 1;
+    if (copy_out(h, p.buf_ptr(p.hdr.out_buf1), score, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf1), out_mem)) return 1;
+    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_detector_forward(pf_handle* h, const void* input, int input_kind, int mem, int batch, float* rows_out, int out_mem) {
+    if (!h) return 1;
+    Program& p = h->prog[PF_NET_DETECTOR];
+    if (!p.loaded) PF_FAIL(h, "detector program not loaded");
+    const size_t px = (size_t)p.hdr.in_h * p.hdr.in_w * 3;
+    if (net_forward_common(h, PF_NET_DETECTOR, input, input_kind, mem, batch, input_kind == PF_INPUT_U8_NHWC ? px : px * 4)) return 1;
+    if (copy_out(h, p.buf_ptr(p.hdr.out_buf0), rows_out, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf0), out_mem)) return 1;
+    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_read_tensor(pf_handle* h, int slot, int tensor_id, int batch, float* out_host, size_t out_elems) {
+    if (!h) return 1;
+    if (slot < 0 || slot >= PF_NET_SLOTS || !h->prog[slot].loaded) PF_FAIL(h, "slot %d not loaded", slot);
+    Program& p = h->prog[slot];
+    if (tensor_id < 0 || tensor_id >= (int)p.tens.size()) PF_FAIL(h, "tensor id %d out of range", tensor_id);
+    const PfTensorRec& t = p.tens[tensor_id];
+    const size_t n = (size_t)batch * t.H * t.W * t.C;
+    if (out_elems < n) PF_FAIL(h, "output too small: %zu < %zu", out_elems, n);
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t item_elems = (size_t)t.H * t.W * t.ld;
+    std::vector<char> tmp(item_elems * p.esize * batch);
+    PF_HIP(h, hipMemcpy(tmp.data(), p.tensor_ptr(tensor_id) - (size_t)t.coff * p.esize, tmp.size(), hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+        for (size_t px = 0; px < (size_t)t.H * t.W; ++px)
+            for (int c = 0; c < t.C; ++c) {
+                const size_t si = (size_t)b * item_elems + px * t.ld + t.coff + c;
+                float v;
+                if (p.esize == 2) v = (float)((const pf_half*)tmp.data())[si];
+                else v = ((const float*)tmp.data())[si];
+                out_host[((size_t)b * t.H * t.W + px) * t.C + c] = v;
+            }
+    return 0;
+}
+
+int pf_profile_enable(pf_handle* h, int on) {
+    if (!h) return 1;
+    h->profiling = on != 0;
+    h->prof.clear();
+    h->prof_order.clear();
+    return 0;
+}
+
+int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int* counts, int cap, int* n_out) {
+    if (!h) return 1;
+    std::string joined;
+    int n = 0;
+    for (const auto& tag : h->prof_order) {
+        if (n >= cap) break;
+        const ProfEntry& e = h->prof[tag];
+        if (ms) ms[n] = (float)e.ms;
+        if (counts) counts[n] = e.count;
+        joined += tag;
+        joined += '\n';
+        ++n;
+    }
+    if (names && names_cap) {
+        const size_t c = std::min(names_cap - 1, joined.size());
+        memcpy(names, joined.data(), c);
+        names[c] = 0;
+    }
+    if (n_out) *n_out = n;
+    return 0;
+}
+
+}  // extern "C"
+
+#include "pipeline.inl"

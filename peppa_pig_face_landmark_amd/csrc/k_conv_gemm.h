@@ -1,0 +1,287 @@
+// Implicit-GEMM convolution on the CDNA4 matrix cores (1x1 and kxk dense convs, NHWC).
+//
+// Replaces what onnxruntime's CPU conv kernels compute for the reference
+// (Skps/core/api/onnx_model_base.py:23-24) for every dense conv of the landmark regressor
+// (TRAIN/face_landmark/lib/core/base_trainer/model.py: 1x1 expand/project convs of the encoder,
+// ASPP :70-83, DecoderBlock conv1/conv2 :146-172, hm head :271) and of the detector.
+//
+// GEMM view:  D[n][m] = sum_k  W[n][k] * X[m][k]
+//   m = output pixel (b, oy, ox) flattened,  n = output channel,  k = (tap, input channel)
+//   MFMA "A" operand = weight rows, "B" operand = pixels, so each lane ends up owning 4 consecutive
+//   output channels of one pixel (contiguous in NHWC -> one 8/16-byte store per accumulator).
+//
+// Tiling: block = 256 threads = 4 waves arranged WARPS_M x WARPS_N over a BM(pixels) x BN(channels)
+// tile; K advances 64 bytes per step (32 f16 / 16 f32 per row) through two LDS stages
+// (register-staged global->LDS copy overlapping the MFMAs of the previous stage).  The 16-byte
+// chunk index inside a 64-byte LDS row is rotated by 2*(row>>2) so that the four 16-lane groups
+// of a ds_read_b128 fragment read hit 16 distinct bank slots.
+//
+// Fused epilogue: + bias[n] (BN folded) (+ per-face bias) (+ residual) -> activation -> store,
+// optional SE gate on the input channels (applied while staging), optional per-(face,channel)
+// running arg-max for the heat-map head (COTRAIN.postp, model.py:520-522).
+#pragma once
+#include "pf_common.h"
+
+struct ConvGemmArgs {
+    const void* in;
+    const void* wt;       // [Npad][KH*KW][Cpad], element type T, zero padded
+    const float* bias;    // [Npad]
+    void* out;
+    const void* res;      // residual (same pixel indexing as out) or nullptr
+    const float* gate;    // [B][inC] multiplicative gate on input channels, or nullptr
+    const float* fbias;   // [B][Npad] per-face bias, or nullptr
+    float* amax_val;      // [B][amaxN][nslots] partial maxima, or nullptr
+    int* amax_idx;
+    int B, inH, inW, inC, inLd;
+    int outH, outW, N, Npad, outLd, outCs;  // channel n is stored at element n*outCs of the pixel row
+    int resLd;
+    int KH, KW, stride, pad, dil, Cpad;
+    int act;
+    int amaxN;
+    int store_out;
+};
+
+template <typename T> struct ConvMma;
+template <> struct ConvMma<pf_half> {
+    __device__ static __forceinline__ pf_f32x4 run(pf_half8 w, pf_half8 x, pf_f32x4 c) {
+        return pf_mfma_16x16x32_f16(w, x, c);
+    }
+};
+template <> struct ConvMma<float> {
+    __device__ static __forceinline__ pf_f32x4 run(pf_f32x4 w, pf_f32x4 x, pf_f32x4 c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = pf_mfma_16x16x4_f32(w[j], x[j], c);
+        return c;
+    }
+};
+
+__device__ __forceinline__ int pf_lds_chunk_off(int row, int chunk) {
+    return row * 64 + (((chunk + 2 * (row >> 2)) & 3) << 4);
+}
+
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;       // elements per 16-byte chunk
+    constexpr int KE = 4 * VE;            // elements per 64-byte K step
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int XROWS = BM / 64;                     // pixel rows staged per thread
+    constexpr int WROWS = (BN + 63) / 64;              // weight rows staged per thread
+    constexpr int STAGE_BYTES = (BM + BN) * 64;
+    static_assert(WARPS_M * WARPS_N == 4, "4 waves per block");
+    static_assert(BM % 64 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int OHW = a.outH * a.outW;
+    const int M = a.B * OHW;
+    const T* __restrict__ in = static_cast<const T*>(a.in);
+    const T* __restrict__ wt = static_cast<const T*>(a.wt);
+
+    // ---- per-thread staging geometry -------------------------------------------------
+    const int chunk = t & 3;
+    const int srow = t >> 2;  // 0..63
+    int xb[XROWS], xiy0[XROWS], xix0[XROWS];
+    bool xvalid[XROWS];
+#pragma unroll
+    for (int r = 0; r < XROWS; ++r) {
+        const int m = m0 + srow + 64 * r;
+        xvalid[r] = m < M;
+        const int mm = xvalid[r] ? m : 0;
+        const int b = mm / OHW;
+        const int rem = mm - b * OHW;
+        const int oy = rem / a.outW;
+        const int ox = rem - oy * a.outW;
+        xb[r] = b;
+        xiy0[r] = oy * a.stride - a.pad;
+        xix0[r] = ox * a.stride - a.pad;
+    }
+    const int taps = a.KH * a.KW;
+    const int cchunks = a.Cpad / KE;
+    const int nk = taps * cchunks;
+    const size_t wrow_stride = (size_t)taps * a.Cpad;
+
+    vec_t xreg[XROWS], wreg[WROWS];
+
+    auto load_tile = [&](int tap, int cc) {
+        const int ky = tap / a.KW;
+        const int kx = tap - ky * a.KW;
+        const int kelem = cc * KE + chunk * VE;
+        const bool kok = kelem < a.inC;
+#pragma unroll
+        for (int r = 0; r < XROWS; ++r) {
+            const int iy = xiy0[r] + ky * a.dil;
+            const int ix = xix0[r] + kx * a.dil;
+            const bool ok = xvalid[r] && kok && (unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW;
+            vec_t v = pf_zero_vec<T>();
+            if (ok) {
+                const size_t off = ((size_t)(xb[r] * a.inH + iy) * a.inW + ix) * a.inLd + kelem;
+                v = pf_ldv<T>(in + off);
+                if (a.gate) {
+                    const float* g = a.gate + (size_t)xb[r] * a.inC + kelem;
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) v[e] = (T)((float)v[e] * g[e]);
+                }
+            }
+            xreg[r] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r) {
+            const int row = srow + 64 * r;
+            const int n = n0 + row;
+            vec_t v = pf_zero_vec<T>();
+            if (row < BN && n < a.Npad) v = pf_ldv<T>(wt + (size_t)n * wrow_stride + (size_t)tap * a.Cpad + kelem);
+            wreg[r] = v;
+        }
+    };
+    auto store_tile = [&](int stage) {
+        unsigned char* xs = smem + stage * STAGE_BYTES;
+        unsigned char* ws = xs + BM * 64;
+#pragma unroll
+        for (int r = 0; r < XROWS; ++r)
+            *reinterpret_cast<vec_t*>(xs + pf_lds_chunk_off(srow + 64 * r, chunk)) = xreg[r];
+#pragma unroll
+        for (int r = 0; r < WROWS; ++r) {
+            const int row = srow + 64 * r;
+            if (row < BN) *reinterpret_cast<vec_t*>(ws + pf_lds_chunk_off(row, chunk)) = wreg[r];
+        }
+    };
+
+    pf_f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- main loop ---------------------------------------------------------------------
+    int tap = 0, cc = 0;
+    load_tile(tap, cc);
+    store_tile(0);
+    __syncthreads();
+    const int frow = lane & 15, fchunk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (++cc == cchunks) { cc = 0; ++tap; }
+            load_tile(tap, cc);
+        }
+        const unsigned char* xs = smem + cur * STAGE_BYTES;
+        const unsigned char* ws = xs + BM * 64;
+        vec_t xf[MT], wf[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            xf[i] = *reinterpret_cast<const vec_t*>(xs + pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            wf[j] = *reinterpret_cast<const vec_t*>(ws + pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk));
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[j][i] = ConvMma<T>::run(wf[j], xf[i], acc[j][i]);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    T* __restrict__ out = static_cast<T*>(a.out);
+    const T* __restrict__ res = static_cast<const T*>(a.res);
+    const int pcol = lane & 15;        // pixel within the 16-wide sub-tile
+    const int crow = (lane >> 4) * 4;  // first of the 4 channels this lane owns
+    const bool want_amax = a.amax_val != nullptr;
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + crow;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (n + r < a.Npad) ? a.bias[n + r] : 0.f;
+        float best_v[4];
+        int best_i[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { best_v[r] = -3.0e38f; best_i[r] = 0x7fffffff; }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WM + i * 16 + pcol;
+            const bool mok = m < M;
+            const int b = mok ? m / OHW : 0;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] + bv[r];
+            if (a.fbias && mok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.Npad) v[r] += a.fbias[(size_t)b * a.Npad + n + r];
+            }
+            if (res && mok) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < a.N) v[r] += (float)res[(size_t)m * a.resLd + n + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = pf_act(v[r], a.act);
+            if (want_amax && mok) {
+                const int local = m - b * OHW;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (v[r] > best_v[r]) { best_v[r] = v[r]; best_i[r] = local; }
+            }
+            if (a.store_out && mok) {
+                T* o = out + (size_t)m * a.outLd;
+                if (a.outCs == 1 && n + 3 < a.N) {
+                    if constexpr (sizeof(T) == 2) {
+                        pf_half4 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pk[r] = (pf_half)v[r];
+                        *reinterpret_cast<pf_half4*>(o + n) = pk;
+                    } else {
+                        pf_f32x4 pk;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pk[r] = v[r];
+                        *reinterpret_cast<pf_f32x4*>(o + n) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < a.N) o[(size_t)(n + r) * a.outCs] = (T)v[r];
+                }
+            }
+        }
+        if (want_amax) {
+            // all BM pixels of this block belong to one face (host guarantees OHW % BM == 0)
+#pragma unroll
+            for (int mask = 1; mask < 16; mask <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float ov = pf_shfl_xor_f32(best_v[r], mask);
+                    const int oi = pf_shfl_xor_i32(best_i[r], mask);
+                    if (ov > best_v[r] || (ov == best_v[r] && oi < best_i[r])) { best_v[r] = ov; best_i[r] = oi; }
+                }
+            }
+            if (pcol == 0 && m0 < M) {
+                const int b = m0 / OHW;
+                const int blocks_per_face = OHW / BM;
+                const int nslots = blocks_per_face * WARPS_M;
+                const int slot = ((m0 - b * OHW) / BM) * WARPS_M + wm;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r < a.amaxN) {
+                        const size_t o = ((size_t)b * a.amaxN + n + r) * nslots + slot;
+                        a.amax_val[o] = best_v[r];
+                        a.amax_idx[o] = best_i[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Tile configurations (BM x BN, waves M x N) picked by the host from the padded channel count.
+#define PF_CONV_CFGS(X) X(128, 128, 2, 2) X(128, 64, 2, 2) X(256, 32, 4, 1) X(256, 16, 4, 1)

@@ -1,0 +1,450 @@
+// Bandwidth-bound layer kernels of the landmark regressor / detector (NHWC, 16-byte vectors).
+//
+//   stem_conv_kernel      3x3 stride-2 conv on the 3-channel image (u8 NHWC or f32 NCHW input)
+//                         -- timm conv_stem (model.py:252-258) / yolov5-face StemBlock.stem_1
+//   dw_conv_kernel        depthwise kxk conv + bias + activation (MobileNetV3 blocks,
+//                         SeparableConv2d.conv_dw model.py:21-27)
+//   upsample_concat_kernel  F.interpolate(x2, bilinear, align_corners=False) + torch.cat
+//                         (DecoderBlock.forward model.py:184-189)
+//   gap_kernel            global average pool -> f32 [B][C]   (SE, cSE, ASPPPooling model.py:49)
+//   fc_kernel             tiny dense layers on pooled vectors (SE / cSE / ASPP pooling branch)
+//   scse_kernel           x*cSE + x*sSE                        (SCSEModule.forward model.py:129-130)
+//   hm_decode_kernel      final arg-max reduction + offset gather + landmark un-normalisation
+//                         (COTRAIN.postp model.py:511-554, face_landmark.py:112-113)
+#pragma once
+#include "pf_common.h"
+
+// --------------------------------------------------------------------------------------------
+struct StemArgs {
+    const void* in;       // u8 [B][H][W][3]  or  f32 [B][3][H][W]
+    const float* wt;      // [27][16] f32, index (ky*3+kx)*3+ci ; 1/255 folded for u8 input
+    const float* bias;    // [16]
+    void* out;            // T [B][outH][outW][16]
+    int in_f32_nchw;
+    int B, inH, inW, outH, outW, outLd, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
+    constexpr int CO = 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = a.B * a.outH * a.outW;
+    if (idx >= total) return;
+    const int b = idx / (a.outH * a.outW);
+    const int rem = idx - b * a.outH * a.outW;
+    const int oy = rem / a.outW, ox = rem - oy * a.outW;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = a.bias[c];
+    const unsigned char* in8 = static_cast<const unsigned char*>(a.in);
+    const float* inf = static_cast<const float*>(a.in);
+    const size_t plane = (size_t)a.inH * a.inW;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 - 1 + ky;
+        if ((unsigned)iy >= (unsigned)a.inH) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 - 1 + kx;
+            if ((unsigned)ix >= (unsigned)a.inW) continue;
+            float px[3];
+            if (a.in_f32_nchw) {
+                const size_t o = (size_t)b * 3 * plane + (size_t)iy * a.inW + ix;
+                px[0] = inf[o]; px[1] = inf[o + plane]; px[2] = inf[o + 2 * plane];
+            } else {
+                const size_t o = ((size_t)b * plane + (size_t)iy * a.inW + ix) * 3;
+                px[0] = (float)in8[o]; px[1] = (float)in8[o + 1]; px[2] = (float)in8[o + 2];
+            }
+            const float* w = a.wt + ((ky * 3 + kx) * 3) * CO;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) acc[c] = fmaf(px[ci], w[ci * CO + c], acc[c]);
+        }
+    }
+    T* o = static_cast<T*>(a.out) + (size_t)idx * a.outLd;
+    constexpr int VE = PfVec<T>::N;
+#pragma unroll
+    for (int v = 0; v < CO / VE; ++v) {
+        typename PfVec<T>::type pk;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) pk[e] = (T)pf_act(acc[v * VE + e], a.act);
+        pf_stv<T>(o + v * VE, pk);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+struct DwArgs {
+    const void* in;
+    const void* wt;     // T [K*K][C]
+    const float* bias;  // [C]
+    void* out;
+    int B, inH, inW, C, inLd, outH, outW, outLd, K, stride, pad, dil, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int CV = a.C / VE;
+    const long long total = (long long)a.B * a.outH * a.outW * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int ox = (int)(pix % a.outW);
+    const long long t2 = pix / a.outW;
+    const int oy = (int)(t2 % a.outH);
+    const int b = (int)(t2 / a.outH);
+    const T* in = static_cast<const T*>(a.in);
+    const T* wt = static_cast<const T*>(a.wt);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = a.bias[cv * VE + e];
+    for (int ky = 0; ky < a.K; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky * a.dil;
+        if ((unsigned)iy >= (unsigned)a.inH) continue;
+        for (int kx = 0; kx < a.K; ++kx) {
+            const int ix = ox * a.stride - a.pad + kx * a.dil;
+            if ((unsigned)ix >= (unsigned)a.inW) continue;
+            const vec_t x = pf_ldv<T>(in + ((size_t)(b * a.inH + iy) * a.inW + ix) * a.inLd + cv * VE);
+            const vec_t w = pf_ldv<T>(wt + (size_t)(ky * a.K + kx) * a.C + cv * VE);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] = fmaf((float)x[e], (float)w[e], acc[e]);
+        }
+    }
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) o[e] = (T)pf_act(acc[e], a.act);
+    pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
+}
+
+// --------------------------------------------------------------------------------------------
+struct UpcatArgs {
+    const void* lo;    // T [B][loH][loW][C1]  (upsampled x2, bilinear, half-pixel centres)
+    const void* skip;  // T [B][2loH][2loW][C2]
+    void* out;         // T [B][2loH][2loW][C1+C2]
+    int B, loH, loW, C1, loLd, C2, skipLd, outLd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_concat_kernel(UpcatArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int H = 2 * a.loH, W = 2 * a.loW;
+    const int CV = (a.C1 + a.C2) / VE;
+    const long long total = (long long)a.B * H * W * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int ox = (int)(pix % W);
+    const long long t2 = pix / W;
+    const int oy = (int)(t2 % H);
+    const int b = (int)(t2 / H);
+    const int c = cv * VE;
+    T* out = static_cast<T*>(a.out) + (size_t)pix * a.outLd + c;
+    if (c >= a.C1) {
+        pf_stv<T>(out, pf_ldv<T>(static_cast<const T*>(a.skip) + (size_t)pix * a.skipLd + (c - a.C1)));
+        return;
+    }
+    // source index = (dst + 0.5) / 2 - 0.5, clamped at 0 (torch area_pixel_compute_source_index)
+    float sy = (oy + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
+    float sx = (ox + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < a.loH - 1 ? 1 : 0), x1 = x0 + (x0 < a.loW - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* lo = static_cast<const T*>(a.lo) + (size_t)b * a.loH * a.loW * a.loLd + c;
+    const vec_t p00 = pf_ldv<T>(lo + ((size_t)y0 * a.loW + x0) * a.loLd);
+    const vec_t p01 = pf_ldv<T>(lo + ((size_t)y0 * a.loW + x1) * a.loLd);
+    const vec_t p10 = pf_ldv<T>(lo + ((size_t)y1 * a.loW + x0) * a.loLd);
+    const vec_t p11 = pf_ldv<T>(lo + ((size_t)y1 * a.loW + x1) * a.loLd);
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e)
+        o[e] = (T)(hy * (hx * (float)p00[e] + lx * (float)p01[e]) + ly * (hx * (float)p10[e] + lx * (float)p11[e]));
+    pf_stv<T>(out, o);
+}
+
+// --------------------------------------------------------------------------------------------
+struct GapArgs {
+    const void* in;  // T [B][HW][ld]
+    float* out;      // [B][C] mean over HW
+    int B, HW, C, ld;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gap_kernel(GapArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    __shared__ float red[32][8][VE];
+    const int t = threadIdx.x;
+    const int cvi = t & 7, prow = t >> 3;
+    const int cv = blockIdx.x * 8 + cvi;
+    const int b = blockIdx.y;
+    const int CV = a.C / VE;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (cv < CV) {
+        const T* in = static_cast<const T*>(a.in) + (size_t)b * a.HW * a.ld + cv * VE;
+        for (int p = prow; p < a.HW; p += 32) {
+            const vec_t x = pf_ldv<T>(in + (size_t)p * a.ld);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) acc[e] += (float)x[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[prow][cvi][e] = acc[e];
+    __syncthreads();
+    if (prow == 0 && cv < CV) {
+        const float inv = 1.0f / (float)a.HW;
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float s = 0.f;
+            for (int r = 0; r < 32; ++r) s += red[r][cvi][e];
+            a.out[(size_t)b * a.C + cv * VE + e] = s * inv;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+struct FcArgs {
+    const float* x;      // [B][K]
+    const float* wt;     // [K][N]  (transposed so that consecutive threads read consecutive n)
+    const float* bias;   // [N] or nullptr
+    const float* scale2; // optional second affine: y = act2(scale2*y + shift2)
+    const float* shift2;
+    float* y;            // [B][N]
+    int B, K, N, act, act2;
+};
+
+__global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (n >= a.N) return;
+    const float* x = a.x + (size_t)b * a.K;
+    float acc = a.bias ? a.bias[n] : 0.f;
+    for (int k = 0; k < a.K; ++k) acc = fmaf(a.wt[(size_t)k * a.N + n], x[k], acc);
+    acc = pf_act(acc, a.act);
+    if (a.scale2) acc = pf_act(a.scale2[n] * acc + a.shift2[n], a.act2);
+    a.y[(size_t)b * a.N + n] = acc;
+}
+
+// --------------------------------------------------------------------------------------------
+struct ScseArgs {
+    const void* in;      // T [B][HW][ld]
+    void* out;           // T [B][HW][outLd]
+    const float* cse;    // [B][C] channel gate (already sigmoid-ed)
+    const float* sse_w;  // [C] 1x1 conv to one channel
+    float sse_b;
+    int B, HW, C, ld, outLd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void scse_kernel(ScseArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int LPP = a.C / VE;  // lanes per pixel: power of two <= 64 (host checks)
+    const int ppb = 256 / LPP;
+    const int t = threadIdx.x;
+    const int cl = t % LPP;
+    const long long pix = (long long)blockIdx.x * ppb + t / LPP;
+    const long long total = (long long)a.B * a.HW;
+    const bool ok = pix < total;
+    const long long pp = ok ? pix : 0;
+    const int b = (int)(pp / a.HW);
+    const vec_t x = pf_ldv<T>(static_cast<const T*>(a.in) + (size_t)pp * a.ld + cl * VE);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) dot = fmaf((float)x[e], a.sse_w[cl * VE + e], dot);
+    for (int mask = 1; mask < LPP; mask <<= 1) dot += pf_shfl_xor_f32(dot, mask);
+    const float sse = 1.f / (1.f + expf(-(dot + a.sse_b)));
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) {
+        const float xv = (float)x[e];
+        o[e] = (T)(xv * a.cse[(size_t)b * a.C + cl * VE + e] + xv * sse);
+    }
+    if (ok) pf_stv<T>(static_cast<T*>(a.out) + (size_t)pp * a.outLd + cl * VE, o);
+}
+
+// --------------------------------------------------------------------------------------------
+struct HmDecodeArgs {
+    const float* amax_val;  // [B][P][nslots]
+    const int* amax_idx;
+    const void* feat;       // T [B][H*W][featLd] : input of the hm 1x1 conv (decx4)
+    const float* off_wt;    // [2P][C] f32 : rows P..3P of the hm conv (offset-x then offset-y)
+    const float* off_bias;  // [2P]
+    const float* crop;      // optional [B][5] = {w_crop, h_crop, x0, y0, add} (face_landmark.py:104)
+    float* loc;             // [B][2P] normalised (x0,y0,x1,y1,...)  == ONNX output 0
+    float* score;           // [B][P]                                == ONNX output 1
+    float* kps;             // optional [B][P][2] frame coordinates (face_landmark.py:112-113)
+    int B, P, nslots, H, W, C, featLd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void hm_decode_kernel(HmDecodeArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, p) pair handled by this wave
+    const bool ok = item < a.B * a.P;
+    const int it = ok ? item : 0;
+    const int b = it / a.P, p = it - b * a.P;
+    float bv = -3.0e38f;
+    int bi = 0x7fffffff;
+    for (int s = lane; s < a.nslots; s += 64) {
+        const float v = a.amax_val[(size_t)it * a.nslots + s];
+        const int i = a.amax_idx[(size_t)it * a.nslots + s];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+    for (int mask = 1; mask < 64; mask <<= 1) {
+        const float ov = pf_shfl_xor_f32(bv, mask);
+        const int oi = pf_shfl_xor_i32(bi, mask);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    const T* f = static_cast<const T*>(a.feat) + ((size_t)b * a.H * a.W + bi) * a.featLd;
+    float sx = 0.f, sy = 0.f;
+    for (int k = lane; k < a.C; k += 64) {
+        const float xv = (float)f[k];
+        sx = fmaf(a.off_wt[(size_t)p * a.C + k], xv, sx);
+        sy = fmaf(a.off_wt[(size_t)(a.P + p) * a.C + k], xv, sy);
+    }
+    for (int mask = 1; mask < 64; mask <<= 1) {
+        sx += pf_shfl_xor_f32(sx, mask);
+        sy += pf_shfl_xor_f32(sy, mask);
+    }
+    if (ok && lane == 0) {
+        const float ox = sx + a.off_bias[p], oy = sy + a.off_bias[a.P + p];
+        const float lx = ((float)(bi % a.W) + ox) / (float)a.W;
+        const float ly = ((float)(bi / a.W) + oy) / (float)a.H;
+        a.loc[(size_t)b * 2 * a.P + 2 * p] = lx;
+        a.loc[(size_t)b * 2 * a.P + 2 * p + 1] = ly;
+        a.score[(size_t)b * a.P + p] = bv;
+        if (a.kps && a.crop) {
+            const float* c = a.crop + (size_t)b * 5;
+            a.kps[((size_t)b * a.P + p) * 2] = (lx * c[0] + c[2]) - c[4];
+            a.kps[((size_t)b * a.P + p) * 2 + 1] = (ly * c[1] + c[3]) - c[4];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Detector-only helpers (yolov5-face: StemBlock max-pool, nearest upsample / channel shuffle copies)
+struct PoolArgs {
+    const void* in; void* out;
+    int B, inH, inW, C, inLd, outH, outW, outLd;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(PoolArgs a) {  // 2x2 stride 2, ceil_mode
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int CV = a.C / VE;
+    const long long total = (long long)a.B * a.outH * a.outW * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int ox = (int)(pix % a.outW);
+    const long long t2 = pix / a.outW;
+    const int oy = (int)(t2 % a.outH);
+    const int b = (int)(t2 / a.outH);
+    const T* in = static_cast<const T*>(a.in) + (size_t)b * a.inH * a.inW * a.inLd + cv * VE;
+    float m[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) m[e] = -3.0e38f;
+    for (int dy = 0; dy < 2; ++dy) {
+        const int iy = oy * 2 + dy;
+        if (iy >= a.inH) continue;
+        for (int dx = 0; dx < 2; ++dx) {
+            const int ix = ox * 2 + dx;
+            if (ix >= a.inW) continue;
+            const vec_t x = pf_ldv<T>(in + ((size_t)iy * a.inW + ix) * a.inLd);
+#pragma unroll
+            for (int e = 0; e < VE; ++e) m[e] = fmaxf(m[e], (float)x[e]);
+        }
+    }
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) o[e] = (T)m[e];
+    pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
+}
+
+struct CopyArgs {
+    const void* in; void* out;
+    int B, inH, inW, C, inLd, outLd, outCs, up;  // out is (inH*up) x (inW*up); channel c -> c*outCs
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_kernel(CopyArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int CV = a.C / VE;
+    const int H = a.inH * a.up, W = a.inW * a.up;
+    const long long total = (long long)a.B * H * W * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int ox = (int)(pix % W);
+    const long long t2 = pix / W;
+    const int oy = (int)(t2 % H);
+    const int b = (int)(t2 / H);
+    const vec_t x = pf_ldv<T>(static_cast<const T*>(a.in) +
+                              ((size_t)(b * a.inH + oy / a.up) * a.inW + ox / a.up) * a.inLd + cv * VE);
+    T* o = static_cast<T*>(a.out) + (size_t)pix * a.outLd;
+    if (a.outCs == 1) {
+        pf_stv<T>(o + cv * VE, x);
+    } else {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) o[(size_t)(cv * VE + e) * a.outCs] = x[e];
+    }
+}
+
+// yolov5-face Detect decode (models/yolo.py Detect.forward, export_cat branch -- third-party, restated):
+// sigmoid on cols 0:5 and 15, xy = (2s-0.5+grid)*stride, wh = (2s)^2*anchor,
+// landmark cols 5:15 = raw*anchor + grid*stride.  Rows ordered (anchor, y, x) per level.
+struct DetDecArgs {
+    const void* in;      // T [B][ny][nx][ld], channel = anchor*16 + o
+    float* rows;         // [B][nrows_total][16]
+    const float* anchors;  // [3][2] (w,h) in pixels
+    int B, ny, nx, ld, row0, nrows_total;
+    float stride;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void detect_decode_kernel(DetDecArgs a) {
+    const long long total = (long long)a.B * 3 * a.ny * a.nx;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.nx);
+    long long t2 = idx / a.nx;
+    const int y = (int)(t2 % a.ny);
+    t2 /= a.ny;
+    const int an = (int)(t2 % 3);
+    const int b = (int)(t2 / 3);
+    const T* in = static_cast<const T*>(a.in) + ((size_t)(b * a.ny + y) * a.nx + x) * a.ld + an * 16;
+    float v[16];
+#pragma unroll
+    for (int o = 0; o < 16; ++o) v[o] = (float)in[o];
+    const float aw = a.anchors[an * 2], ah = a.anchors[an * 2 + 1];
+    const float gx = (float)x, gy = (float)y;
+    float r[16];
+    const float s0 = pf_act(v[0], PF_ACT_SIGMOID), s1 = pf_act(v[1], PF_ACT_SIGMOID);
+    const float s2 = pf_act(v[2], PF_ACT_SIGMOID), s3 = pf_act(v[3], PF_ACT_SIGMOID);
+    r[0] = (s0 * 2.f - 0.5f + gx) * a.stride;
+    r[1] = (s1 * 2.f - 0.5f + gy) * a.stride;
+    r[2] = (s2 * 2.f) * (s2 * 2.f) * aw;
+    r[3] = (s3 * 2.f) * (s3 * 2.f) * ah;
+    r[4] = pf_act(v[4], PF_ACT_SIGMOID);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        r[5 + 2 * k] = v[5 + 2 * k] * aw + gx * a.stride;
+        r[6 + 2 * k] = v[6 + 2 * k] * ah + gy * a.stride;
+    }
+    r[15] = pf_act(v[15], PF_ACT_SIGMOID);
+    float* out = a.rows + ((size_t)b * a.nrows_total + a.row0 + ((size_t)an * a.ny + y) * a.nx + x) * 16;
+#pragma unroll
+    for (int o = 0; o < 16; o += 4) *reinterpret_cast<pf_f32x4*>(out + o) = pf_f32x4{r[o], r[o + 1], r[o + 2], r[o + 3]};
+}

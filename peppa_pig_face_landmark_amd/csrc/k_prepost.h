@@ -1,0 +1,369 @@
+// Pre/post-processing kernels of the FaceAna pipeline (all HBM-bound byte/float shuffling).
+//
+//   letterbox_kernel      FaceDetector.preprocess        face_detector.py:45-63  (K1)
+//   nms_kernel            xywh2xyxy + score filter + sort + greedy NMS + scale_coords
+//                         face_detector.py:31-37,73-136 ; then FaceAna.sort_and_filter facer.py:120-142 (K4)
+//   crop_params_kernel    box arithmetic of FaceLandmark.preprocess  face_landmark.py:74-93 (numpy-1.23
+//                         promotion: float32 boxes, float64 for (1+2*extend)*w and every // 2)
+//   crop_resize_kernel    zero-pad + crop + cv2.resize  face_landmark.py:79-98  (K5)
+//
+// cv2.resize(INTER_LINEAR, uint8) is reproduced bit-for-bit as OpenCV's fixed-point bilinear
+// (11-bit coefficients, int32 horizontal pass, ((b0*(r0>>4))>>16 + (b1*(r1>>4))>>16 + 2)>>2 vertical
+// pass, exact-2x shrink -> 2x2 box average) -- third-party algorithm, restated (see oracle/prepost.py).
+// Float box arithmetic uses the non-contracting __f*_rn intrinsics so results equal numpy's.
+#pragma once
+#include "pf_common.h"
+
+
+struct PipelineScratch {
+    // set by the pipeline before running the landmark program so that hm_decode_kernel also
+    // back-projects to frame coordinates (face_landmark.py:112-113); nullptr otherwise
+    const float* d_crop_for_decode = nullptr;
+    float* d_kps_for_decode = nullptr;
+    // device scratch owned by the handle (allocated lazily by pipeline.inl)
+    unsigned char* d_frames = nullptr; size_t frames_bytes = 0;
+    unsigned char* d_letterbox = nullptr; size_t letterbox_bytes = 0;
+    unsigned char* d_crops = nullptr; size_t crops_bytes = 0;
+    float* d_rows_planted = nullptr; size_t rows_planted_bytes = 0;
+    float* d_lbinfo = nullptr;       // [4] scale,left,top,pad
+    float h_lbinfo[4] = {0.f, 0.f, 0.f, 0.f};  // host copy kept alive for the async upload
+    float* d_keep_rows = nullptr;    // [F][max_keep][16]
+    int* d_keep_count = nullptr;     // [F]
+    float* d_sel_boxes = nullptr;    // [F][top_k][4]
+    int* d_sel_count = nullptr;      // [F]
+    int* d_crop_params = nullptr;    // [faces][8]
+    float* d_cropf = nullptr;        // [faces][5]
+    float* d_kps = nullptr;          // [faces][98][2]
+    unsigned long long* d_nms_keys = nullptr;  // [F][cap]
+    unsigned char* d_nms_flags = nullptr;      // [F][cap]
+    int cap_frames = 0, cap_faces = 0, cap_keep = 0, cap_topk = 0, cap_rows = 0;
+    void release() {
+        void* ptrs[] = {d_frames, d_letterbox, d_crops, d_rows_planted, d_lbinfo, d_keep_rows, d_keep_count,
+                        d_sel_boxes, d_sel_count, d_crop_params, d_cropf, d_kps, d_nms_keys, d_nms_flags};
+        for (void* p : ptrs) if (p) (void)hipFree(p);
+        *this = PipelineScratch();
+    }
+};
+
+// --------------------------------------------------------------------------------------------
+// OpenCV fixed-point bilinear taps
+struct LinTap { int i0, i1, a0, a1; };
+
+// horizontal flavour: weights reset at the borders (resize.cpp: "fx = 0, sx = 0" / "sx = ssize-1")
+__device__ __forceinline__ LinTap pf_cv_tap_h(int d, double scale, int src_len) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= src_len - 1) { s = src_len - 1; f = 0.f; }
+    LinTap t;
+    t.i0 = s;
+    t.i1 = s + 1 < src_len ? s + 1 : src_len - 1;
+    t.a0 = (int)rintf((1.f - f) * 2048.f);
+    t.a1 = (int)rintf(f * 2048.f);
+    return t;
+}
+// vertical flavour: weights kept, rows clamped
+__device__ __forceinline__ LinTap pf_cv_tap_v(int d, double scale, int src_len) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    const int s = (int)floorf(f);
+    f -= (float)s;
+    LinTap t;
+    t.i0 = s < 0 ? 0 : (s > src_len - 1 ? src_len - 1 : s);
+    t.i1 = s + 1 < 0 ? 0 : (s + 1 > src_len - 1 ? src_len - 1 : s + 1);
+    t.a0 = (int)rintf((1.f - f) * 2048.f);
+    t.a1 = (int)rintf(f * 2048.f);
+    return t;
+}
+__device__ __forceinline__ int pf_cv_vmix(int h0, int h1, int b0, int b1) {
+    return ((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xFF;
+}
+
+// --------------------------------------------------------------------------------------------
+struct LetterboxArgs {
+    const unsigned char* frames;  // [F][H][row_stride] BGR
+    unsigned char* out;           // [F][outH][outW][3] RGB
+    int F, H, W, row_stride, outH, outW, rw, rh, top, left;
+    double scale_x, scale_y;      // 1/(rw/W), 1/(rh/H) as OpenCV derives them
+    int pad_value;
+};
+
+__global__ __launch_bounds__(256) void letterbox_kernel(LetterboxArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (idx >= a.outH * a.outW) return;
+    const int oy = idx / a.outW, ox = idx - oy * a.outW;
+    unsigned char* o = a.out + ((size_t)f * a.outH * a.outW + idx) * 3;
+    const int ry = oy - a.top, rx = ox - a.left;
+    if ((unsigned)ry >= (unsigned)a.rh || (unsigned)rx >= (unsigned)a.rw) {
+        o[0] = o[1] = o[2] = (unsigned char)a.pad_value;
+        return;
+    }
+    const unsigned char* src = a.frames + (size_t)f * a.H * a.row_stride;
+    int r[3];
+    if (a.W == 2 * a.rw && a.H == 2 * a.rh) {
+        const unsigned char* p0 = src + (size_t)(2 * ry) * a.row_stride + (size_t)(2 * rx) * 3;
+        const unsigned char* p1 = p0 + a.row_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+    } else {
+        const LinTap tx = pf_cv_tap_h(rx, a.scale_x, a.W);
+        const LinTap ty = pf_cv_tap_v(ry, a.scale_y, a.H);
+        const unsigned char* r0 = src + (size_t)ty.i0 * a.row_stride;
+        const unsigned char* r1 = src + (size_t)ty.i1 * a.row_stride;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int h0 = r0[tx.i0 * 3 + c] * tx.a0 + r0[tx.i1 * 3 + c] * tx.a1;
+            const int h1 = r1[tx.i0 * 3 + c] * tx.a0 + r1[tx.i1 * 3 + c] * tx.a1;
+            r[c] = pf_cv_vmix(h0, h1, ty.a0, ty.a1);
+        }
+    }
+    o[0] = (unsigned char)r[2];  // BGR -> RGB (face_detector.py:47)
+    o[1] = (unsigned char)r[1];
+    o[2] = (unsigned char)r[0];
+}
+
+// --------------------------------------------------------------------------------------------
+struct NmsArgs {
+    const float* rows;     // [F][R][16] decoded detector rows (cx,cy,w,h,score,...) letterboxed pixels
+    const float* lbinfo;   // [4] = scale, left, top, unused (same geometry for every frame)
+    float* keep_rows;      // [F][max_keep][16]  kept rows, xyxy un-letterboxed in cols 0:4
+    int* keep_count;       // [F]
+    float* sel_boxes;      // [F][top_k][4]  after sort_and_filter (may be nullptr)
+    int* sel_count;        // [F]
+    unsigned long long* keys;  // [F][cap] scratch (cap = power of two >= R)
+    unsigned char* flags;      // [F][cap] scratch
+    int R, cap, max_keep, top_k;
+    float score_thres, iou_thres, min_face;
+};
+
+__device__ __forceinline__ unsigned pf_orderable(float v) {
+    unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup (1024 threads) per frame.  Candidate compaction in row order, bitonic sort of
+// (score desc, row asc) keys, then the reference's greedy loop with every surviving candidate
+// tested in parallel against the current pick.
+__global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
+    __shared__ int s_wave_cnt[16];
+    __shared__ int s_base, s_count, s_nkeep;
+    __shared__ int s_keep[1024];
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const float* rows = a.rows + (size_t)f * a.R * 16;
+    unsigned long long* keys = a.keys + (size_t)f * a.cap;
+    unsigned char* flags = a.flags + (size_t)f * a.cap;
+    if (tid == 0) { s_base = 0; s_nkeep = 0; }
+    __syncthreads();
+    // 1. compaction: score > thres (strict, face_detector.py:97)
+    for (int r0 = 0; r0 < a.R; r0 += 1024) {
+        const int r = r0 + tid;
+        const bool pass = r < a.R && rows[(size_t)r * 16 + 4] > a.score_thres;
+        const unsigned long long m = __ballot(pass);
+        if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
+        if (pass) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            keys[pos] = ((unsigned long long)pf_orderable(rows[(size_t)r * 16 + 4]) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)r);
+        }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += s_wave_cnt[w]; s_base += t; }
+        __syncthreads();
+    }
+    const int C = s_base;
+    int n2 = 1;
+    while (n2 < C) n2 <<= 1;
+    for (int i = C + tid; i < n2; i += 1024) keys[i] = 0ull;
+    for (int i = tid; i < n2; i += 1024) flags[i] = 0;
+    __syncthreads();
+    // 2. bitonic sort, descending
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < n2; i += 1024) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const unsigned long long x = keys[i], y = keys[p];
+                    const bool desc = (i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { keys[i] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // 3. greedy suppression (face_detector.py:110-134)
+    for (int i = 0; i < C; ++i) {
+        if (flags[i]) continue;  // uniform: written before the barrier that ended the previous pick
+        const int ri = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const float* bi = rows + (size_t)ri * 16;
+        const float hw = bi[2] / 2.f, hh = bi[3] / 2.f;
+        const float x1 = __fsub_rn(bi[0], hw), y1 = __fsub_rn(bi[1], hh);
+        const float x2 = __fadd_rn(bi[0], hw), y2 = __fadd_rn(bi[1], hh);
+        const float area = __fmul_rn(__fsub_rn(x2, x1), __fsub_rn(y2, y1));
+        if (tid == 0) { if (s_nkeep < 1024) s_keep[s_nkeep] = ri; s_nkeep++; }
+        for (int j = i + 1 + tid; j < C; j += 1024) {
+            if (flags[j]) continue;
+            const int rj = (int)(0xFFFFFFFFu - (unsigned)(keys[j] & 0xFFFFFFFFull));
+            const float* bj = rows + (size_t)rj * 16;
+            const float jw = bj[2] / 2.f, jh = bj[3] / 2.f;
+            const float u1 = __fsub_rn(bj[0], jw), v1 = __fsub_rn(bj[1], jh);
+            const float u2 = __fadd_rn(bj[0], jw), v2 = __fadd_rn(bj[1], jh);
+            const float iw = fmaxf(0.f, __fsub_rn(fminf(x2, u2), fmaxf(x1, u1)));
+            const float ih = fmaxf(0.f, __fsub_rn(fminf(y2, v2), fmaxf(y1, v1)));
+            const float inter = __fmul_rn(ih, iw);
+            const float aj = __fmul_rn(__fsub_rn(v2, v1), __fsub_rn(u2, u1));
+            const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area, aj), inter));
+            if (!(iou < a.iou_thres)) flags[j] = 1;  // NaN is suppressed too, like np.where(iou < thr)
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // 4. emit kept rows with scale_coords applied (face_detector.py:37,82-93)
+    const int nk = s_nkeep < a.max_keep ? (s_nkeep < 1024 ? s_nkeep : 1024) : a.max_keep;
+    const float scale = a.lbinfo[0], left = a.lbinfo[1], top = a.lbinfo[2];
+    float* out = a.keep_rows + (size_t)f * a.max_keep * 16;
+    for (int k = tid; k < nk; k += 1024) {
+        const float* b = rows + (size_t)s_keep[k] * 16;
+        const float hw = b[2] / 2.f, hh = b[3] / 2.f;
+        float* o = out + (size_t)k * 16;
+        o[0] = __fdiv_rn(__fsub_rn(__fsub_rn(b[0], hw), left), scale);
+        o[1] = __fdiv_rn(__fsub_rn(__fsub_rn(b[1], hh), top), scale);
+        o[2] = __fdiv_rn(__fsub_rn(__fadd_rn(b[0], hw), left), scale);
+        o[3] = __fdiv_rn(__fsub_rn(__fadd_rn(b[1], hh), top), scale);
+        for (int c = 4; c < 16; ++c) o[c] = b[c];
+    }
+    if (tid == 0) a.keep_count[f] = nk;
+    __syncthreads();
+    // 5. FaceAna.sort_and_filter (facer.py:120-142): area > min_face, top_k by area if more remain
+    if (a.sel_boxes && tid == 0) {
+        float* sb = a.sel_boxes + (size_t)f * a.top_k * 4;
+        int nsel = 0, npass = 0;
+        for (int k = 0; k < nk; ++k) {
+            const float* o = out + (size_t)k * 16;
+            if (__fmul_rn(__fsub_rn(o[2], o[0]), __fsub_rn(o[3], o[1])) > a.min_face) npass++;
+        }
+        if (npass <= a.top_k) {
+            for (int k = 0; k < nk; ++k) {
+                const float* o = out + (size_t)k * 16;
+                if (__fmul_rn(__fsub_rn(o[2], o[0]), __fsub_rn(o[3], o[1])) > a.min_face) {
+                    for (int c = 0; c < 4; ++c) sb[nsel * 4 + c] = o[c];
+                    nsel++;
+                }
+            }
+        } else {
+            float last_area = 3.0e38f;
+            int last_k = -1;
+            for (int s = 0; s < a.top_k; ++s) {  // selection by descending area (ties: later index first,
+                float best = -1.f;               // i.e. the reversed ascending argsort of the reference)
+                int bk = -1;
+                for (int k = nk - 1; k >= 0; --k) {
+                    const float* o = out + (size_t)k * 16;
+                    const float ar = __fmul_rn(__fsub_rn(o[2], o[0]), __fsub_rn(o[3], o[1]));
+                    if (!(ar > a.min_face)) continue;
+                    const bool before = ar > last_area || (ar == last_area && k >= last_k);
+                    if (before) continue;
+                    if (ar > best) { best = ar; bk = k; }
+                }
+                if (bk < 0) break;
+                const float* o = out + (size_t)bk * 16;
+                for (int c = 0; c < 4; ++c) sb[nsel * 4 + c] = o[c];
+                nsel++;
+                last_area = best;
+                last_k = bk;
+            }
+        }
+        a.sel_count[f] = nsel;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+struct CropParamArgs {
+    const float* boxes;   // [n][4] xyxy float32 (frame coordinates)
+    const int* counts;    // optional [F]: faces actually present per frame (slots beyond are invalid)
+    int* params;          // [n][8] = valid, add, x0, y0, xs, ys, w_crop, h_crop
+    float* cropf;         // [n][5] = w_crop, h_crop, x0, y0, add  (face_landmark.py:104 "detail")
+    int n, per_frame, H, W;
+    float min_face;       // 20 (face_landmark.py:26)
+    double width_factor;  // 1 + 2*extend[0]  (face_landmark.py:83)
+};
+
+__global__ __launch_bounds__(64) void crop_params_kernel(CropParamArgs a) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= a.n) return;
+    int* p = a.params + (size_t)i * 8;
+    float* cf = a.cropf + (size_t)i * 5;
+    for (int k = 0; k < 8; ++k) p[k] = 0;
+    for (int k = 0; k < 5; ++k) cf[k] = 0.f;
+    if (a.counts && (i % a.per_frame) >= a.counts[i / a.per_frame]) return;
+    const float* b = a.boxes + (size_t)i * 4;
+    const float w = __fsub_rn(b[2], b[0]), h = __fsub_rn(b[3], b[1]);
+    if (w <= a.min_face || h <= a.min_face || !(w == w) || !(h == h)) return;
+    const int add = (int)fmaxf(w, h);
+    const float fa = (float)add;
+    const float b0 = __fadd_rn(b[0], fa), b1 = __fadd_rn(b[1], fa), b2 = __fadd_rn(b[2], fa), b3 = __fadd_rn(b[3], fa);
+    const double face_width = a.width_factor * (double)w;
+    const double cx = floor((double)__fadd_rn(b0, b2) / 2.0);
+    const double cy = floor((double)__fadd_rn(b1, b3) / 2.0);
+    const double half = floor(face_width / 2.0);
+    const int x0 = (int)(float)(cx - half), y0 = (int)(float)(cy - half);
+    const int x1 = (int)(float)(cx + half), y1 = (int)(float)(cy + half);
+    const int ph = a.H + 2 * add, pw = a.W + 2 * add;
+    const int xs = min(max(x0, 0), pw), xe = min(max(x1, 0), pw);
+    const int ys = min(max(y0, 0), ph), ye = min(max(y1, 0), ph);
+    const int wc = xe - xs, hc = ye - ys;
+    if (wc <= 0 || hc <= 0) return;
+    p[0] = 1; p[1] = add; p[2] = x0; p[3] = y0; p[4] = xs; p[5] = ys; p[6] = wc; p[7] = hc;
+    cf[0] = (float)wc; cf[1] = (float)hc; cf[2] = (float)x0; cf[3] = (float)y0; cf[4] = fa;
+}
+
+// --------------------------------------------------------------------------------------------
+struct CropResizeArgs {
+    const unsigned char* frames;  // [F][H][row_stride] BGR
+    const int* params;            // [n][8]
+    unsigned char* out;           // [n][S][S][3]  (channel order untouched, face_landmark.py:42-46)
+    int n, per_frame, H, W, row_stride, S;
+};
+
+__device__ __forceinline__ int pf_padded_px(const unsigned char* src, int row_stride, int H, int W, int py, int px, int add, int c) {
+    const int y = py - add, x = px - add;  // padded -> frame coordinates; outside = 0 (copyMakeBorder constant 0)
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return 0;
+    return src[(size_t)y * row_stride + (size_t)x * 3 + c];
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(CropResizeArgs a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int face = blockIdx.y;
+    if (idx >= a.S * a.S) return;
+    const int* p = a.params + (size_t)face * 8;
+    unsigned char* o = a.out + ((size_t)face * a.S * a.S + idx) * 3;
+    if (!p[0]) { o[0] = o[1] = o[2] = 0; return; }
+    const int add = p[1], xs = p[4], ys = p[5], wc = p[6], hc = p[7];
+    const unsigned char* src = a.frames + (size_t)(face / a.per_frame) * a.H * a.row_stride;
+    const int dy = idx / a.S, dx = idx - dy * a.S;
+    if (wc == 2 * a.S && hc == 2 * a.S) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int s = pf_padded_px(src, a.row_stride, a.H, a.W, ys + 2 * dy, xs + 2 * dx, add, c) +
+                          pf_padded_px(src, a.row_stride, a.H, a.W, ys + 2 * dy, xs + 2 * dx + 1, add, c) +
+                          pf_padded_px(src, a.row_stride, a.H, a.W, ys + 2 * dy + 1, xs + 2 * dx, add, c) +
+                          pf_padded_px(src, a.row_stride, a.H, a.W, ys + 2 * dy + 1, xs + 2 * dx + 1, add, c);
+            o[c] = (unsigned char)((s + 2) >> 2);
+        }
+        return;
+    }
+    const double scale_x = 1.0 / ((double)a.S / (double)wc);
+    const double scale_y = 1.0 / ((double)a.S / (double)hc);
+    const LinTap tx = pf_cv_tap_h(dx, scale_x, wc);
+    const LinTap ty = pf_cv_tap_v(dy, scale_y, hc);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int h0 = pf_padded_px(src, a.row_stride, a.H, a.W, ys + ty.i0, xs + tx.i0, add, c) * tx.a0 +
+                       pf_padded_px(src, a.row_stride, a.H, a.W, ys + ty.i0, xs + tx.i1, add, c) * tx.a1;
+        const int h1 = pf_padded_px(src, a.row_stride, a.H, a.W, ys + ty.i1, xs + tx.i0, add, c) * tx.a0 +
+                       pf_padded_px(src, a.row_stride, a.H, a.W, ys + ty.i1, xs + tx.i1, add, c) * tx.a1;
+        o[c] = (unsigned char)pf_cv_vmix(h0, h1, ty.a0, ty.a1);
+    }
+}

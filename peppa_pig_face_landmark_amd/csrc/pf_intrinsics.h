@@ -1,0 +1,30 @@
+// CDNA4 (gfx950) device intrinsics used by the peppa-hip kernels.
+//
+// Thin named wrappers over the gfx950 matrix-core and cross-lane builtins so every kernel
+// states which instruction it relies on:
+//   pf_mfma_16x16x32_f16  -> v_mfma_f32_16x16x32_f16  (8 f16 per lane per operand, f32 accumulate)
+//   pf_mfma_16x16x4_f32   -> v_mfma_f32_16x16x4_f32   (exact f32, verification mode)
+// Fragment layout (cdna_hip_programming.md section 3): operand lane l supplies row/col (l & 15) and
+// k-group (l >> 4); accumulator lane l, register r holds D[4*(l>>4)+r][l&15].
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef _Float16 pf_half;
+typedef _Float16 pf_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf_half4 __attribute__((ext_vector_type(4)));
+typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ pf_f32x4 pf_mfma_16x16x32_f16(pf_half8 a, pf_half8 b, pf_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float pf_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float pf_exp(float x) { return __expf(x); }
+
+#define PF_BUILD_TAG "gfx950"
+#define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

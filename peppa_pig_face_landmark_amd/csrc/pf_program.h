@@ -1,0 +1,53 @@
+// Packed network program: the binary interface between the Python graph builder
+// (peppa_pig_face_landmark_amd/graph/ir.py -- keep the two in sync) and the HIP executor.
+//
+// A program is a straight-line list of fused layer ops over NHWC activation tensors that live in
+// one device arena.  Everything is little-endian int32 (floats are bit-cast), so the Python side
+// needs nothing but struct.pack.
+//
+//   blob := Header | BufRec[n_bufs] | TensorRec[n_tensors] | OpRec[n_ops] | pad to 256 | const bytes
+//
+// Buffers scale linearly with the batch: buffer i lives at arena + offset_units*256*max_batch and
+// item b of it at + b * item_bytes.  Tensors are (buffer, channel offset, pixel stride) views, which
+// is how torch.cat (DecoderBlock, ASPP, detector PAN) costs nothing: producers write channel slices.
+#pragma once
+#include <stdint.h>
+
+#define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
+#define PF_PROGRAM_VERSION 3
+
+enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
+
+struct PfHeader {
+    int32_t magic, version, dtype, n_bufs, n_tensors, n_ops, const_bytes, arena_units_per_item;
+    int32_t in_h, in_w, out_buf0, out_buf1, out_buf2, reserved0, reserved1, reserved2;
+};
+struct PfBufRec {
+    int32_t etype, elems_per_item, offset_units, reserved;
+};
+struct PfTensorRec {
+    int32_t buf, coff, ld, H, W, C, reserved0, reserved1;
+};
+#define PF_OP_FIELDS 39
+struct PfOpRec {
+    int32_t code;
+    int32_t f[PF_OP_FIELDS];
+};
+
+enum PfOpCode : int32_t {
+    PF_OP_STEM = 1,     // f: in_t(-1 = program input) out_t wt bias act
+    PF_OP_CONV = 2,     // f: in_t out_t wt bias res_t gate_buf fbias_buf KH KW stride pad dil Cpad Npad N act
+                        //    outCs amax_val_buf amax_idx_buf amaxN store_out cfg
+    PF_OP_DW = 3,       // f: in_t out_t wt bias K stride pad dil act
+    PF_OP_UPCAT = 4,    // f: lo_t skip_t out_t
+    PF_OP_GAP = 5,      // f: in_t out_buf
+    PF_OP_FC = 6,       // f: x_buf y_buf wt bias K N act scale2 shift2 act2
+    PF_OP_SCSE = 7,     // f: in_t out_t cse_buf ssew sse_b(float bits)
+    PF_OP_HMDEC = 8,    // f: val_buf idx_buf feat_t offwt offbias P nslots loc_buf score_buf
+    PF_OP_MAXPOOL = 9,  // f: in_t out_t            (2x2 stride 2, ceil mode)
+    PF_OP_COPY = 10,    // f: in_t out_t out_cs up  (channel-strided copy, optional nearest x2 upsample)
+    PF_OP_DETDEC = 11,  // f: in_t rows_buf row0 stride anchors(wt off, 6 floats) nrows_total
+};
+
+// tile configurations of conv_gemm_kernel (index = cfg field)
+#define PF_CONV_NCFG 4

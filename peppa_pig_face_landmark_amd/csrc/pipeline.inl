@@ -1,0 +1,260 @@
+// Pipeline-level entry points of the C ABI (included at the end of engine.cpp):
+//   pf_detect          == FaceDetector.__call__       face_detector.py:23-42
+//   pf_landmarks       == FaceLandmark.__call__       face_landmark.py:33-64
+//   pf_run_frames*     == FaceAna.run()+reset()       facer.py:52-85 / demo.py:83-86, batched over frames
+// Everything between the frame bytes and the result arrays stays on the device.
+#include <math.h>
+
+namespace {
+
+const int kMaxKeep = 1024;   // rows kept per frame after NMS (s_keep capacity of nms_kernel)
+const int kNumPoints = 98;
+
+template <typename T>
+int ensure_dev(pf_handle* h, T*& ptr, size_t& have_bytes, size_t need_bytes) {
+    if (need_bytes <= have_bytes && ptr) return 0;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    have_bytes = 0;
+    PF_HIP(h, hipMalloc((void**)&ptr, need_bytes));
+    have_bytes = need_bytes;
+    return 0;
+}
+
+template <typename T>
+int realloc_dev(pf_handle* h, T*& ptr, size_t bytes) {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    PF_HIP(h, hipMalloc((void**)&ptr, bytes));
+    return 0;
+}
+
+int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+int ensure_pipeline(pf_handle* h, int frames, int faces, int top_k, int rows) {
+    PipelineScratch& s = h->pipe;
+    if (frames > s.cap_frames || top_k > s.cap_topk || rows > s.cap_rows) {
+        const int F = std::max(frames, s.cap_frames), K = std::max(top_k, s.cap_topk), R = std::max(rows, s.cap_rows);
+        const int cap = next_pow2(std::max(R, 2));
+        if (realloc_dev(h, s.d_lbinfo, 4 * sizeof(float))) return 1;
+        if (realloc_dev(h, s.d_keep_rows, (size_t)F * kMaxKeep * 16 * sizeof(float))) return 1;
+        if (realloc_dev(h, s.d_keep_count, (size_t)F * sizeof(int))) return 1;
+        if (realloc_dev(h, s.d_sel_boxes, (size_t)F * K * 4 * sizeof(float))) return 1;
+        if (realloc_dev(h, s.d_sel_count, (size_t)F * sizeof(int))) return 1;
+        if (realloc_dev(h, s.d_nms_keys, (size_t)F * cap * sizeof(unsigned long long))) return 1;
+        if (realloc_dev(h, s.d_nms_flags, (size_t)F * cap)) return 1;
+        s.cap_frames = F; s.cap_topk = K; s.cap_rows = R;
+    }
+    if (faces > s.cap_faces) {
+        if (realloc_dev(h, s.d_crop_params, (size_t)faces * 8 * sizeof(int))) return 1;
+        if (realloc_dev(h, s.d_cropf, (size_t)faces * 5 * sizeof(float))) return 1;
+        if (realloc_dev(h, s.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float))) return 1;
+        s.cap_faces = faces;
+    }
+    return 0;
+}
+
+struct LetterboxGeom {
+    double scale; int rw, rh, top, left; double scale_x, scale_y;
+};
+
+// face_detector.py:51-61 in the same double arithmetic Python uses
+LetterboxGeom letterbox_geom(int H, int W, int outH, int outW) {
+    LetterboxGeom g;
+    const double sh = (double)outH / (double)H, sw = (double)outW / (double)W;
+    g.scale = sh < sw ? sh : sw;
+    g.rw = (int)((double)W * g.scale);
+    g.rh = (int)((double)H * g.scale);
+    const double dh = (double)(outH - g.rh) / 2.0, dw = (double)(outW - g.rw) / 2.0;
+    g.top = (int)nearbyint(dh - 0.1);   // Python round() == round-half-even
+    g.left = (int)nearbyint(dw - 0.1);
+    g.scale_x = 1.0 / ((double)g.rw / (double)W);   // OpenCV: scale = 1 / inv_scale
+    g.scale_y = 1.0 / ((double)g.rh / (double)H);
+    return g;
+}
+
+// frames (host or device) -> device pointer
+int stage_frames(pf_handle* h, const uint8_t* frames, int mem, size_t bytes, const unsigned char** d_out) {
+    if (mem == PF_MEM_DEVICE) { *d_out = frames; return 0; }
+    if (ensure_dev(h, h->pipe.d_frames, h->pipe.frames_bytes, bytes)) return 1;
+    PF_HIP(h, hipMemcpyAsync(h->pipe.d_frames, frames, bytes, hipMemcpyHostToDevice, h->stream));
+    *d_out = h->pipe.d_frames;
+    return 0;
+}
+
+// letterbox + detector network; leaves decoded rows in the detector program's output buffer
+int run_detector_stage(pf_handle* h, const unsigned char* d_frames, int F, int H, int W, int row_stride,
+                       const LetterboxGeom& g) {
+    Program& det = h->prog[PF_NET_DETECTOR];
+    const int oh = det.hdr.in_h, ow = det.hdr.in_w;
+    if (ensure_dev(h, h->pipe.d_letterbox, h->pipe.letterbox_bytes, (size_t)F * oh * ow * 3)) return 1;
+    LetterboxArgs la{};
+    la.frames = d_frames; la.out = h->pipe.d_letterbox;
+    la.F = F; la.H = H; la.W = W; la.row_stride = row_stride; la.outH = oh; la.outW = ow;
+    la.rw = g.rw; la.rh = g.rh; la.top = g.top; la.left = g.left;
+    la.scale_x = g.scale_x; la.scale_y = g.scale_y; la.pad_value = 114;
+    {
+        ProfScope ps(h, "letterbox");
+        PF_LAUNCH(letterbox_kernel, dim3(pf_div_up(oh * ow, 256), F), dim3(256), h->stream, la);
+    }
+    return run_program(h, PF_NET_DETECTOR, h->pipe.d_letterbox, PF_INPUT_U8_NHWC, F);
+}
+
+int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const LetterboxGeom& g,
+                  float score_thres, float iou_thres, float min_face, int top_k, bool select) {
+    PipelineScratch& s = h->pipe;
+    s.h_lbinfo[0] = (float)g.scale; s.h_lbinfo[1] = (float)g.left; s.h_lbinfo[2] = (float)g.top; s.h_lbinfo[3] = 0.f;
+    PF_HIP(h, hipMemcpyAsync(s.d_lbinfo, s.h_lbinfo, sizeof(s.h_lbinfo), hipMemcpyHostToDevice, h->stream));
+    NmsArgs na{};
+    na.rows = d_rows; na.lbinfo = s.d_lbinfo; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
+    na.sel_boxes = select ? s.d_sel_boxes : nullptr; na.sel_count = s.d_sel_count;
+    na.keys = s.d_nms_keys; na.flags = s.d_nms_flags;
+    na.R = rows; na.cap = next_pow2(std::max(s.cap_rows, 2)); na.max_keep = kMaxKeep; na.top_k = top_k;
+    na.score_thres = score_thres; na.iou_thres = iou_thres; na.min_face = min_face;
+    ProfScope ps(h, "nms");
+    PF_LAUNCH(nms_kernel, dim3(F), dim3(1024), h->stream, na);
+    return 0;
+}
+
+// crop boxes -> crops -> landmark program (with back-projection to frame coordinates)
+int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
+                       const float* d_boxes, const int* d_counts, int faces, int per_frame) {
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    PipelineScratch& s = h->pipe;
+    const int S = lm.hdr.in_h;
+    if (faces > lm.max_batch) PF_FAIL(h, "%d faces exceed the landmark program's max_batch %d", faces, lm.max_batch);
+    if (ensure_dev(h, s.d_crops, s.crops_bytes, (size_t)faces * S * S * 3)) return 1;
+    CropParamArgs ca{};
+    ca.boxes = d_boxes; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
+    ca.n = faces; ca.per_frame = per_frame; ca.H = H; ca.W = W;
+    ca.min_face = 20.f;                  // FaceLandmark.min_face, face_landmark.py:26
+    ca.width_factor = 1 + 2 * 0.2;       // (1 + 2*extend[0]) with extend = [0.2, 0.3], Skps.yml:14
+    {
+        ProfScope ps(h, "crop_params");
+        PF_LAUNCH(crop_params_kernel, dim3(pf_div_up(faces, 64)), dim3(64), h->stream, ca);
+    }
+    CropResizeArgs ra{};
+    ra.frames = d_frames; ra.params = s.d_crop_params; ra.out = s.d_crops;
+    ra.n = faces; ra.per_frame = per_frame; ra.H = H; ra.W = W; ra.row_stride = row_stride; ra.S = S;
+    {
+        ProfScope ps(h, "crop_resize");
+        PF_LAUNCH(crop_resize_kernel, dim3(pf_div_up(S * S, 256), faces), dim3(256), h->stream, ra);
+    }
+    s.d_crop_for_decode = s.d_cropf;
+    s.d_kps_for_decode = s.d_kps;
+    const int rc = run_program(h, PF_NET_LANDMARK, s.d_crops, PF_INPUT_U8_NHWC, faces);
+    s.d_crop_for_decode = nullptr;
+    s.d_kps_for_decode = nullptr;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+              float score_thres, float iou_thres, float* boxes, int max_n, int* n_out) {
+    if (!h) return 1;
+    Program& det = h->prog[PF_NET_DETECTOR];
+    if (!det.loaded) PF_FAIL(h, "detector program not loaded");
+    if (!bgr || !boxes || !n_out || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_detect: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    const int rows = det.bufs[det.hdr.out_buf0].elems_per_item / 16;
+    if (ensure_pipeline(h, 1, 0, 1, rows)) return 1;
+    const unsigned char* d_frames = nullptr;
+    if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
+    const LetterboxGeom g = letterbox_geom(height, width, det.hdr.in_h, det.hdr.in_w);
+    if (run_detector_stage(h, d_frames, 1, height, width, row_stride, g)) return 1;
+    if (run_nms_stage(h, (const float*)det.buf_ptr(det.hdr.out_buf0), rows, 1, g, score_thres, iou_thres, 0.f, 1, false)) return 1;
+    int n = 0;
+    PF_HIP(h, hipMemcpyAsync(&n, h->pipe.d_keep_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    n = std::min(n, max_n);
+    if (n > 0) PF_HIP(h, hipMemcpy(boxes, h->pipe.d_keep_rows, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return 0;
+}
+
+int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 const float* boxes, int n, float* kps, float* scores, int* valid) {
+    if (!h) return 1;
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
+    if (n < 0 || !bgr || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_landmarks: bad arguments");
+    if (n == 0) return 0;
+    PF_HIP(h, hipSetDevice(h->device));
+    if (ensure_pipeline(h, 1, n, n, 2)) return 1;
+    const unsigned char* d_frames = nullptr;
+    if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
+    PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n)) return 1;
+    std::vector<int> params((size_t)n * 8);
+    std::vector<float> hk((size_t)n * kNumPoints * 2), hs((size_t)n * kNumPoints);
+    PF_HIP(h, hipMemcpyAsync(params.data(), h->pipe.d_crop_params, params.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipMemcpyAsync(hk.data(), h->pipe.d_kps, hk.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipMemcpyAsync(hs.data(), lm.buf_ptr(lm.hdr.out_buf1), hs.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        const int ok = params[(size_t)i * 8];
+        if (valid) valid[i] = ok;
+        if (!ok) continue;
+        if (kps) memcpy(kps + (size_t)i * kNumPoints * 2, hk.data() + (size_t)i * kNumPoints * 2, kNumPoints * 2 * sizeof(float));
+        if (scores) memcpy(scores + (size_t)i * kNumPoints, hs.data() + (size_t)i * kNumPoints, kNumPoints * sizeof(float));
+    }
+    return 0;
+}
+
+int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                          const float* det_rows, int rows, float score_thres, float iou_thres,
+                          float min_face, int top_k,
+                          int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+    if (!h) return 1;
+    Program& det = h->prog[PF_NET_DETECTOR];
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
+    if (!det.loaded && !det_rows) PF_FAIL(h, "no detector program and no planted rows");
+    if (!frames || n_frames < 1 || height < 1 || width < 1 || top_k < 1) PF_FAIL(h, "pf_run_frames: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    const int F = n_frames, faces = F * top_k;
+    const int det_nrows = det.loaded ? det.bufs[det.hdr.out_buf0].elems_per_item / 16 : rows;
+    if (det_rows && det.loaded && rows != det_nrows) PF_FAIL(h, "planted rows %d != detector rows %d", rows, det_nrows);
+    if (ensure_pipeline(h, F, faces, top_k, det_nrows)) return 1;
+    const int row_stride = width * 3;
+    const unsigned char* d_frames = nullptr;
+    if (stage_frames(h, frames, mem, (size_t)F * height * row_stride, &d_frames)) return 1;
+    const int in_h = det.loaded ? det.hdr.in_h : 384, in_w = det.loaded ? det.hdr.in_w : 640;
+    const LetterboxGeom g = letterbox_geom(height, width, in_h, in_w);
+    if (det.loaded) {
+        if (F > det.max_batch) PF_FAIL(h, "%d frames exceed the detector program's max_batch %d", F, det.max_batch);
+        if (run_detector_stage(h, d_frames, F, height, width, row_stride, g)) return 1;
+    }
+    const float* d_rows = det.loaded ? (const float*)det.buf_ptr(det.hdr.out_buf0) : nullptr;
+    if (det_rows) {
+        if (mem == PF_MEM_DEVICE) {
+            d_rows = det_rows;
+        } else {
+            const size_t bytes = (size_t)F * rows * 16 * sizeof(float);
+            if (ensure_dev(h, h->pipe.d_rows_planted, h->pipe.rows_planted_bytes, bytes)) return 1;
+            PF_HIP(h, hipMemcpyAsync(h->pipe.d_rows_planted, det_rows, bytes, hipMemcpyHostToDevice, h->stream));
+            d_rows = h->pipe.d_rows_planted;
+        }
+    }
+    if (run_nms_stage(h, d_rows, det_nrows, F, g, score_thres, iou_thres, min_face, top_k, true)) return 1;
+    if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, h->pipe.d_sel_count, faces, top_k)) return 1;
+    const hipMemcpyKind kind = out_mem == PF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (counts) PF_HIP(h, hipMemcpyAsync(counts, h->pipe.d_sel_count, (size_t)F * sizeof(int), kind, h->stream));
+    if (boxes) PF_HIP(h, hipMemcpyAsync(boxes, h->pipe.d_sel_boxes, (size_t)faces * 4 * sizeof(float), kind, h->stream));
+    if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
+    if (scores) PF_HIP(h, hipMemcpyAsync(scores, lm.buf_ptr(lm.hdr.out_buf1), (size_t)faces * kNumPoints * sizeof(float), kind, h->stream));
+    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                  float score_thres, float iou_thres, float min_face, int top_k,
+                  int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+    return pf_run_frames_planted(h, frames, mem, n_frames, height, width, nullptr, 0, score_thres, iou_thres,
+                                 min_face, top_k, counts, boxes, kps, scores, out_mem);
+}
+
+}  // extern "C"

@@ -1,0 +1,298 @@
+"""Program assembler: builds the packed network program executed by ``csrc/engine.cpp``.
+
+The binary layout is defined in ``csrc/pf_program.h`` -- keep both in sync.  numpy only (the
+engine side of the boundary never sees torch / onnxruntime).
+
+A program is a straight-line list of fused layer ops over NHWC activation tensors.  BatchNorm is
+folded into the preceding conv here (float64), weights are re-laid-out for the kernels
+(``[Npad][taps][Cpad]`` rows of 64-byte K steps for the MFMA implicit-GEMM, ``[taps][C]`` for the
+depthwise kernel, ``[K][N]`` for the tiny pooled-vector FCs) and activation buffers are placed in
+one arena with lifetime-based reuse.
+"""
+from __future__ import annotations
+
+import struct
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+MAGIC = 0x47504650
+VERSION = 3
+OP_FIELDS = 39
+
+DTYPE_F16, DTYPE_F32 = 0, 1
+ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
+ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
+
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC = range(1, 12)
+
+# conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
+CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def fold_bn(weight: np.ndarray, conv_bias: Optional[np.ndarray], bn: Optional[Dict[str, np.ndarray]],
+            eps: float = 1e-5) -> Tuple[np.ndarray, np.ndarray]:
+    """conv (+bias) followed by eval-mode BatchNorm -> (weight', bias') in float64."""
+    w = weight.astype(np.float64)
+    cout = w.shape[0]
+    b = np.zeros(cout, np.float64) if conv_bias is None else conv_bias.astype(np.float64)
+    if bn is not None:
+        s = bn["weight"].astype(np.float64) / np.sqrt(bn["running_var"].astype(np.float64) + eps)
+        w = w * s.reshape((-1,) + (1,) * (w.ndim - 1))
+        b = (b - bn["running_mean"].astype(np.float64)) * s + bn["bias"].astype(np.float64)
+    return w, b
+
+
+def bn_affine(bn: Dict[str, np.ndarray], eps: float = 1e-5) -> Tuple[np.ndarray, np.ndarray]:
+    """eval-mode BatchNorm as y = s*x + t (float64)."""
+    s = bn["weight"].astype(np.float64) / np.sqrt(bn["running_var"].astype(np.float64) + eps)
+    t = bn["bias"].astype(np.float64) - bn["running_mean"].astype(np.float64) * s
+    return s, t
+
+
+class _Buf:
+    __slots__ = ("etype", "elems", "first", "last", "pinned", "offset_units", "name")
+
+
+class _Tensor:
+    __slots__ = ("buf", "coff", "ld", "H", "W", "C", "name")
+
+
+class ProgramBuilder:
+    def __init__(self, dtype: str, in_h: int, in_w: int, keep_all: bool = False):
+        assert dtype in ("f16", "f32")
+        self.dtype = DTYPE_F16 if dtype == "f16" else DTYPE_F32
+        self.np_act = np.float16 if dtype == "f16" else np.float32
+        self.esize = 2 if dtype == "f16" else 4
+        self.ve = 16 // self.esize          # elements per 16-byte vector
+        self.ke = 64 // self.esize          # elements per 64-byte K step
+        self.in_h, self.in_w = in_h, in_w
+        self.keep_all = keep_all
+        self.bufs: List[_Buf] = []
+        self.tensors: List[_Tensor] = []
+        self.ops: List[Tuple[int, List[int], List[int], List[int]]] = []  # code, fields, reads(bufs), writes(bufs)
+        self.consts = bytearray()
+        self.tensor_names: Dict[str, int] = {}
+
+    # ---- storage --------------------------------------------------------------------------
+    def buffer(self, elems: int, etype: int = ELEM_ACT, name: str = "", pinned: bool = False) -> int:
+        b = _Buf()
+        b.etype, b.elems, b.first, b.last, b.pinned, b.offset_units, b.name = etype, int(elems), None, None, pinned, 0, name
+        self.bufs.append(b)
+        return len(self.bufs) - 1
+
+    def tensor(self, H: int, W: int, C: int, buf: Optional[int] = None, coff: int = 0, ld: Optional[int] = None,
+               name: str = "") -> int:
+        assert C % self.ve == 0, f"channel count {C} must be a multiple of {self.ve}"
+        if buf is None:
+            ld = C if ld is None else ld
+            buf = self.buffer(H * W * ld, ELEM_ACT, name)
+        assert ld is not None and coff % self.ve == 0 and ld % self.ve == 0
+        t = _Tensor()
+        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name = buf, coff, ld, H, W, C, name
+        self.tensors.append(t)
+        tid = len(self.tensors) - 1
+        if name:
+            self.tensor_names[name] = tid
+        return tid
+
+    def view(self, base_buf: int, H: int, W: int, C: int, coff: int, ld: int, name: str = "") -> int:
+        return self.tensor(H, W, C, base_buf, coff, ld, name)
+
+    def const(self, arr: np.ndarray) -> int:
+        while len(self.consts) % 256:
+            self.consts.append(0)
+        off = len(self.consts)
+        self.consts += np.ascontiguousarray(arr).tobytes()
+        return off
+
+    def const_f32(self, arr) -> int:
+        return self.const(np.asarray(arr, np.float64).astype(np.float32))
+
+    def const_act(self, arr) -> int:
+        return self.const(np.asarray(arr, np.float64).astype(self.np_act))
+
+    def _op(self, code: int, fields: Sequence[int], reads: Sequence[int], writes: Sequence[int]):
+        f = [int(v) for v in fields]
+        assert len(f) <= OP_FIELDS
+        f += [0] * (OP_FIELDS - len(f))
+        self.ops.append((code, f, [r for r in reads if r is not None and r >= 0],
+                         [w for w in writes if w is not None and w >= 0]))
+
+    def _tb(self, t: int) -> int:
+        return self.tensors[t].buf if t is not None and t >= 0 else -1
+
+    # ---- ops --------------------------------------------------------------------------------
+    def stem(self, weight: np.ndarray, bias: np.ndarray, act: str, out_name: str = "") -> int:
+        """3x3 stride-2 pad-1 conv on the 3-channel program input; weight [16,3,3,3] (BN folded)."""
+        assert weight.shape == (16, 3, 3, 3)
+        oh, ow = (self.in_h + 1) // 2, (self.in_w + 1) // 2
+        out = self.tensor(oh, ow, 16, name=out_name)
+        w = np.transpose(weight.astype(np.float64), (2, 3, 1, 0)).reshape(27, 16)  # [(ky,kx,ci)][co]
+        off_u8 = self.const_f32(w / 255.0)
+        off_f32 = self.const_f32(w)
+        off_b = self.const_f32(bias)
+        self._op(OP_STEM, [-1, out, off_u8, off_b, ACT[act], off_f32], [], [self._tb(out)])
+        return out
+
+    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int]:
+        """[N,Cin,KH,KW] -> const offset of [Npad][KH*KW][Cpad] in the activation dtype."""
+        n, cin, kh, kw = weight.shape
+        npad, cpad = _round_up(n, 16), _round_up(cin, self.ke)
+        w = np.zeros((npad, kh * kw, cpad), np.float64)
+        w[:n, :, :cin] = np.transpose(weight.astype(np.float64), (0, 2, 3, 1)).reshape(n, kh * kw, cin)
+        return self.const_act(w), npad, cpad
+
+    def conv(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
+             dil: int = 1, out: Optional[int] = None, res: int = -1, gate_buf: int = -1, fbias_buf: int = -1,
+             out_cs: int = 1, amax: Optional[Tuple[int, int, int]] = None, store_out: bool = True,
+             cfg: int = -1, out_name: str = "") -> int:
+        """Dense conv as MFMA implicit GEMM.  weight [N,Cin,KH,KW] float (already BN-folded)."""
+        ti = self.tensors[x]
+        n, cin, kh, kw = weight.shape
+        assert cin == ti.C, (cin, ti.C)
+        oh = (ti.H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        ow = (ti.W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        if out is None:
+            out = self.tensor(oh, ow, _round_up(n, self.ve), name=out_name)
+        to = self.tensors[out]
+        assert (to.H, to.W) == (oh, ow), ((to.H, to.W), (oh, ow))
+        woff, npad, cpad = self.pack_conv_weight(weight)
+        b = np.zeros(npad, np.float64)
+        b[:n] = bias
+        boff = self.const_f32(b)
+        av, ai, an = amax if amax is not None else (-1, -1, 0)
+        self._op(OP_CONV, [x, out, woff, boff, res, gate_buf, fbias_buf, kh, kw, stride, pad, dil, cpad, npad, n,
+                           ACT[act], out_cs, av, ai, an, 1 if store_out else 0, cfg],
+                 [self._tb(x), self._tb(res), gate_buf, fbias_buf], [self._tb(out), av, ai])
+        return out
+
+    def dw(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
+           dil: int = 1, out_name: str = "") -> int:
+        """Depthwise conv; weight [C,1,K,K] float (BN folded)."""
+        ti = self.tensors[x]
+        c, one, k, k2 = weight.shape
+        assert one == 1 and k == k2 and c == ti.C
+        oh = (ti.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        ow = (ti.W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        out = self.tensor(oh, ow, c, name=out_name)
+        woff = self.const_act(np.transpose(weight.astype(np.float64).reshape(c, k * k), (1, 0)))
+        boff = self.const_f32(bias)
+        self._op(OP_DW, [x, out, woff, boff, k, stride, pad, dil, ACT[act]], [self._tb(x)], [self._tb(out)])
+        return out
+
+    def upcat(self, lo: int, skip: int, out_name: str = "") -> int:
+        tl, ts = self.tensors[lo], self.tensors[skip]
+        assert (ts.H, ts.W) == (2 * tl.H, 2 * tl.W)
+        out = self.tensor(ts.H, ts.W, tl.C + ts.C, name=out_name)
+        self._op(OP_UPCAT, [lo, skip, out], [self._tb(lo), self._tb(skip)], [self._tb(out)])
+        return out
+
+    def gap(self, x: int) -> int:
+        out = self.buffer(self.tensors[x].C, ELEM_F32, "gap")
+        self._op(OP_GAP, [x, out], [self._tb(x)], [out])
+        return out
+
+    def fc(self, xbuf: int, weight: np.ndarray, bias: Optional[np.ndarray], act: str,
+           scale2: Optional[np.ndarray] = None, shift2: Optional[np.ndarray] = None, act2: str = "none") -> int:
+        """y = act(W x + b) on pooled f32 vectors; weight [N,K]."""
+        n, k = weight.shape
+        assert self.bufs[xbuf].elems == k
+        out = self.buffer(n, ELEM_F32, "fc")
+        woff = self.const_f32(np.transpose(weight.astype(np.float64), (1, 0)))
+        boff = self.const_f32(bias) if bias is not None else -1
+        s2 = self.const_f32(scale2) if scale2 is not None else -1
+        t2 = self.const_f32(shift2) if shift2 is not None else -1
+        self._op(OP_FC, [xbuf, out, woff, boff, k, n, ACT[act], s2, t2, ACT[act2]], [xbuf], [out])
+        return out
+
+    def scse(self, x: int, cse_buf: int, sse_w: np.ndarray, sse_b: float, out_name: str = "") -> int:
+        ti = self.tensors[x]
+        out = self.tensor(ti.H, ti.W, ti.C, name=out_name)
+        woff = self.const_f32(sse_w.reshape(-1))
+        bbits = struct.unpack("<i", struct.pack("<f", float(sse_b)))[0]
+        self._op(OP_SCSE, [x, out, cse_buf, woff, bbits], [self._tb(x), cse_buf], [self._tb(out)])
+        return out
+
+    def hmdec(self, val_buf: int, idx_buf: int, feat: int, off_w: np.ndarray, off_b: np.ndarray, points: int,
+              nslots: int) -> Tuple[int, int]:
+        loc = self.buffer(points * 2, ELEM_F32, "loc_fix", pinned=True)
+        score = self.buffer(points, ELEM_F32, "score", pinned=True)
+        woff = self.const_f32(off_w)
+        boff = self.const_f32(off_b)
+        self._op(OP_HMDEC, [val_buf, idx_buf, feat, woff, boff, points, nslots, loc, score],
+                 [val_buf, idx_buf, self._tb(feat)], [loc, score])
+        return loc, score
+
+    def maxpool(self, x: int, out: Optional[int] = None, out_name: str = "") -> int:
+        ti = self.tensors[x]
+        oh, ow = (ti.H + 1) // 2, (ti.W + 1) // 2
+        if out is None:
+            out = self.tensor(oh, ow, ti.C, name=out_name)
+        self._op(OP_MAXPOOL, [x, out], [self._tb(x)], [self._tb(out)])
+        return out
+
+    def copy(self, x: int, out: int, out_cs: int = 1, up: int = 1):
+        self._op(OP_COPY, [x, out, out_cs, up], [self._tb(x)], [self._tb(out)])
+
+    def detdec(self, x: int, rows_buf: int, row0: int, stride: float, anchors: np.ndarray, nrows_total: int):
+        aoff = self.const_f32(np.asarray(anchors, np.float64).reshape(-1))
+        sbits = struct.unpack("<i", struct.pack("<f", float(stride)))[0]
+        self._op(OP_DETDEC, [x, rows_buf, row0, sbits, aoff, nrows_total], [self._tb(x)], [rows_buf])
+
+    # ---- assembly ---------------------------------------------------------------------------
+    def _item_units(self, b: _Buf) -> int:
+        es = self.esize if b.etype == ELEM_ACT else (1 if b.etype == ELEM_U8 else 4)
+        return max(1, (b.elems * es + 255) // 256)
+
+    def _plan(self) -> int:
+        for oi, (_, _, reads, writes) in enumerate(self.ops):
+            for b in reads + writes:
+                bb = self.bufs[b]
+                bb.first = oi if bb.first is None else bb.first
+                bb.last = oi
+        n_ops = len(self.ops)
+        for b in self.bufs:
+            if b.first is None:
+                b.first, b.last = 0, n_ops
+            if b.pinned or self.keep_all:
+                b.first, b.last = 0, n_ops
+        # greedy first-fit over buffers sorted by first use; intervals [first, last]
+        placed: List[_Buf] = []
+        total = 0
+        for b in sorted(self.bufs, key=lambda q: (q.first, -self._item_units(q))):
+            size = self._item_units(b)
+            busy = sorted((p.offset_units, p.offset_units + self._item_units(p)) for p in placed
+                          if not (p.last < b.first or p.first > b.last))
+            off = 0
+            for lo, hi in busy:
+                if off + size <= lo:
+                    break
+                off = max(off, hi)
+            b.offset_units = off
+            placed.append(b)
+            total = max(total, off + size)
+        return total
+
+    def finish(self, out_bufs: Sequence[int]) -> bytes:
+        for ob in out_bufs:
+            self.bufs[ob].pinned = True
+        arena_units = self._plan()
+        outs = list(out_bufs) + [-1] * (3 - len(out_bufs))
+        blob = bytearray()
+        blob += struct.pack("<16i", MAGIC, VERSION, self.dtype, len(self.bufs), len(self.tensors), len(self.ops),
+                            len(self.consts), arena_units, self.in_h, self.in_w, outs[0], outs[1], outs[2], 0, 0, 0)
+        for b in self.bufs:
+            blob += struct.pack("<4i", b.etype, b.elems, b.offset_units, 0)
+        for t in self.tensors:
+            blob += struct.pack("<8i", t.buf, t.coff, t.ld, t.H, t.W, t.C, 0, 0)
+        for code, f, _, _ in self.ops:
+            blob += struct.pack(f"<{OP_FIELDS + 1}i", code, *f)
+        while len(blob) % 256:
+            blob.append(0)
+        blob += self.consts
+        return bytes(blob)

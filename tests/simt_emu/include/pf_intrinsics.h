@@ -1,0 +1,71 @@
+// CPU SIMT emulator flavour of csrc/pf_intrinsics.h -- TEST INFRASTRUCTURE ONLY.
+// Found ahead of the product header through the include path of the emulator build; implements
+// the CDNA4 matrix-core semantics the kernels rely on:
+//   v_mfma_f32_16x16x32_f16 : A lane l = A[i=l&15][k=8*(l>>4)..+7], B lane l = B[k=8*(l>>4)..+7][j=l&15]
+//   v_mfma_f32_16x16x4_f32  : A lane l = A[i=l&15][k=l>>4],        B lane l = B[k=l>>4][j=l&15]
+//   C/D (both)              : lane l, reg r -> row 4*(l>>4)+r, col l&15
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef _Float16 pf_half;
+typedef _Float16 pf_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pf_half4 __attribute__((ext_vector_type(4)));
+typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
+typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
+
+inline pf_f32x4 pf_mfma_16x16x32_f16(pf_half8 a, pf_half8 b, pf_f32x4 c) {
+    struct Pack { pf_half8 a, b; };
+    static_assert(sizeof(Pack) == 32, "pack");
+    pf_emu::WaveState& w = pf_emu::wave_state();
+    const int buf = w.gen & 1;
+    const int l = pf_emu::lane_id();
+    Pack p{a, b};
+    std::memcpy(w.stage[buf][l], &p, sizeof(p));
+    pf_emu::wave_barrier();
+    const int col = l & 15;
+    pf_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            Pack pa, pb;
+            std::memcpy(&pa, w.stage[buf][row + 16 * g], sizeof(Pack));
+            std::memcpy(&pb, w.stage[buf][col + 16 * g], sizeof(Pack));
+            for (int e = 0; e < 8; ++e) acc += (float)pa.a[e] * (float)pb.b[e];
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+inline pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
+    struct Pack { float a, b; };
+    pf_emu::WaveState& w = pf_emu::wave_state();
+    const int buf = w.gen & 1;
+    const int l = pf_emu::lane_id();
+    Pack p{a, b};
+    std::memcpy(w.stage[buf][l], &p, sizeof(p));
+    pf_emu::wave_barrier();
+    const int col = l & 15;
+    pf_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            Pack pa, pb;
+            std::memcpy(&pa, w.stage[buf][row + 16 * g], sizeof(Pack));
+            std::memcpy(&pb, w.stage[buf][col + 16 * g], sizeof(Pack));
+            acc = std::fmaf(pa.a, pb.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+inline float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
+inline int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
+inline float pf_rcp(float x) { return 1.0f / x; }
+inline float pf_exp(float x) { return std::exp(x); }
+
+#define PF_BUILD_TAG "simt-emu"
+#define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

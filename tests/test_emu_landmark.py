@@ -1,0 +1,82 @@
+"""Kernel-logic parity of the landmark regressor on the CPU SIMT emulator (no GPU needed).
+
+The emulator executes the *same* HIP sources (implicit-GEMM MFMA tiling, fused epilogues, SE /
+SCSE / ASPP fusions, fused heat-map arg-max) with gfx950 fragment layouts; the checker is the
+oracle.  This guards the indexing and fusion algebra; the real-hardware parity lives in
+test_gpu_landmark.py.
+"""
+import numpy as np
+import pytest
+
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from tests import helpers
+
+
+@pytest.mark.parametrize("size", [64, 128])
+def test_student_f32_layers_and_landmarks(emu_engine, student_weights, size):
+    B = 2
+    blob, info = build_student_program(student_weights, size, "f32", keep_all=True, debug_full_hm=True)
+    emu_engine.load_program(0, blob, B)
+    crops = sw.smooth_blob_images(B, size, seed=1000 + size)
+    loc, score = emu_engine.landmark_forward(crops)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    for name in info["tensors"]:
+        if name not in taps:
+            continue
+        ref = helpers.tap_nhwc(taps, name)
+        got = helpers.read_engine_tensor(emu_engine, 0, info, name, B, ref.shape[1:], 4)
+        rel = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12)
+        assert rel < 2e-4, (name, rel)
+    # tolerance of the north star is 1e-3 (normalised crop units); the f32 path is ~1e-5
+    margins = helpers.heat_margins(taps)
+    safe = margins > 1e-3
+    d = np.abs(loc - oloc).reshape(B, 98, 2).max(2)
+    assert d[safe].max() < 1e-4
+    assert np.abs(score - oscore)[safe].max() < 2e-3
+
+
+def test_student_f32_input_kinds_agree(emu_engine, student_weights):
+    """uint8 NHWC input (engine-native) and float32 NCHW /255 input (the ONNX seam) agree."""
+    B, size = 1, 64
+    blob, _ = build_student_program(student_weights, size, "f32")
+    emu_engine.load_program(0, blob, B)
+    crops = sw.smooth_blob_images(B, size, seed=5)
+    loc8, score8 = emu_engine.landmark_forward(crops)
+    xf = (crops.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2)
+    locf, scoref = emu_engine.landmark_forward(np.ascontiguousarray(xf))
+    assert np.abs(loc8 - locf).max() < 2e-4
+    assert np.abs(score8 - scoref).max() < 2e-3
+
+
+def test_student_buffer_reuse_matches_keep_all(emu_engine, student_weights):
+    """The lifetime-based arena planner must not change results."""
+    B, size = 2, 64
+    crops = sw.smooth_blob_images(B, size, seed=6)
+    outs = []
+    for keep in (True, False):
+        blob, _ = build_student_program(student_weights, size, "f32", keep_all=keep)
+        emu_engine.load_program(0, blob, B)
+        outs.append(emu_engine.landmark_forward(crops))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_student_f16_tracks_oracle(emu_engine, student_weights):
+    """f16 storage / f32 accumulate: every feature map within 5% of its range, landmarks equal
+    wherever the oracle's arg-max margin exceeds the accumulated f16 error."""
+    B, size = 2, 64
+    blob, info = build_student_program(student_weights, size, "f16", keep_all=True, debug_full_hm=True)
+    emu_engine.load_program(0, blob, B)
+    crops = sw.smooth_blob_images(B, size, seed=7)
+    loc, score = emu_engine.landmark_forward(crops)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    ref = helpers.tap_nhwc(taps, "hm")
+    got = helpers.read_engine_tensor(emu_engine, 0, info, "hm", B, ref.shape[1:], 8)
+    hm_err = np.abs(got - ref).max()
+    assert hm_err / np.abs(ref).max() < 0.08
+    margins = helpers.heat_margins(taps)
+    safe = margins > 4 * hm_err
+    if safe.any():
+        idx_ok = np.abs(loc - oloc).reshape(B, 98, 2).max(2)[safe]
+        assert idx_ok.max() < (4 * hm_err) / 64 + 1e-3
