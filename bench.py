@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Benchmark of the FaceAna hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already
+resident in HBM when the timed region starts:
+  --workload pipeline : BASELINE.json configs[2] -- F 1080p frames x 8 planted faces each through
+                        letterbox -> detector net -> decode -> NMS -> top-k -> crop/resize ->
+                        Student@256 -> heat-map decode -> back-projection   (default when built)
+  --workload landmark : BASELINE.json configs[1] -- 256 pre-cropped 256x256 faces through Student@256
+Frames / faces shard across ranks with no data-path collective (weak scaling: per-rank work is
+fixed); the only collective is the one-time RCCL broadcast of the packed weights from rank 0.
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GFLOP_PER_FACE = 2.968       # Student@256 inference graph, SURVEY.md section 8(d) (1 484.1 M MAC)
+GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstream figure)
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
+HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto", "landmark", "pipeline"])
+    ap.add_argument("--batch", type=int, default=256, help="faces per step per GPU (landmark workload)")
+    ap.add_argument("--frames", type=int, default=32, help="1080p frames per step per GPU (pipeline workload)")
+    ap.add_argument("--faces-per-frame", type=int, default=8)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-faces", type=int, default=48)
+    return ap.parse_args()
+
+
+def cpu_baseline(workload: str, n_faces: int):
+    """Reference-shaped CPU path timed on this box's host cores: the torch-CPU oracle (stand-in for
+    onnxruntime-CPU, which is not installed) run exactly like face_landmark.py:40-48 -- one face at
+    a time, batch 1, float32 -- on a bounded sample.  Baseline, not target."""
+    import torch
+    from oracle import landmark_net as ln
+    from oracle import synth_weights as sw
+
+    W = ln.to_torch(sw.student_weights())
+    crops = sw.smooth_blob_images(8, 256, seed=99)
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        ln.student_forward(W, x[:1])
+        t0 = time.perf_counter()
+        for i in range(n_faces):
+            ln.student_forward(W, x[i % 8:i % 8 + 1])
+        dt = time.perf_counter() - t0
+    return {"value": round(n_faces / dt, 2), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d faces, Student@256 landmark forward only, batch=1 python loop (face_landmark.py:40-48 shape), "
+                      "torch-CPU f32 oracle as stand-in for onnxruntime-CPU; %.1f s" % (n_faces, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from peppa_pig_face_landmark_amd import build as pbuild
+    from peppa_pig_face_landmark_amd._native import Engine, PF_INPUT_U8_NHWC
+    from peppa_pig_face_landmark_amd import bench_support as bs
+
+    if rank == 0:
+        pbuild.build_hip()
+    if world > 1:
+        dist.barrier()
+    eng = Engine(local_rank)
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "pipeline" if bs.pipeline_available() else "landmark"
+
+    # ---- weights: packed on rank 0, broadcast once over RCCL / xGMI -----------------------------
+    t0 = time.time()
+    blobs = bs.build_programs(workload, args.dtype) if rank == 0 else None
+    bcast_ms = 0.0
+    if world > 1:
+        blobs, bcast_ms = bs.broadcast_blobs(blobs, dev, rank)
+    faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
+    bs.load_programs(eng, blobs, workload, faces_per_step, args.frames)
+    setup_s = time.time() - t0
+
+    # ---- synthetic inputs, resident in HBM ----------------------------------------------------------
+    if workload == "landmark":
+        state = bs.LandmarkWorkload(eng, dev, args.batch, seed=1234 + rank)
+    else:
+        state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        state.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        state.step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    barrier()
+    state.check()
+
+    # ---- per-kernel device time (HIP events on the engine's own stream), dominant kernel roofline ---
+    prof = state.profile(3)
+    hero_ms, hero_n = prof.get(HERO_TAG, (0.0, 0))
+    roofline = None
+    if hero_n:
+        avg_ms = hero_ms / hero_n
+        achieved = HERO_FLOP_PER_FACE * faces_per_step / (avg_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128> %s" % (args.dtype, HERO_TAG),
+                    "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": hero_n}
+
+    ms_per_step = elapsed / args.steps * 1e3
+    faces_total = faces_per_step * world * args.steps
+    value = faces_total / elapsed
+    out = {
+        "metric": "faces/sec (whole node), Student@256" + (" 1080px8-face full pipeline" if workload == "pipeline" else " landmark-only"),
+        "value": round(value, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": ("configs[2] full pipeline: %d x 1080p frames x %d planted faces per GPU per step" % (args.frames, args.faces_per_frame))
+                   if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
+                   "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d, no data-path collective" % world,
+                   "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast %.2f ms" % bcast_ms},
+        "roofline": roofline,
+        "cpu_baseline": None,
+        "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
+                  "algorithmic_tflops": round(value * GFLOP_PER_FACE / 1e3, 2),
+                  "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE / 1e3 / PEAK_TFLOPS[args.dtype], 4),
+                  "setup_s": round(setup_s, 2),
+                  "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(workload, args.cpu_faces)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

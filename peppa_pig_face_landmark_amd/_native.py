@@ -220,10 +220,11 @@ class Engine:
         self._check(self.lib.pf_profile_enable(self.h, 1 if on else 0), "pf_profile_enable")
 
     def profile_fetch(self):
-        names = C.create_string_buffer(4096)
-        ms = (C.c_float * 64)()
-        cnt = (C.c_int * 64)()
+        cap = 256
+        names = C.create_string_buffer(16384)
+        ms = (C.c_float * cap)()
+        cnt = (C.c_int * cap)()
         n = C.c_int(0)
-        self._check(self.lib.pf_profile_fetch(self.h, names, 4096, ms, cnt, 64, C.byref(n)), "pf_profile_fetch")
+        self._check(self.lib.pf_profile_fetch(self.h, names, 16384, ms, cnt, cap, C.byref(n)), "pf_profile_fetch")
         tags = [t for t in names.value.decode().split("\n") if t]
         return {tags[k]: (float(ms[k]), int(cnt[k])) for k in range(n.value)}

@@ -1,0 +1,119 @@
+"""Benchmark plumbing shared by bench.py: program packing, RCCL weight broadcast, device-resident
+synthetic workloads.  torch is used only for device memory and torch.distributed (plumbing); every
+kernel on the timed path is the HIP engine's."""
+from __future__ import annotations
+
+import time
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _native
+from .graph.random_init import random_student_weights
+from .graph.student import build_student_program
+
+try:  # the detector program builder arrives with the full pipeline
+    from .graph.detector import build_detector_program, random_detector_weights
+except ImportError:  # pragma: no cover
+    build_detector_program = None
+    random_detector_weights = None
+
+
+def pipeline_available() -> bool:
+    return build_detector_program is not None
+
+
+def build_programs(workload: str, dtype: str) -> Dict[int, bytes]:
+    blobs = {_native.PF_NET_LANDMARK: build_student_program(random_student_weights(0), 256, dtype)[0]}
+    if workload == "pipeline":
+        blobs[_native.PF_NET_DETECTOR] = build_detector_program(random_detector_weights(1), (384, 640), dtype)[0]
+    return blobs
+
+
+def broadcast_blobs(blobs: Optional[Dict[int, bytes]], dev, rank: int) -> Tuple[Dict[int, bytes], float]:
+    """One-time weight distribution: rank 0's packed programs -> every rank, as uint8 HBM tensors
+    over RCCL (torch.distributed 'nccl' backend == RCCL on ROCm).  Returns (blobs, milliseconds)."""
+    import torch
+    import torch.distributed as dist
+
+    meta = torch.zeros(8, dtype=torch.int64, device=dev)
+    if rank == 0:
+        slots = sorted(blobs)
+        meta[0] = len(slots)
+        for i, s in enumerate(slots):
+            meta[1 + 2 * i] = s
+            meta[2 + 2 * i] = len(blobs[s])
+    dist.broadcast(meta, 0)
+    n = int(meta[0].item())
+    out: Dict[int, bytes] = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tensors = []
+    for i in range(n):
+        slot, size = int(meta[1 + 2 * i].item()), int(meta[2 + 2 * i].item())
+        if rank == 0:
+            t = torch.frombuffer(bytearray(blobs[slot]), dtype=torch.uint8).to(dev)
+        else:
+            t = torch.empty(size, dtype=torch.uint8, device=dev)
+        dist.broadcast(t, 0)
+        tensors.append((slot, t))
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    for slot, t in tensors:
+        out[slot] = t.cpu().numpy().tobytes()
+    return out, ms
+
+
+def load_programs(eng: "_native.Engine", blobs: Dict[int, bytes], workload: str, faces: int, frames: int):
+    eng.load_program(_native.PF_NET_LANDMARK, blobs[_native.PF_NET_LANDMARK], faces)
+    if workload == "pipeline":
+        eng.load_program(_native.PF_NET_DETECTOR, blobs[_native.PF_NET_DETECTOR], frames)
+
+
+def synthetic_crops(n: int, size: int, seed: int) -> np.ndarray:
+    """uint8 [n,size,size,3]: smooth blobs + noise (SURVEY 8d set B), 8 distinct images tiled."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    base = []
+    for _ in range(min(n, 8)):
+        img = np.full((size, size, 3), 40.0, np.float32)
+        for c in range(3):
+            for _ in range(6):
+                cx, cy = rng.uniform(0, size, 2)
+                sig = rng.uniform(8.0, 40.0) * size / 256.0
+                img[:, :, c] += rng.uniform(40.0, 200.0) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sig * sig))
+        img += rng.normal(0.0, 6.0, img.shape)
+        base.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+    reps = (n + len(base) - 1) // len(base)
+    return np.stack((base * reps)[:n])
+
+
+class LandmarkWorkload:
+    """BASELINE configs[1]: B pre-cropped 256x256 faces, device resident, outputs stay on device."""
+
+    def __init__(self, eng, dev, batch: int, seed: int):
+        import torch
+        self.eng, self.batch = eng, batch
+        self.crops = torch.from_numpy(synthetic_crops(batch, 256, seed)).to(dev)
+        self.loc = torch.empty((batch, 196), dtype=torch.float32, device=dev)
+        self.score = torch.empty((batch, 98), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+
+    def step(self):
+        self.eng.landmark_forward_device(self.crops.data_ptr(), _native.PF_INPUT_U8_NHWC, self.batch,
+                                         self.loc.data_ptr(), self.score.data_ptr())
+
+    def check(self):
+        import torch
+        self.eng.sync()
+        assert bool(torch.isfinite(self.loc).all()) and bool(torch.isfinite(self.score).all()), "non-finite landmarks"
+
+    def profile(self, steps: int):
+        self.eng.sync()
+        self.eng.profile_enable(True)
+        for _ in range(steps):
+            self.step()
+        self.eng.sync()
+        prof = self.eng.profile_fetch()
+        self.eng.profile_enable(False)
+        return prof

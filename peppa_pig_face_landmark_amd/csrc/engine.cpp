@@ -83,9 +83,9 @@ static std::string g_create_error;
 // profiling helper: wraps one launch in an event pair when enabled
 struct ProfScope {
     pf_handle* h;
-    const char* tag;
-    ProfScope(pf_handle* h_, const char* tag_) : h(h_), tag(tag_) {
-        if (h->profiling) (void)hipEventRecord(h->ev0, h->stream);
+    std::string tag;
+    ProfScope(pf_handle* h_, const char* tag_) : h(h_) {
+        if (h->profiling) { tag = tag_; (void)hipEventRecord(h->ev0, h->stream); }
     }
     ~ProfScope() {
         if (!h->profiling) return;
@@ -127,7 +127,12 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256}, bn[PF_CONV_NCFG] = {128, 64, 32, 16};
     if (a.amax_val && ((a.outH * a.outW) % bm[cfg]) != 0) PF_FAIL(h, "argmax conv: H*W=%d not a multiple of BM=%d", a.outH * a.outW, bm[cfg]);
     dim3 grid(pf_div_up(M, bm[cfg]), pf_div_up(a.Npad, bn[cfg]));
-    ProfScope ps(h, a.KH == 1 ? (a.amax_val ? "conv1x1_argmax" : "conv1x1") : "conv3x3");
+    char tagbuf[96];
+    tagbuf[0] = 0;
+    if (h->profiling)
+        snprintf(tagbuf, sizeof(tagbuf), "conv%dx%d%s_c%d_n%d_%dx%d", a.KH, a.KW, a.amax_val ? "_argmax" : "", a.inC, a.N,
+                 a.outH, a.outW);
+    ProfScope ps(h, tagbuf);
     switch (cfg) {
         case 0: PF_LAUNCH((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), h->stream, a); break;
         case 1: PF_LAUNCH((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), h->stream, a); break;

@@ -1,0 +1,114 @@
+"""Parity of the HIP landmark regressor on a real MI355X (through the C ABI) against the oracle.
+
+Tolerance: the north star asks for landmarks within 1e-3 (normalised crop units, the ONNX
+output units of model.py:549-552) on identical 256x256 crops.  The f32 path is checked at 1e-4.
+"""
+import numpy as np
+import pytest
+
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+LANDMARK_TOL = 1e-3  # north-star tolerance; asserted values below are tighter where stated
+
+
+def _layer_report(eng, info, taps, batch, ve):
+    worst = ("", 0.0)
+    for name in info["tensors"]:
+        if name not in taps:
+            continue
+        ref = helpers.tap_nhwc(taps, name)
+        got = helpers.read_engine_tensor(eng, 0, info, name, batch, ref.shape[1:], ve)
+        rel = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+        if rel > worst[1]:
+            worst = (name, rel)
+    return worst
+
+
+@pytest.mark.parametrize("size,batch", [(256, 4), (128, 3)])
+def test_student_f32_matches_oracle(gpu_engine, student_weights, size, batch):
+    blob, info = build_student_program(student_weights, size, "f32", keep_all=True, debug_full_hm=True)
+    gpu_engine.load_program(0, blob, batch)
+    crops = sw.smooth_blob_images(batch, size, seed=4000 + size)
+    loc, score = gpu_engine.landmark_forward(crops)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    name, rel = _layer_report(gpu_engine, info, taps, batch, 4)
+    assert rel < 5e-4, (name, rel)
+    margins = helpers.heat_margins(taps)
+    safe = margins > 2e-3
+    assert safe.mean() > 0.9
+    d = np.abs(loc - oloc).reshape(batch, 98, 2).max(2)
+    assert d[safe].max() < 1e-4 < LANDMARK_TOL
+    assert np.abs(score - oscore)[safe].max() < 5e-3
+    # unsafe (near-tie) landmarks may pick the other of two equal-height cells; report, don't hide
+    flips = int((d[~safe] > LANDMARK_TOL).sum())
+    print(f"near-tie landmarks: {int((~safe).sum())}, of which flipped: {flips}")
+
+
+def test_student_f32_production_program_equals_debug_program(gpu_engine, student_weights):
+    """Arena reuse + fused 98-channel head give the same answers as the keep-all debug build."""
+    size, batch = 256, 4
+    crops = sw.smooth_blob_images(batch, size, seed=11)
+    blob, _ = build_student_program(student_weights, size, "f32", keep_all=True, debug_full_hm=True)
+    gpu_engine.load_program(0, blob, batch)
+    a = gpu_engine.landmark_forward(crops)
+    blob, _ = build_student_program(student_weights, size, "f32")
+    gpu_engine.load_program(0, blob, batch)
+    b = gpu_engine.landmark_forward(crops)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_student_f32_batch_256_is_batch_independent(gpu_engine, student_weights):
+    """BASELINE config 2 size (256 crops): every face's result is independent of its batch-mates
+    (size-independent property; the oracle cannot run 256 faces in seconds)."""
+    size = 256
+    blob, _ = build_student_program(student_weights, size, "f32")
+    gpu_engine.load_program(0, blob, 256)
+    base = sw.smooth_blob_images(8, size, seed=21)
+    big = np.concatenate([base] * 32, 0)
+    perm = np.random.default_rng(3).permutation(256)
+    loc, score = gpu_engine.landmark_forward(big[perm])
+    loc8, score8 = gpu_engine.landmark_forward(base)
+    assert np.array_equal(loc, loc8[perm % 8])
+    assert np.array_equal(score, score8[perm % 8])
+    oloc, _, taps = helpers.oracle_student(student_weights, base)
+    safe = helpers.heat_margins(taps) > 2e-3
+    assert np.abs(loc8 - oloc).reshape(8, 98, 2).max(2)[safe].max() < 1e-4
+
+
+def test_student_f32_nchw_float_input_seam(gpu_engine, student_weights):
+    """ONNXEngine-level seam: float32 NCHW /255 input (face_landmark.py:44-47) == uint8 NHWC path."""
+    size, batch = 256, 2
+    blob, _ = build_student_program(student_weights, size, "f32")
+    gpu_engine.load_program(0, blob, batch)
+    crops = sw.smooth_blob_images(batch, size, seed=31)
+    loc8, score8 = gpu_engine.landmark_forward(crops)
+    xf = np.ascontiguousarray((crops.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2))
+    locf, scoref = gpu_engine.landmark_forward(xf)
+    assert np.abs(loc8 - locf).max() < 1e-4
+    assert np.abs(score8 - scoref).max() < 5e-3
+
+
+def test_student_f16_fast_mode(gpu_engine, student_weights):
+    """f16 storage / f16 MFMA / f32 accumulate fast mode: heat-maps within 8% of range on the
+    noise-like synthetic weights; landmarks agree wherever the oracle's arg-max margin exceeds
+    the measured heat-map error (SURVEY 8c protocol).  Flip rate is printed, not hidden."""
+    size, batch = 256, 4
+    blob, info = build_student_program(student_weights, size, "f16", keep_all=True, debug_full_hm=True)
+    gpu_engine.load_program(0, blob, batch)
+    crops = sw.smooth_blob_images(batch, size, seed=41)
+    loc, score = gpu_engine.landmark_forward(crops)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    ref = helpers.tap_nhwc(taps, "hm")
+    got = helpers.read_engine_tensor(gpu_engine, 0, info, "hm", batch, ref.shape[1:], 8)
+    hm_err = float(np.abs(got - ref).max())
+    assert hm_err / np.abs(ref).max() < 0.08
+    margins = helpers.heat_margins(taps)
+    d = np.abs(loc - oloc).reshape(batch, 98, 2).max(2)
+    safe = margins > 4 * hm_err
+    print(f"f16: hm max err {hm_err:.4f}; landmarks beyond 1e-3: {(d > 1e-3).mean():.3f}; safe frac {safe.mean():.3f}")
+    if safe.any():
+        assert d[safe].max() < 4 * hm_err / 64 + 1e-3
