@@ -100,6 +100,21 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
                           float min_face, int top_k,
                           int* counts, float* boxes, float* kps, float* scores, int out_mem);
 
+/* Stage-level entry points (each is one reference function on its own; the parity tests check
+ * them bit-for-bit against the numpy/OpenCV restatement):
+ *  pf_letterbox   == FaceDetector.preprocess up to the float conversion (face_detector.py:45-63):
+ *                    BGR frame -> RGB uint8 [out_h][out_w][3] letterboxed with 114; info = scale,left,top
+ *  pf_nms_rows    == xywh2xyxy + py_nms + scale_coords (face_detector.py:31-37,73-136) on decoded
+ *                    rows [R][16] (host); kept rows (xyxy in frame coords) in keep order
+ *  pf_crop_faces  == FaceLandmark.preprocess (face_landmark.py:66-104): crops uint8 [n][S][S][3] and
+ *                    params [n][8] = valid, add, x0, y0, xs, ys, w_crop, h_crop */
+int pf_letterbox(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 int out_h, int out_w, uint8_t* out_host, float* info3);
+int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, float left, float top,
+                float score_thres, float iou_thres, float* kept, int max_n, int* n_out);
+int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                  const float* boxes, int n, int out_size, uint8_t* crops_host, int* params_host);
+
 /* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream
  * when profiling is enabled.  names: '\n'-separated kernel tags; ms: same order. */
 int pf_profile_enable(pf_handle* h, int on);

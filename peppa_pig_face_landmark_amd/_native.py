@@ -44,11 +44,14 @@ def _declare(lib):
     lib.pf_landmarks.argtypes = [vp, vp, i, i, i, i, fp, i, fp, fp, ip]
     lib.pf_run_frames.argtypes = [vp, vp, i, i, i, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_run_frames_planted.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
+    lib.pf_letterbox.argtypes = [vp, vp, i, i, i, i, i, i, vp, fp]
+    lib.pf_nms_rows.argtypes = [vp, fp, i, f, f, f, f, f, fp, i, ip]
+    lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
     lib.pf_profile_enable.argtypes = [vp, i]
     lib.pf_profile_fetch.argtypes = [vp, C.c_char_p, sz, fp, ip, i, ip]
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
                  "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
-                 "pf_profile_enable", "pf_profile_fetch"):
+                 "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces"):
         getattr(lib, name).restype = i
     return lib
 
@@ -214,6 +217,40 @@ class Engine:
                                             _ptr(d_boxes) if d_boxes else None, _ptr(d_kps) if d_kps else None,
                                             _ptr(d_scores) if d_scores else None, PF_MEM_DEVICE)
         self._check(rc, "pf_run_frames_planted")
+
+    # ---- stage-level seams -----------------------------------------------------------------------
+    def letterbox(self, image_bgr: np.ndarray, out_hw=(384, 640)):
+        """FaceDetector.preprocess (uint8 stage): -> (RGB uint8 [H,W,3], [scale, left, top])."""
+        img = np.ascontiguousarray(image_bgr)
+        out = np.empty((out_hw[0], out_hw[1], 3), np.uint8)
+        info = np.zeros(3, np.float32)
+        self._check(self.lib.pf_letterbox(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                          out_hw[0], out_hw[1], _ptr(out), info.ctypes.data_as(C.POINTER(C.c_float))),
+                    "pf_letterbox")
+        return out, info
+
+    def nms_rows(self, rows: np.ndarray, scale: float, left: float, top: float, score_thres: float, iou_thres: float,
+                 max_n: int = 1024) -> np.ndarray:
+        """xywh2xyxy + py_nms + scale_coords on decoded rows [R,16]."""
+        r = np.ascontiguousarray(rows, np.float32)
+        kept = np.empty((max_n, 16), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.pf_nms_rows(self.h, r.ctypes.data_as(C.POINTER(C.c_float)), r.shape[0], float(scale),
+                                         float(left), float(top), float(score_thres), float(iou_thres),
+                                         kept.ctypes.data_as(C.POINTER(C.c_float)), max_n, C.byref(n)), "pf_nms_rows")
+        return kept[:n.value].copy()
+
+    def crop_faces(self, image_bgr: np.ndarray, boxes: np.ndarray, out_size: int = 256):
+        """FaceLandmark.preprocess: -> (crops uint8 [n,S,S,3], params int32 [n,8])."""
+        img = np.ascontiguousarray(image_bgr)
+        b = np.ascontiguousarray(np.asarray(boxes, np.float32)[:, :4])
+        n = b.shape[0]
+        crops = np.zeros((n, out_size, out_size, 3), np.uint8)
+        params = np.zeros((n, 8), np.int32)
+        self._check(self.lib.pf_crop_faces(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                           b.ctypes.data_as(C.POINTER(C.c_float)), n, out_size, _ptr(crops),
+                                           params.ctypes.data_as(C.POINTER(C.c_int))), "pf_crop_faces")
+        return crops, params
 
     # ---- profiling ----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

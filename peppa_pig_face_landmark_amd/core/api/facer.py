@@ -1,0 +1,144 @@
+"""FaceAna: the public API of the reference (Skps/core/api/facer.py:25-208) on the MI355X engine.
+
+``FaceAna().run(image_bgr) -> [{'box': (4,), 'kps': (98,2), 'scores': (98,)}, ...]`` and
+``reset()`` keep the reference's semantics, including the frame-difference gate that skips the
+detector on static video (facer.py:98-118), IoU matching + EMA of boxes against the previous frame
+(:144-189), top-k by area (:120-142) and One-Euro landmark smoothing.  The two network stages run
+on the GPU through ``pf_detect`` / ``pf_landmarks``; the per-frame bookkeeping stays host-side
+Python exactly where the reference has it."""
+from __future__ import annotations
+
+import logging
+import os
+import pathlib
+from typing import Dict, Optional
+
+import numpy as np
+import yaml
+
+from ... import _native
+from ...logger.logger import logger
+from ..smoother.lk import EmaFilter, GroupTrack
+from .face_detector import FaceDetector
+from .face_landmark import FaceLandmark
+
+
+def get_cfg(path: Optional[str] = None):
+    root = pathlib.Path(__file__).resolve().parents[2]
+    path = path or os.path.join(root, "config", "Skps.yml")
+    with open(path, encoding="UTF-8") as f:
+        return yaml.safe_load(f)
+
+
+def _load_weights(root, rel_path: str, what: str) -> Dict[str, np.ndarray]:
+    path = rel_path if os.path.isabs(rel_path) else os.path.join(root, rel_path)
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{what} weights not found at {path}.  The reference's .onnx blobs are not redistributable here; "
+            "export the checkpoint's state_dict to an .npz (tensor names as in the reference) or pass "
+            "FaceAna(weights={'detector': {...}, 'keypoints': {...}}).")
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _box_iou(a, b) -> float:
+    total = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1])
+    iw = max(0, min(a[2], b[2]) - max(a[0], b[0]))
+    ih = max(0, min(a[3], b[3]) - max(a[1], b[1]))
+    inter = iw * ih
+    return inter / (total - inter)
+
+
+class FaceAna:
+    def __init__(self, verbose: bool = False, cfg: Optional[dict] = None, weights: Optional[dict] = None,
+                 device: Optional[int] = None, library: Optional[str] = None):
+        if verbose:
+            logger.setLevel(logging.DEBUG)
+        cfg = cfg or get_cfg()
+        sk = cfg["Skps"]
+        eng_cfg = sk.get("Engine", {})
+        dev = int(eng_cfg.get("device", 0)) if device is None else int(device)
+        dtype = eng_cfg.get("dtype", "f32")
+        root = pathlib.Path(__file__).resolve().parents[2]
+        weights = weights or {}
+        det_w = weights.get("detector") or _load_weights(root, sk["Detect"]["model_path"], "detector")
+        kps_w = weights.get("keypoints") or _load_weights(root, sk["Keypoints"]["model_path"], "keypoints")
+
+        self.top_k = sk["Detect"]["topk"]
+        self.engine = _native.Engine(dev, library)      # one GPU, one stream, shared by both stages
+        max_faces = max(int(eng_cfg.get("max_faces", 8)), int(self.top_k))
+        self.face_detector = FaceDetector(sk["Detect"], det_w, engine=self.engine, dtype=dtype)
+        self.face_landmark = FaceLandmark(sk["Keypoints"], kps_w, engine=self.engine, dtype=dtype, max_batch=max_faces)
+        self.trace = GroupTrack(sk["Trace"])
+        logger.info("model init done!")
+
+        self.track_box = None
+        self.previous_image = None
+        self.previous_box = None
+        self.diff_thres = 5
+        self.min_face = sk["Detect"]["min_face"]
+        self.iou_thres = sk["Trace"]["iou_thres"]
+        self.alpha = sk["Trace"]["smooth_box"]
+        self.filter = EmaFilter(self.alpha)
+
+    # ---- per-frame entry ---------------------------------------------------------------------------
+    def run(self, image: np.ndarray):
+        if self.diff_frames(self.previous_image, image):
+            boxes = self.face_detector(image)
+            self.previous_image = image
+            boxes = self.judge_boxs(self.track_box, boxes)
+            self.trace.previous_landmarks_set = None     # detector ran: smoothing history is dropped
+        else:
+            boxes = self.track_box
+            self.previous_image = image
+        boxes = self.sort_and_filter(boxes)
+        boxes_return = np.array(boxes)
+        landmarks, states = self.face_landmark(image, boxes)
+        landmarks = self.trace.calculate(image, landmarks)
+        hulls = [[np.min(l[:, 0]), np.min(l[:, 1]), np.max(l[:, 0]), np.max(l[:, 1])] for l in landmarks]
+        self.track_box = self.judge_boxs(boxes_return, np.array(hulls))
+        return self.to_dict(self.track_box, landmarks, states)
+
+    def to_dict(self, bboxes, kps, states):
+        return [{"box": bboxes[i], "kps": kps[i], "scores": states[i]} for i in range(len(bboxes))]
+
+    def diff_frames(self, previous_frame, image) -> bool:
+        """True -> run the detector (facer.py:98-118): mean absolute difference of the frames > 5."""
+        if previous_frame is None:
+            return True
+        if previous_frame.shape != image.shape:
+            return True
+        diff = np.abs(previous_frame.astype(np.int16) - image.astype(np.int16)).sum(dtype=np.int64)
+        return diff / previous_frame.shape[0] / previous_frame.shape[1] / 3.0 > self.diff_thres
+
+    def sort_and_filter(self, bboxes):
+        if len(bboxes) < 1:
+            return []
+        area = (bboxes[:, 2] - bboxes[:, 0]) * (bboxes[:, 3] - bboxes[:, 1])
+        keep = area > self.min_face
+        area, bboxes = area[keep], bboxes[keep, :]
+        if bboxes.shape[0] > self.top_k:
+            bboxes = bboxes[area.argsort()[-self.top_k:][::-1]]
+        return np.array(bboxes)
+
+    def judge_boxs(self, previuous_bboxs, now_bboxs):
+        """Match each current box to the first previous box with IoU > thres and EMA-smooth it."""
+        if previuous_bboxs is None:
+            return now_bboxs
+        out = []
+        for i in range(now_bboxs.shape[0]):
+            for j in range(previuous_bboxs.shape[0]):
+                if _box_iou(now_bboxs[i], previuous_bboxs[j]) > self.iou_thres:
+                    out.append(self.smooth(now_bboxs[i], previuous_bboxs[j]))
+                    break
+            else:
+                out.append(now_bboxs[i][0:4])
+        return np.array(out)
+
+    def smooth(self, now_box, previous_box):
+        return self.filter(now_box[:4], previous_box[:4])
+
+    def reset(self):
+        self.track_box = None
+        self.previous_image = None
+        self.previous_box = None

@@ -116,13 +116,10 @@ int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const Lett
     return 0;
 }
 
-// crop boxes -> crops -> landmark program (with back-projection to frame coordinates)
-int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
-                       const float* d_boxes, const int* d_counts, int faces, int per_frame) {
-    Program& lm = h->prog[PF_NET_LANDMARK];
+// crop boxes -> uint8 crops (FaceLandmark.preprocess)
+int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
+                   const float* d_boxes, const int* d_counts, int faces, int per_frame, int S) {
     PipelineScratch& s = h->pipe;
-    const int S = lm.hdr.in_h;
-    if (faces > lm.max_batch) PF_FAIL(h, "%d faces exceed the landmark program's max_batch %d", faces, lm.max_batch);
     if (ensure_dev(h, s.d_crops, s.crops_bytes, (size_t)faces * S * S * 3)) return 1;
     CropParamArgs ca{};
     ca.boxes = d_boxes; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
@@ -140,6 +137,16 @@ int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W
         ProfScope ps(h, "crop_resize");
         PF_LAUNCH(crop_resize_kernel, dim3(pf_div_up(S * S, 256), faces), dim3(256), h->stream, ra);
     }
+    return 0;
+}
+
+// crops -> landmark program (with back-projection to frame coordinates)
+int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
+                       const float* d_boxes, const int* d_counts, int faces, int per_frame) {
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    PipelineScratch& s = h->pipe;
+    if (faces > lm.max_batch) PF_FAIL(h, "%d faces exceed the landmark program's max_batch %d", faces, lm.max_batch);
+    if (run_crop_stage(h, d_frames, H, W, row_stride, d_boxes, d_counts, faces, per_frame, lm.hdr.in_h)) return 1;
     s.d_crop_for_decode = s.d_cropf;
     s.d_kps_for_decode = s.d_kps;
     const int rc = run_program(h, PF_NET_LANDMARK, s.d_crops, PF_INPUT_U8_NHWC, faces);
@@ -247,6 +254,64 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
     if (scores) PF_HIP(h, hipMemcpyAsync(scores, lm.buf_ptr(lm.hdr.out_buf1), (size_t)faces * kNumPoints * sizeof(float), kind, h->stream));
     if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_letterbox(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 int out_h, int out_w, uint8_t* out_host, float* info3) {
+    if (!h) return 1;
+    if (!bgr || !out_host || height < 1 || width < 1 || out_h < 1 || out_w < 1 || row_stride < width * 3) PF_FAIL(h, "pf_letterbox: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    const unsigned char* d_frames = nullptr;
+    if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
+    const LetterboxGeom g = letterbox_geom(height, width, out_h, out_w);
+    if (ensure_dev(h, h->pipe.d_letterbox, h->pipe.letterbox_bytes, (size_t)out_h * out_w * 3)) return 1;
+    LetterboxArgs la{};
+    la.frames = d_frames; la.out = h->pipe.d_letterbox;
+    la.F = 1; la.H = height; la.W = width; la.row_stride = row_stride; la.outH = out_h; la.outW = out_w;
+    la.rw = g.rw; la.rh = g.rh; la.top = g.top; la.left = g.left;
+    la.scale_x = g.scale_x; la.scale_y = g.scale_y; la.pad_value = 114;
+    PF_LAUNCH(letterbox_kernel, dim3(pf_div_up(out_h * out_w, 256), 1), dim3(256), h->stream, la);
+    PF_HIP(h, hipMemcpyAsync(out_host, h->pipe.d_letterbox, (size_t)out_h * out_w * 3, hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (info3) { info3[0] = (float)g.scale; info3[1] = (float)g.left; info3[2] = (float)g.top; }
+    return 0;
+}
+
+int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, float left, float top,
+                float score_thres, float iou_thres, float* kept, int max_n, int* n_out) {
+    if (!h) return 1;
+    if (!rows_host || n_rows < 1 || !kept || !n_out) PF_FAIL(h, "pf_nms_rows: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    if (ensure_pipeline(h, 1, 0, 1, n_rows)) return 1;
+    const size_t bytes = (size_t)n_rows * 16 * sizeof(float);
+    if (ensure_dev(h, h->pipe.d_rows_planted, h->pipe.rows_planted_bytes, bytes)) return 1;
+    PF_HIP(h, hipMemcpyAsync(h->pipe.d_rows_planted, rows_host, bytes, hipMemcpyHostToDevice, h->stream));
+    LetterboxGeom g{};
+    g.scale = scale; g.left = (int)left; g.top = (int)top;
+    if (run_nms_stage(h, h->pipe.d_rows_planted, n_rows, 1, g, score_thres, iou_thres, 0.f, 1, false)) return 1;
+    int n = 0;
+    PF_HIP(h, hipMemcpyAsync(&n, h->pipe.d_keep_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    n = std::min(n, max_n);
+    if (n > 0) PF_HIP(h, hipMemcpy(kept, h->pipe.d_keep_rows, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost));
+    *n_out = n;
+    return 0;
+}
+
+int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                  const float* boxes, int n, int out_size, uint8_t* crops_host, int* params_host) {
+    if (!h) return 1;
+    if (!bgr || !boxes || n < 1 || out_size < 1 || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_crop_faces: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    if (ensure_pipeline(h, 1, n, n, 2)) return 1;
+    const unsigned char* d_frames = nullptr;
+    if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
+    PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (run_crop_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n, out_size)) return 1;
+    if (crops_host) PF_HIP(h, hipMemcpyAsync(crops_host, h->pipe.d_crops, (size_t)n * out_size * out_size * 3, hipMemcpyDeviceToHost, h->stream));
+    if (params_host) PF_HIP(h, hipMemcpyAsync(params_host, h->pipe.d_crop_params, (size_t)n * 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

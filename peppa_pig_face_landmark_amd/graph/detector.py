@@ -1,0 +1,185 @@
+"""yolov5n-0.5 face detector -> packed HIP program.
+
+The reference executes a pre-exported third-party blob (``pretrained/yolov5n-0.5.onnx``,
+Skps/config/Skps.yml:4; deepcam-cn/yolov5-face, README.md:24-26) whose contract is pinned at
+Skps/core/api/face_detector.py:29-37: ``[1,3,384,640]`` RGB/255 in, ``(15120,16)`` decoded rows
+out.  The graph here follows the published ``yolov5n-0.5.yaml`` (StemBlock, ShuffleV2 backbone,
+PAN head with C3 blocks, Detect with 3 anchors x 16 outputs per level) with ``Conv`` =
+Conv2d + BatchNorm(eps 1e-3) + SiLU folded into fused implicit-GEMM launches.
+
+``weights``: ``{name: ndarray}`` with upstream state_dict names (``model.0.stem_1.conv.weight`` ...).
+
+Layout tricks (all zero-cost views into concat buffers):
+  * torch.cat is never materialised by a copy of both halves: producers write channel slices;
+  * ShuffleV2's channel_shuffle(groups=2) is folded into the stores: branch outputs are written
+    with channel stride 2 (even channels = pass-through / branch1, odd = branch2).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import ir
+
+BN_EPS = 1e-3
+ANCHORS = [[4, 5, 8, 10, 13, 16], [23, 29, 43, 55, 73, 105], [146, 217, 231, 300, 335, 433]]
+STRIDES = [8, 16, 32]
+NO = 16
+_BACKBONE = [(1, 16, 64, 3), (3, 64, 128, 7), (5, 128, 256, 3)]
+
+
+def _bn(w, prefix):
+    return {k: w[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
+
+
+def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (384, 640),
+                           dtype: str = "f32", keep_all: bool = False):
+    w = weights
+    H, W = input_hw
+    assert H % 32 == 0 and W % 32 == 0
+    pb = ir.ProgramBuilder(dtype, H, W, keep_all=keep_all)
+
+    def fconv(prefix):
+        return ir.fold_bn(w[f"{prefix}.conv.weight"], None, _bn(w, f"{prefix}.bn"), BN_EPS)
+
+    def conv(x, prefix, k=1, s=1, out=None, name=""):
+        wt, b = fconv(prefix)
+        return pb.conv(x, wt, b, "silu", stride=s, pad=k // 2, out=out, out_name=name or prefix)
+
+    # ---- StemBlock ------------------------------------------------------------------------------
+    wt, b = fconv("model.0.stem_1")
+    s1 = pb.stem(wt, b, "silu", out_name="model.0.stem_1")
+    h2, w2 = H // 4, W // 4
+    cat = pb.buffer(h2 * w2 * 32, ir.ELEM_ACT, "stem.cat")
+    s2a = conv(s1, "model.0.stem_2a")
+    conv(s2a, "model.0.stem_2b", 3, 2, out=pb.view(cat, h2, w2, 16, 0, 32))
+    pb.maxpool(s1, out=pb.view(cat, h2, w2, 16, 16, 32))
+    x = conv(pb.view(cat, h2, w2, 32, 0, 32), "model.0.stem_3", name="model.0")
+
+    # ---- ShuffleV2 backbone -----------------------------------------------------------------------
+    def shuffle_block(x, prefix, inp, oup, stride, name=""):
+        tx = pb.tensors[x]
+        bf = oup // 2
+        oh, ow = tx.H // stride, tx.W // stride
+        out_buf = pb.buffer(oh * ow * oup, ir.ELEM_ACT, name or prefix)
+        even = pb.strided_view(out_buf, oh, ow, bf, 0, oup)
+        odd = pb.strided_view(out_buf, oh, ow, bf, 1, oup)
+        if stride == 1:
+            pb.copy(pb.view(tx.buf, tx.H, tx.W, bf, tx.coff, tx.ld), even, out_cs=2)
+            x2 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff + bf, tx.ld)
+        else:
+            wt, b = ir.fold_bn(w[f"{prefix}.branch1.0.weight"], None, _bn(w, f"{prefix}.branch1.1"), BN_EPS)
+            y = pb.dw(x, wt, b, "none", stride=2, pad=1)
+            wt, b = ir.fold_bn(w[f"{prefix}.branch1.2.weight"], None, _bn(w, f"{prefix}.branch1.3"), BN_EPS)
+            pb.conv(y, wt, b, "silu", out=even, out_cs=2)
+            x2 = x
+        wt, b = ir.fold_bn(w[f"{prefix}.branch2.0.weight"], None, _bn(w, f"{prefix}.branch2.1"), BN_EPS)
+        y = pb.conv(x2, wt, b, "silu")
+        wt, b = ir.fold_bn(w[f"{prefix}.branch2.3.weight"], None, _bn(w, f"{prefix}.branch2.4"), BN_EPS)
+        y = pb.dw(y, wt, b, "none", stride=stride, pad=1)
+        wt, b = ir.fold_bn(w[f"{prefix}.branch2.5.weight"], None, _bn(w, f"{prefix}.branch2.6"), BN_EPS)
+        pb.conv(y, wt, b, "silu", out=odd, out_cs=2)
+        return pb.view(out_buf, oh, ow, oup, 0, oup, name=name)
+
+    feats = {}
+    for li, cin, cout, reps in _BACKBONE:
+        x = shuffle_block(x, f"model.{li}", cin, cout, 2, name=f"model.{li}")
+        for r in range(reps):
+            x = shuffle_block(x, f"model.{li + 1}.{r}", cout, cout, 1, name=f"model.{li + 1}" if r == reps - 1 else "")
+        feats[li + 1] = x
+
+    # ---- PAN head -------------------------------------------------------------------------------------
+    def c3(x, prefix, name):
+        tx = pb.tensors[x]
+        catb = pb.buffer(tx.H * tx.W * 64, ir.ELEM_ACT, prefix + ".cat")
+        y1 = conv(x, f"{prefix}.cv1")
+        y1 = conv(y1, f"{prefix}.m.0.cv1")
+        conv(y1, f"{prefix}.m.0.cv2", 3, 1, out=pb.view(catb, tx.H, tx.W, 32, 0, 64))
+        conv(x, f"{prefix}.cv2", out=pb.view(catb, tx.H, tx.W, 32, 32, 64))
+        return conv(pb.view(catb, tx.H, tx.W, 64, 0, 64), f"{prefix}.cv3", name=name)
+
+    def concat2(a, up, b_, name):
+        ta, tb = pb.tensors[a], pb.tensors[b_]
+        hh, ww = ta.H * up, ta.W * up
+        assert (hh, ww) == (tb.H, tb.W)
+        buf = pb.buffer(hh * ww * (ta.C + tb.C), ir.ELEM_ACT, name)
+        pb.copy(a, pb.view(buf, hh, ww, ta.C, 0, ta.C + tb.C), out_cs=1, up=up)
+        pb.copy(b_, pb.view(buf, hh, ww, tb.C, ta.C, ta.C + tb.C), out_cs=1, up=1)
+        return pb.view(buf, hh, ww, ta.C + tb.C, 0, ta.C + tb.C)
+
+    l7 = conv(feats[6], "model.7")
+    l10 = c3(concat2(l7, 2, feats[4], "cat9"), "model.10", "model.10")
+    l11 = conv(l10, "model.11")
+    l14 = c3(concat2(l11, 2, feats[2], "cat13"), "model.14", "model.14")
+    l15 = conv(l14, "model.15", 3, 2)
+    l17 = c3(concat2(l15, 1, l11, "cat16"), "model.17", "model.17")
+    l18 = conv(l17, "model.18", 3, 2)
+    l20 = c3(concat2(l18, 1, l7, "cat19"), "model.20", "model.20")
+
+    # ---- Detect + decode ----------------------------------------------------------------------------------
+    levels = [l14, l17, l20]
+    nrows = sum(3 * pb.tensors[t].H * pb.tensors[t].W for t in levels)
+    rows = pb.buffer(nrows * NO, ir.ELEM_F32, "rows", pinned=True)
+    row0 = 0
+    for i, t in enumerate(levels):
+        o = pb.conv(t, w[f"model.21.m.{i}.weight"].astype(np.float64), w[f"model.21.m.{i}.bias"].astype(np.float64),
+                    "none", out_name=f"model.21.m.{i}")
+        pb.detdec(o, rows, row0, STRIDES[i], np.asarray(ANCHORS[i], np.float64), nrows)
+        row0 += 3 * pb.tensors[t].H * pb.tensors[t].W
+    blob = pb.finish([rows])
+    info = {"tensors": dict(pb.tensor_names), "rows": nrows, "n_ops": len(pb.ops), "dtype": dtype}
+    return blob, info
+
+
+def detector_param_shapes() -> List[Tuple[str, Tuple[int, ...], str]]:
+    out: List[Tuple[str, Tuple[int, ...], str]] = []
+
+    def cv(p, cin, cout, k):
+        out.extend([(f"{p}.conv.weight", (cout, cin, k, k), "conv"), (f"{p}.bn", (cout,), "bn")])
+
+    def sh(p, inp, oup, stride):
+        bf = oup // 2
+        if stride > 1:
+            out.extend([(f"{p}.branch1.0.weight", (inp, 1, 3, 3), "conv"), (f"{p}.branch1.1", (inp,), "bn"),
+                        (f"{p}.branch1.2.weight", (bf, inp, 1, 1), "conv"), (f"{p}.branch1.3", (bf,), "bn")])
+        c2 = inp if stride > 1 else bf
+        out.extend([(f"{p}.branch2.0.weight", (bf, c2, 1, 1), "conv"), (f"{p}.branch2.1", (bf,), "bn"),
+                    (f"{p}.branch2.3.weight", (bf, 1, 3, 3), "conv"), (f"{p}.branch2.4", (bf,), "bn"),
+                    (f"{p}.branch2.5.weight", (bf, bf, 1, 1), "conv"), (f"{p}.branch2.6", (bf,), "bn")])
+
+    def c3(p, c1):
+        cv(f"{p}.cv1", c1, 32, 1); cv(f"{p}.cv2", c1, 32, 1); cv(f"{p}.cv3", 64, 64, 1)
+        cv(f"{p}.m.0.cv1", 32, 32, 1); cv(f"{p}.m.0.cv2", 32, 32, 3)
+
+    cv("model.0.stem_1", 3, 16, 3); cv("model.0.stem_2a", 16, 8, 1); cv("model.0.stem_2b", 8, 16, 3); cv("model.0.stem_3", 32, 16, 1)
+    for li, cin, cout, reps in _BACKBONE:
+        sh(f"model.{li}", cin, cout, 2)
+        for r in range(reps):
+            sh(f"model.{li + 1}.{r}", cout, cout, 1)
+    cv("model.7", 256, 64, 1); c3("model.10", 192); cv("model.11", 64, 64, 1); c3("model.14", 128)
+    cv("model.15", 64, 64, 3); c3("model.17", 128); cv("model.18", 64, 64, 3); c3("model.20", 128)
+    for i in range(3):
+        out.extend([(f"model.21.m.{i}.weight", (3 * NO, 64, 1, 1), "conv"), (f"model.21.m.{i}.bias", (3 * NO,), "bias")])
+    return out
+
+
+def random_detector_weights(seed: int = 1) -> Dict[str, np.ndarray]:
+    """Random-init weights of the exact architecture (benchmarks only; see graph/random_init.py)."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    last_var = 1.0
+    for name, shape, kind in detector_param_shapes():
+        if kind == "conv":
+            cout, cin_g, kh, kw = shape
+            std = np.sqrt(2.0 / (cout * kh * kw))
+            w[name] = (rng.standard_normal(shape) * std).astype(np.float32)
+            last_var = max(cin_g * kh * kw * std * std * 0.4, 1e-3)
+        elif kind == "bias":
+            w[name] = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        else:
+            w[f"{name}.weight"] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+            w[f"{name}.bias"] = (rng.standard_normal(shape) * 0.3).astype(np.float32)
+            w[f"{name}.running_mean"] = np.zeros(shape, np.float32)
+            w[f"{name}.running_var"] = np.full(shape, last_var, np.float32)
+    return w

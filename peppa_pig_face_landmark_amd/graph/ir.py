@@ -103,6 +103,14 @@ class ProgramBuilder:
     def view(self, base_buf: int, H: int, W: int, C: int, coff: int, ld: int, name: str = "") -> int:
         return self.tensor(H, W, C, base_buf, coff, ld, name)
 
+    def strided_view(self, base_buf: int, H: int, W: int, C: int, coff: int, ld: int) -> int:
+        """Write-only target for channel-interleaved stores (channel n lands at coff + n*cs): no
+        vector-alignment requirement because those stores are scalar."""
+        t = _Tensor()
+        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name = base_buf, coff, ld, H, W, C, ""
+        self.tensors.append(t)
+        return len(self.tensors) - 1
+
     def const(self, arr: np.ndarray) -> int:
         while len(self.consts) % 256:
             self.consts.append(0)

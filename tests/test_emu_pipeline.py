@@ -1,0 +1,119 @@
+"""Pre/post-processing kernels and the fused pipeline on the CPU SIMT emulator vs the numpy oracle
+(bit-exact for the integer / byte work: letterbox pixels, crop boxes, crop pixels, NMS keep lists)."""
+import numpy as np
+import pytest
+
+from oracle import prepost as pp
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from tests import helpers
+from tests.synth_frames import make_frame, plant_rows
+
+
+@pytest.mark.parametrize("hw,out_hw", [((270, 480), (96, 160)), ((300, 200), (96, 160)), ((192, 320), (96, 160)),
+                                       ((101, 333), (64, 96))])
+def test_letterbox_bit_exact(emu_engine, hw, out_hw):
+    frame, _ = make_frame(hw[0], hw[1], 2, seed=3)
+    got, info = emu_engine.letterbox(frame, out_hw)
+    ref, rinfo = pp.detector_preprocess_u8(frame, out_hw)
+    assert np.array_equal(got, ref)
+    assert info[0] == np.float32(rinfo[0]) and info[1] == rinfo[1] and info[2] == rinfo[2]
+
+
+def test_nms_rows_matches_py_nms(emu_engine):
+    rng = np.random.default_rng(0)
+    for trial in range(3):
+        n = 600
+        rows = np.zeros((n, 16), np.float32)
+        rows[:, 0] = rng.uniform(50, 590, n)
+        rows[:, 1] = rng.uniform(50, 330, n)
+        rows[:, 2:4] = rng.uniform(10, 120, (n, 2))
+        rows[:, 4] = rng.permutation(np.linspace(0.01, 0.99, n)).astype(np.float32)
+        rows[:, 5:] = rng.uniform(0, 1, (n, 11))
+        if trial == 2:
+            rows[5, 2:4] = 0.0   # zero-area box: IoU is 0/0 = NaN against itself -> must be handled like numpy
+        info = [np.float32(1.0 / 3.0), 0, 12]
+        ref = pp.detector_postprocess(rows, info, 0.3, 0.5)
+        got = emu_engine.nms_rows(rows, info[0], info[1], info[2], 0.5, 0.3)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref)
+
+
+def test_crop_faces_bit_exact(emu_engine):
+    frame, boxes = make_frame(270, 480, 4, seed=5)
+    extra = np.array([[-30.0, -20.0, 60.0, 70.0],       # sticks out of the frame (zero padding visible)
+                      [400.0, 200.0, 479.5, 269.0],     # bottom-right corner
+                      [100.0, 100.0, 115.0, 140.0],     # too narrow: rejected (w <= 20)
+                      [200.0, 50.0, 296.0, 140.0]], np.float32)  # 2*floor(0.7*96)=134 -> generic resize
+    allb = np.concatenate([boxes, extra], 0)
+    S = 64
+    crops, params = emu_engine.crop_faces(frame, allb, S)
+    for i, b in enumerate(allb):
+        ci = pp.landmark_crop_box(b, frame.shape[0], frame.shape[1])
+        assert bool(params[i, 0]) == ci.valid, i
+        if not ci.valid:
+            continue
+        assert (params[i, 1], params[i, 2], params[i, 3], params[i, 6], params[i, 7]) == \
+               (ci.add, ci.x0, ci.y0, ci.w_crop, ci.h_crop), i
+        ref = pp.landmark_crop(frame, ci, (S, S))
+        assert np.array_equal(crops[i], ref), i
+
+
+def test_crop_exact_2x_uses_box_average(emu_engine):
+    frame, _ = make_frame(270, 480, 1, seed=9)
+    w = 92.0   # 2*floor(0.7*92) = 128 = 2*64
+    box = np.array([[150.0, 80.0, 150.0 + w, 180.0]], np.float32)
+    crops, params = emu_engine.crop_faces(frame, box, 64)
+    ci = pp.landmark_crop_box(box[0], 270, 480)
+    assert ci.w_crop == 128 and ci.h_crop == 128
+    assert np.array_equal(crops[0], pp.landmark_crop(frame, ci, (64, 64)))
+
+
+def test_landmarks_stage_matches_reference_chain(emu_engine, student_weights):
+    """pf_landmarks == FaceLandmark.__call__: crop -> /255 -> net -> back-projection."""
+    S = 64
+    frame, boxes = make_frame(270, 480, 3, seed=11)
+    blob, _ = build_student_program(student_weights, S, "f32")
+    emu_engine.load_program(0, blob, 4)
+    bad = np.array([[10.0, 10.0, 25.0, 60.0]], np.float32)
+    kps, scores, valid = emu_engine.landmarks(frame, np.concatenate([boxes, bad], 0))
+    assert valid.tolist() == [True, True, True, False]
+    for i, b in enumerate(boxes):
+        ci = pp.landmark_crop_box(b, 270, 480)
+        crop = pp.landmark_crop(frame, ci, (S, S))
+        oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
+        ref = pp.landmark_backproject(oloc[0], ci)
+        safe = helpers.heat_margins(taps)[0] > 1e-3
+        assert np.abs(kps[i] - ref)[safe].max() < 1e-3 * max(ci.w_crop, ci.h_crop)  # north-star 1e-3 (normalised)
+        assert np.abs(scores[i] - oscore[0])[safe].max() < 2e-3
+
+
+def test_run_frames_planted_end_to_end(emu_engine, student_weights):
+    """FaceAna.run()+reset() semantics on planted detections: NMS must keep exactly the planted
+    boxes, top-k by area, then landmarks for each."""
+    S, F, top_k = 64, 2, 3
+    blob, _ = build_student_program(student_weights, S, "f32")
+    emu_engine.load_program(0, blob, F * top_k)
+    frames, rows_all, refs = [], [], []
+    for f in range(F):
+        frame, boxes = make_frame(270, 480, 4, seed=20 + f, face_w=300 + 40 * f, face_h=400)
+        boxes[:, 2] += np.arange(4) * 6     # distinct areas so top-k is unambiguous
+        rows = plant_rows(boxes, (270, 480), n_rows=1260, input_hw=(384, 640), per_box=6, seed=f)
+        frames.append(frame)
+        rows_all.append(rows)
+        _, info = pp.detector_preprocess_u8(frame, (384, 640))
+        kept = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+        assert kept.shape[0] == 4
+        refs.append(pp.sort_and_filter(kept, 100.0, top_k))
+    counts, boxes_out, kps, scores = emu_engine.run_frames(np.stack(frames), 0.5, 0.3, 100.0, top_k,
+                                                            planted_rows=np.stack(rows_all))
+    assert counts.tolist() == [top_k, top_k]
+    for f in range(F):
+        assert np.array_equal(boxes_out[f], refs[f][:, :4])
+        for k in range(top_k):
+            ci = pp.landmark_crop_box(refs[f][k], 270, 480)
+            crop = pp.landmark_crop(frames[f], ci, (S, S))
+            oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
+            ref = pp.landmark_backproject(oloc[0], ci)
+            safe = helpers.heat_margins(taps)[0] > 1e-3
+            assert np.abs(kps[f, k] - ref)[safe].max() < 1e-3 * max(ci.w_crop, ci.h_crop)  # north-star 1e-3 (normalised)
