@@ -229,7 +229,7 @@ class CropInfo:
 
 
 def landmark_crop_box(bbox_xyxy: Sequence[float], frame_h: int, frame_w: int,
-                      min_face: float = 20.0, extend: float = 0.2) -> CropInfo:
+                      min_face: float = 20.0, extend: float = 0.2, numpy1_promotion: bool = True) -> CropInfo:
     """Box arithmetic of face_landmark.py:74-94 under numpy-1.23 promotion rules:
     ``bbox`` is a float32 row; width/height are float32; ``(1+2*extend)*width`` and every
     ``// 2`` promote to float64; results are stored back into the float32 row and truncated
@@ -244,10 +244,18 @@ def landmark_crop_box(bbox_xyxy: Sequence[float], frame_h: int, frame_w: int,
         return ci
     add = int(max(w, h))
     b = (b + np.float32(add)).astype(np.float32)
-    face_width = (1 + 2 * extend) * float(w)               # float64
-    cx = float(np.float32(b[0] + b[2])) // 2                # float64 floor-div
-    cy = float(np.float32(b[1] + b[3])) // 2
-    half = face_width // 2
+    if numpy1_promotion:
+        face_width = (1 + 2 * extend) * float(w)               # float64
+        cx = float(np.float32(b[0] + b[2])) // 2                # float64 floor-div
+        cy = float(np.float32(b[1] + b[3])) // 2
+        half = face_width // 2
+    else:
+        # numpy >= 2 (NEP 50): python scalars are weak, everything stays float32.  Only used to pin
+        # this restatement against the reference source executed under the numpy installed here.
+        face_width = np.float32(1 + 2 * extend) * w
+        cx = float(np.float32(b[0] + b[2]) // np.float32(2))
+        cy = float(np.float32(b[1] + b[3]) // np.float32(2))
+        half = float(face_width // np.float32(2))
     box = np.array([cx - half, cy - half, cx + half, cy + half], np.float64).astype(np.float32)
     x0, y0, x1, y1 = (int(v) for v in box.astype(np.int32))
     ph, pw = frame_h + 2 * add, frame_w + 2 * add

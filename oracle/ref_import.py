@@ -120,3 +120,60 @@ def load_reference_cotrain(weights_np: Dict[str, np.ndarray]):
     own_names = {k for k in own if not k.startswith("encoder.")}
     assert ref_names == own_names, (sorted(ref_names ^ own_names))
     return model
+
+
+# --------------------------------------------------------------------------------------
+# the reference's own numpy pre/post-processing (face_detector.py / face_landmark.py)
+# --------------------------------------------------------------------------------------
+def _install_cv2_stub():
+    """``cv2`` and ``onnxruntime`` are not installed; the reference modules import both at module
+    scope.  cv2 is stubbed with the oracle's OpenCV restatement (so what gets pinned is the
+    reference's box arithmetic / slicing / NMS / call structure, not OpenCV itself)."""
+    from . import prepost as pp
+
+    if "cv2" not in sys.modules:
+        cv2 = types.ModuleType("cv2")
+        cv2.COLOR_BGR2RGB = 4
+        cv2.BORDER_CONSTANT = 0
+        cv2.cvtColor = lambda img, code: np.ascontiguousarray(img[:, :, ::-1])
+        cv2.resize = lambda img, dsize: pp.resize_linear_u8(np.ascontiguousarray(img), int(dsize[0]), int(dsize[1]))
+
+        def copyMakeBorder(img, top, bottom, left, right, borderType=0, value=0):
+            v = value if np.isscalar(value) else np.asarray(value)[:img.shape[2]]
+            return pp.pad_constant(img, top, bottom, left, right, v)
+
+        cv2.copyMakeBorder = copyMakeBorder
+        sys.modules["cv2"] = cv2
+    if "onnxruntime" not in sys.modules:
+        sys.modules["onnxruntime"] = types.ModuleType("onnxruntime")
+
+
+def load_reference_stages():
+    """Returns (FaceDetector, FaceLandmark) -- the reference's classes, importable because cv2 /
+    onnxruntime are stubbed.  Instances must be made with ``__new__`` (the constructors open .onnx files)."""
+    assert available()
+    sys.dont_write_bytecode = True
+    _install_cv2_stub()
+    skps = os.path.join(REFERENCE_ROOT, "Skps")
+    if skps not in sys.path:
+        sys.path.append(skps)  # the reference does the same at Skps/__init__.py:3-5
+    import logging
+    level = logging.getLogger().level
+    from core.api.face_detector import FaceDetector
+    from core.api.face_landmark import FaceLandmark
+    logging.getLogger().setLevel(level)  # logger/logger.py:25 sets the root logger to DEBUG
+    return FaceDetector, FaceLandmark
+
+
+def reference_detector_stage(input_shape=(384, 640, 3), score_thrs=0.5, iou_thrs=0.3):
+    FaceDetector, _ = load_reference_stages()
+    d = FaceDetector.__new__(FaceDetector)
+    d.input_size, d.score_thrs, d.iou_thrs = list(input_shape), score_thrs, iou_thrs
+    return d
+
+
+def reference_landmark_stage(input_shape=(256, 256, 3)):
+    _, FaceLandmark = load_reference_stages()
+    l = FaceLandmark.__new__(FaceLandmark)
+    l.min_face, l.keypoints_num, l.input_size, l.extend = 20, 98, list(input_shape), [0.2, 0.3]
+    return l

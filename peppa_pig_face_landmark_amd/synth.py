@@ -1,4 +1,4 @@
-"""Synthetic frames + planted detector rows shared by tests and bench."""
+"""Synthetic 1080p-style frames + planted detector rows for tests and bench."""
 import numpy as np
 
 

@@ -1,0 +1,101 @@
+"""Generate the committed golden vectors by running the REFERENCE's own code (build container only:
+needs /root/reference).  Usage:  python tests/golden/make_golden.py
+
+What each vector pins:
+  landmark_student128.npz  COTRAIN(inference='student') from the reference's model.py (decoder, heads,
+                           postp executed from reference source; encoder = oracle restatement of timm)
+                           on the oracle's synthetic weights: inputs, loc_fix, score, arg-max margins.
+  detector_post.npz        the reference's own FaceDetector.xywh2xyxy / py_nms / scale_coords and
+                           preprocess geometry on seeded rows / frame sizes.
+  landmark_pre.npz         the reference's own FaceLandmark.preprocess 'detail' output (executed under
+                           the installed numpy 2.x) on seeded boxes + the numpy-1.23-promotion variant of
+                           the restatement for the same boxes (what the engine must reproduce).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import landmark_net as ln  # noqa: E402
+from oracle import prepost as pp  # noqa: E402
+from oracle import ref_import as ri  # noqa: E402
+from oracle import synth_weights as sw  # noqa: E402
+from peppa_pig_face_landmark_amd.synth import make_frame  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    assert ri.available(), "needs /root/reference"
+    w = sw.student_weights(cache=False)
+    # ---- landmark net ---------------------------------------------------------------------------
+    model = ri.load_reference_cotrain(w)
+    crops = sw.smooth_blob_images(2, 128, seed=2024)
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        ref_loc, ref_score = model(x)
+        taps = {}
+        oloc, oscore = ln.student_forward(ln.to_torch(w), x, taps)
+    assert torch.equal(ref_loc, oloc) and torch.equal(ref_score, oscore), "oracle != reference"
+    hm = taps["hm"].numpy()
+    flat = np.sort(hm[:, :98].reshape(2, 98, -1), axis=2)
+    np.savez_compressed(os.path.join(OUT, "landmark_student128.npz"), crops=crops, loc_fix=ref_loc.numpy(),
+                        score=ref_score.numpy(), margin=flat[:, :, -1] - flat[:, :, -2],
+                        hm_absmax=np.abs(hm).max(), hm_mean=hm.mean(), weight_checksum=np.float64(
+                            sum(float(np.abs(v).sum()) for v in w.values())))
+    # ---- detector post-processing -----------------------------------------------------------------
+    det = ri.reference_detector_stage()
+    rng = np.random.default_rng(11)
+    n = 500
+    rows = np.zeros((n, 16), np.float32)
+    rows[:, 0] = rng.uniform(50, 590, n)
+    rows[:, 1] = rng.uniform(50, 330, n)
+    rows[:, 2:4] = rng.uniform(10, 120, (n, 2))
+    rows[:, 4] = rng.permutation(np.linspace(0.01, 0.99, n)).astype(np.float32)
+    rows[:, 5:] = rng.uniform(0, 1, (n, 11))
+    r = rows.copy()
+    r[:, :4] = det.xywh2xyxy(r[:, :4])
+    kept = det.py_nms(r, 0.3, 0.5)
+    kept[:, :4] = det.scale_coords(kept[:, :4], [1.0 / 3.0, 0, 12])
+    geoms = []
+    for (h, w_) in ((1080, 1920), (2160, 3840), (720, 1280), (480, 640), (273, 410), (1000, 1000), (333, 777)):
+        frame = np.zeros((h, w_, 3), np.uint8)
+        xin, info = det.preprocess(frame)
+        assert xin.shape == (1, 3, 384, 640)
+        geoms.append([h, w_, info[0], info[1], info[2]])
+    np.savez_compressed(os.path.join(OUT, "detector_post.npz"), rows=rows, kept=kept, geoms=np.asarray(geoms, np.float64))
+    # ---- landmark pre-processing --------------------------------------------------------------------
+    lm = ri.reference_landmark_stage()
+    frame, _ = make_frame(270, 480, 2, seed=1)
+    boxes, details, details_np1 = [], [], []
+    diff = 0
+    while len(boxes) < 400:
+        x1, y1 = rng.uniform(0, 380), rng.uniform(0, 180)
+        bw, bh = rng.uniform(15, 220), rng.uniform(15, 220)
+        b = np.array([x1, y1, x1 + bw, y1 + bh], np.float32)
+        ci2 = pp.landmark_crop_box(b, 270, 480, numpy1_promotion=False)
+        if ci2.valid and (ci2.x0 < 0 or ci2.y0 < 0):
+            continue
+        crop, detail = lm.preprocess(frame, b.copy(), 0)
+        ci1 = pp.landmark_crop_box(b, 270, 480, numpy1_promotion=True)
+        if crop is None:
+            details.append([0, 0, 0, 0, 0, 0])
+        else:
+            assert (detail[0], detail[1], int(detail[2]), int(detail[3]), detail[4]) == (ci2.h_crop, ci2.w_crop, ci2.y0, ci2.x0, ci2.add)
+            assert np.array_equal(crop, pp.landmark_crop(frame, ci2, (256, 256)))
+            details.append([1, detail[0], detail[1], int(detail[2]), int(detail[3]), detail[4]])
+        details_np1.append([int(ci1.valid), ci1.h_crop, ci1.w_crop, ci1.y0, ci1.x0, ci1.add])
+        diff += details[-1] != details_np1[-1]
+        boxes.append(b)
+    np.savez_compressed(os.path.join(OUT, "landmark_pre.npz"), boxes=np.asarray(boxes), frame_hw=np.array([270, 480]),
+                        detail_reference_numpy2=np.asarray(details, np.int64), detail_numpy1=np.asarray(details_np1, np.int64))
+    print("golden written; numpy-1.23 vs numpy-2 promotion differs on %d of %d boxes" % (diff, len(boxes)))
+
+
+if __name__ == "__main__":
+    main()

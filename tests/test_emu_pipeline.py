@@ -7,7 +7,7 @@ from oracle import prepost as pp
 from oracle import synth_weights as sw
 from peppa_pig_face_landmark_amd.graph.student import build_student_program
 from tests import helpers
-from tests.synth_frames import make_frame, plant_rows
+from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
 
 
 @pytest.mark.parametrize("hw,out_hw", [((270, 480), (96, 160)), ((300, 200), (96, 160)), ((192, 320), (96, 160)),

@@ -1,0 +1,94 @@
+"""The oracle is pinned against (a) golden vectors produced by the reference's own code
+(tests/golden/make_golden.py) and, where /root/reference exists, (b) the reference executed live."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import landmark_net as ln
+from oracle import prepost as pp
+from oracle import ref_import as ri
+from oracle import synth_weights as sw
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_cost_model_reproduces_reference_readme():
+    """README.md:34-37 quotes thop MACs/1024^3 and params/1024^2 (model.py:594-601)."""
+    macs256, params = ln.count_macs_params(256)
+    macs128, _ = ln.count_macs_params(128)
+    assert abs(macs256 / 1024 ** 3 - 1.39) < 0.015      # Student@256 "Flops(G)" 1.39
+    assert abs(macs128 / 1024 ** 3 - 0.35) < 0.005      # Student@128 0.35
+    assert abs(params / 1024 ** 2 - 3.25) < 0.03        # Params(M) 3.25
+
+
+def test_landmark_oracle_reproduces_reference_golden(student_weights):
+    g = np.load(os.path.join(GOLD, "landmark_student128.npz"))
+    chk = sum(float(np.abs(v).sum()) for v in student_weights.values())
+    assert abs(chk - float(g["weight_checksum"])) < 1e-6 * chk, "synthetic weights are not reproducible"
+    x = torch.from_numpy(g["crops"].astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        loc, score = ln.student_forward(ln.to_torch(student_weights), x)
+    safe = g["margin"] > 1e-4
+    d = np.abs(loc.numpy() - g["loc_fix"]).reshape(2, 98, 2).max(2)
+    assert d[safe].max() < 1e-5
+    assert np.abs(score.numpy() - g["score"]).max() < 1e-4
+
+
+def test_detector_postprocess_reproduces_reference_golden():
+    g = np.load(os.path.join(GOLD, "detector_post.npz"))
+    mine = pp.detector_postprocess(g["rows"], [1.0 / 3.0, 0, 12], 0.3, 0.5)
+    assert np.array_equal(mine, g["kept"])
+    for h, w, scale, left, top in g["geoms"]:
+        s, rw, rh, t, b, l, r = pp.letterbox_geometry(int(h), int(w))
+        assert (s, l, t) == (scale, left, top)
+
+
+def test_landmark_crop_boxes_reproduce_reference_golden():
+    g = np.load(os.path.join(GOLD, "landmark_pre.npz"))
+    h, w = (int(v) for v in g["frame_hw"])
+    for b, ref2, ref1 in zip(g["boxes"], g["detail_reference_numpy2"], g["detail_numpy1"]):
+        for variant, ref in ((False, ref2), (True, ref1)):
+            ci = pp.landmark_crop_box(b, h, w, numpy1_promotion=variant)
+            got = [int(ci.valid), ci.h_crop, ci.w_crop, ci.y0, ci.x0, ci.add] if ci.valid else [0] * 6
+            assert got == list(ref)
+
+
+def test_resize_matches_float_bilinear_within_one_lsb():
+    """Sanity of the OpenCV fixed-point restatement: equals exact half-pixel bilinear to +-1."""
+    rng = np.random.default_rng(0)
+    src = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for dw, dh in ((64, 64), (20, 11), (53, 37), (106, 74)):
+        got = pp.resize_linear_u8(src, dw, dh).astype(np.float64)
+        fx = np.clip((np.arange(dw) + 0.5) * 53 / dw - 0.5, 0, 52)
+        fy = np.clip((np.arange(dh) + 0.5) * 37 / dh - 0.5, 0, 36)
+        x0, y0 = np.floor(fx).astype(int), np.floor(fy).astype(int)
+        x1, y1 = np.minimum(x0 + 1, 52), np.minimum(y0 + 1, 36)
+        ax, ay = (fx - x0)[None, :, None], (fy - y0)[:, None, None]
+        s = src.astype(np.float64)
+        ref = (1 - ay) * ((1 - ax) * s[y0][:, x0] + ax * s[y0][:, x1]) + ay * ((1 - ax) * s[y1][:, x0] + ax * s[y1][:, x1])
+        assert np.abs(got - ref).max() <= 1.0 + 1e-9
+
+
+@pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
+def test_oracle_equals_reference_live(student_weights):
+    model = ri.load_reference_cotrain(student_weights)
+    crops = sw.smooth_blob_images(2, 256, seed=31337)
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        rloc, rscore = model(x)
+        oloc, oscore = ln.student_forward(ln.to_torch(student_weights), x)
+    assert torch.equal(rloc, oloc) and torch.equal(rscore, oscore)
+    det = ri.reference_detector_stage()
+    rng = np.random.default_rng(5)
+    rows = np.zeros((300, 16), np.float32)
+    rows[:, 0] = rng.uniform(50, 590, 300)
+    rows[:, 1] = rng.uniform(50, 330, 300)
+    rows[:, 2:4] = rng.uniform(10, 120, (300, 2))
+    rows[:, 4] = rng.permutation(np.linspace(0.01, 0.99, 300)).astype(np.float32)
+    r = rows.copy()
+    r[:, :4] = det.xywh2xyxy(r[:, :4])
+    kept = det.py_nms(r, 0.3, 0.5)
+    kept[:, :4] = det.scale_coords(kept[:, :4], [0.5, 3, 7])
+    assert np.array_equal(kept, pp.detector_postprocess(rows, [0.5, 3, 7], 0.3, 0.5))
