@@ -1,0 +1,146 @@
+"""Full-size parity of the detector, the pre/post kernels and the fused pipeline on a real MI355X
+(through the C ABI) against the oracle.  Byte / index work is bit-exact; float work within the
+north-star tolerance (1e-3 of the crop size for landmarks)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import detector_net as dn
+from oracle import prepost as pp
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd.graph.detector import build_detector_program
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frame1080():
+    return make_frame(1080, 1920, 8, seed=7)
+
+
+def test_detector_384x640_matches_oracle(gpu_engine, detector_weights):
+    blob, info = build_detector_program(detector_weights, (384, 640), "f32", keep_all=True)
+    assert info["rows"] == 15120                       # face_detector.py:31
+    gpu_engine.load_program(1, blob, 2)
+    img = sw.smooth_blob_images(2, 640, seed=9)[:, :384]
+    rows = gpu_engine.detector_forward(img, 15120)
+    W = {k: torch.from_numpy(v) for k, v in detector_weights.items()}
+    x = torch.from_numpy(img.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    taps = {}
+    with torch.no_grad():
+        ref = dn.detector_forward(W, x, taps).numpy()
+    for name, tid in info["tensors"].items():
+        if name in taps:
+            r = taps[name].permute(0, 2, 3, 1).numpy()
+            g = gpu_engine.read_tensor(1, tid, 2, r.shape[1:])
+            assert np.abs(g - r).max() / (np.abs(r).max() + 1e-9) < 2e-4, name
+    assert np.abs(rows - ref).max() / np.abs(ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("hw", [(1080, 1920), (2160, 3840), (720, 1280), (273, 410), (768, 1280)])
+def test_letterbox_bit_exact(gpu_engine, hw):
+    frame, _ = make_frame(hw[0], hw[1], 4, seed=13)
+    got, info = gpu_engine.letterbox(frame, (384, 640))
+    ref, rinfo = pp.detector_preprocess_u8(frame, (384, 640))
+    assert np.array_equal(got, ref)
+    assert (info[0], info[1], info[2]) == (np.float32(rinfo[0]), rinfo[1], rinfo[2])
+
+
+def test_nms_15120_rows_bit_exact(gpu_engine, frame1080):
+    frame, boxes = frame1080
+    rows = plant_rows(boxes, (1080, 1920), 15120, (384, 640), 24, seed=7)
+    _, info = pp.detector_preprocess_u8(frame, (384, 640))
+    info = [np.float32(info[0]), info[1], info[2]]
+    ref = pp.detector_postprocess(rows, info, 0.3, 0.5)
+    assert ref.shape[0] == 8                           # exactly the planted faces survive
+    got = gpu_engine.nms_rows(rows, info[0], info[1], info[2], 0.5, 0.3)
+    assert np.array_equal(got, ref)
+    # dense case: thousands of overlapping candidates above threshold
+    rng = np.random.default_rng(1)
+    dense = rows.copy()
+    dense[:, 4] = rng.permutation(np.linspace(0.2, 0.999, 15120)).astype(np.float32)
+    ref = pp.detector_postprocess(dense, info, 0.3, 0.5)
+    got = gpu_engine.nms_rows(dense, info[0], info[1], info[2], 0.5, 0.3, max_n=1024)
+    assert np.array_equal(got, ref[:1024])
+
+
+def test_crops_256_bit_exact(gpu_engine, frame1080):
+    frame, boxes = frame1080
+    extra = np.array([[-40.0, -30.0, 160.0, 220.0], [1700.0, 900.0, 1919.0, 1079.0], [300.0, 300.0, 318.0, 380.0],
+                      [600.0, 200.0, 600.0 + 366.0, 640.0]], np.float32)   # last: 2*floor(0.7*366)=512 -> exact 2x path
+    allb = np.concatenate([boxes, extra], 0)
+    crops, params = gpu_engine.crop_faces(frame, allb, 256)
+    for i, b in enumerate(allb):
+        ci = pp.landmark_crop_box(b, 1080, 1920)
+        assert bool(params[i, 0]) == ci.valid
+        if ci.valid:
+            assert (params[i, 1], params[i, 2], params[i, 3], params[i, 6], params[i, 7]) == \
+                   (ci.add, ci.x0, ci.y0, ci.w_crop, ci.h_crop)
+            assert np.array_equal(crops[i], pp.landmark_crop(frame, ci, (256, 256))), i
+
+
+def test_run_frames_1080p_x8_planted(gpu_engine, student_weights, detector_weights, frame1080):
+    """BASELINE configs[2] shape: 1080p frames x 8 faces, detector net running, planted detections."""
+    F, K = 2, 8
+    blob, _ = build_student_program(student_weights, 256, "f32")
+    gpu_engine.load_program(0, blob, F * K)
+    blob, _ = build_detector_program(detector_weights, (384, 640), "f32")
+    gpu_engine.load_program(1, blob, F)
+    frames, rows_all = [], []
+    for f in range(F):
+        frame, boxes = make_frame(1080, 1920, K, seed=7 + f)
+        frames.append(frame)
+        rows_all.append(plant_rows(boxes, (1080, 1920), 15120, (384, 640), 24, seed=7 + f))
+    counts, bout, kps, scores = gpu_engine.run_frames(np.stack(frames), 0.5, 0.3, 1600.0, K,
+                                                      planted_rows=np.stack(rows_all))
+    assert counts.tolist() == [K] * F
+    worst = 0.0
+    for f in range(F):
+        _, info = pp.detector_preprocess_u8(frames[f], (384, 640))
+        kept = pp.detector_postprocess(rows_all[f], [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+        ref_boxes = pp.sort_and_filter(kept, 1600.0, K)
+        assert np.array_equal(bout[f], ref_boxes[:, :4])
+        for k in range(K):
+            ci = pp.landmark_crop_box(ref_boxes[k], 1080, 1920)
+            crop = pp.landmark_crop(frames[f], ci, (256, 256))
+            oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
+            ref = pp.landmark_backproject(oloc[0], ci)
+            safe = helpers.heat_margins(taps)[0] > 2e-3
+            worst = max(worst, float(np.abs(kps[f, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)))
+    print("pipeline: worst normalised landmark error %.2e" % worst)
+    assert worst < 1e-3
+
+
+def test_detect_chain_is_self_consistent(gpu_engine, detector_weights, frame1080):
+    """pf_detect (letterbox -> net -> decode -> NMS -> scale_coords) equals the numpy post-processing
+    applied to the rows the network itself produced for the engine's own letterboxed image."""
+    frame, _ = frame1080
+    blob, _ = build_detector_program(detector_weights, (384, 640), "f32")
+    gpu_engine.load_program(1, blob, 1)
+    got = gpu_engine.detect(frame, 0.5, 0.3, max_n=1024)
+    lb, info = gpu_engine.letterbox(frame, (384, 640))
+    rows = gpu_engine.detector_forward(lb[None], 15120)[0]
+    ref = pp.detector_postprocess(rows, [info[0], info[1], info[2]], 0.3, 0.5)
+    assert np.array_equal(got, ref[:1024])
+
+
+def test_faceana_facade(hip_library, student_weights, detector_weights, frame1080):
+    """Skps.FaceAna()/run()/reset() surface (facer.py:25-208) on the HIP engine."""
+    from Skps import FaceAna
+    from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+    cfg = get_cfg()
+    cfg["Skps"]["Detect"]["topk"] = 8
+    facer = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=hip_library)
+    frame, _ = frame1080
+    res = facer.run(frame)
+    assert isinstance(res, list)
+    for r in res:
+        assert r["box"].shape == (4,) and r["kps"].shape == (98, 2) and r["scores"].shape == (98,)
+    res2 = facer.run(frame)           # static frame: detector skipped, tracked boxes reused
+    assert len(res2) == len(res)
+    facer.reset()
+    assert facer.track_box is None and facer.previous_image is None
+    facer.engine.close()
