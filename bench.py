@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=48)
+    ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
     return ap.parse_args()
 
 
@@ -149,6 +150,11 @@ def main():
                     "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
                     "avg_launch_ms": round(avg_ms, 4), "launches": hero_n}
 
+    if args.dump_profile and rank == 0:
+        with open(args.dump_profile, "w") as f:
+            json.dump({"steps": 3, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
+                       "kernels": {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
+                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}, f, indent=1)
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
