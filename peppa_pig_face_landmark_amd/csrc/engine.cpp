@@ -176,9 +176,18 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.inH = ti.H; a.inW = ti.W; a.C = ti.C; a.inLd = ti.ld;
                 a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
                 a.K = f[4]; a.stride = f[5]; a.pad = f[6]; a.dil = f[7]; a.act = f[8];
-                const long long total = (long long)B * to.H * to.W * (ti.C / VE);
                 ProfScope ps(h, "dw_conv");
-                PF_LAUNCH((dw_conv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                constexpr int TX = 4;
+                const long long tiled = (long long)B * to.H * ((to.W + TX - 1) / TX) * (ti.C / VE);
+                const dim3 tg((unsigned)((tiled + 255) / 256));
+                if (a.K == 3 && a.stride == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 1, TX>), tg, dim3(256), h->stream, a);
+                else if (a.K == 3 && a.stride == 2) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 2, TX>), tg, dim3(256), h->stream, a);
+                else if (a.K == 5 && a.stride == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 1, TX>), tg, dim3(256), h->stream, a);
+                else if (a.K == 5 && a.stride == 2) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 2, TX>), tg, dim3(256), h->stream, a);
+                else {
+                    const long long total = (long long)B * to.H * to.W * (ti.C / VE);
+                    PF_LAUNCH((dw_conv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
+                }
                 break;
             }
             case PF_OP_UPCAT: {
@@ -201,6 +210,20 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.HW = ti.H * ti.W; a.C = ti.C; a.ld = ti.ld;
                 ProfScope ps(h, "gap");
                 PF_LAUNCH((gap_kernel<T>), dim3(pf_div_up(ti.C / VE, 8), B), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_POOLMLP: {
+                const PfTensorRec& ti = p.tens[f[0]];
+                PoolMlpArgs a{};
+                a.in = p.tensor_ptr(f[0]); a.out = (float*)p.buf_ptr(f[1]);
+                a.w1 = (const float*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]); a.R = f[4]; a.act1 = f[5];
+                a.s2 = (const float*)p.cptr(f[6]); a.t2 = (const float*)p.cptr(f[7]); a.act2 = f[8];
+                a.w2t = (const float*)p.cptr(f[9]); a.b2 = (const float*)p.cptr(f[10]); a.N = f[11]; a.act3 = f[12];
+                a.B = B; a.HW = ti.H * ti.W; a.C = ti.C; a.ld = ti.ld;
+                if (a.C > PF_POOLMLP_MAXC || a.R > PF_POOLMLP_MAXR || a.C / VE > 256 || a.C / VE < 1)
+                    PF_FAIL(h, "pool_mlp: C=%d R=%d outside kernel limits", a.C, a.R);
+                ProfScope ps(h, "pool_mlp");
+                PF_LAUNCH((pool_mlp_kernel<T>), dim3(B), dim3(256), h->stream, a);
                 break;
             }
             case PF_OP_FC: {

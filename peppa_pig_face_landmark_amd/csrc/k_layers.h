@@ -448,3 +448,158 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DetDecArgs a) {
 #pragma unroll
     for (int o = 0; o < 16; o += 4) *reinterpret_cast<pf_f32x4*>(out + o) = pf_f32x4{r[o], r[o + 1], r[o + 2], r[o + 3]};
 }
+
+// --------------------------------------------------------------------------------------------
+// Fused squeeze-excite style gate: global average pool -> FC -> act [-> affine -> act] -> FC -> act,
+// one workgroup per batch item, pooled / hidden vectors never leave LDS.  Covers timm SqueezeExcite
+// (mean -> conv_reduce -> ReLU -> conv_expand -> hard_sigmoid), SCSEModule.cSE (model.py:119-125) and the
+// ASPP pooling branch folded into a per-face bias of the project conv (model.py:46-61,92-96).
+struct PoolMlpArgs {
+    const void* in;       // T [B][HW][ld], channels [0, C)
+    float* out;           // [B][N]
+    const float* w1;      // [R][C]
+    const float* b1;      // [R] or nullptr
+    const float* s2;      // optional affine on the hidden vector: h = act2(s2*h + t2)
+    const float* t2;
+    const float* w2t;     // [R][N]  (transposed: consecutive threads read consecutive n)
+    const float* b2;      // [N] or nullptr
+    int B, HW, C, ld, R, N, act1, act2, act3;
+};
+
+#define PF_POOLMLP_MAXC 1024
+#define PF_POOLMLP_MAXR 256
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_mlp_kernel(PoolMlpArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    __shared__ float s_pool[PF_POOLMLP_MAXC + PF_POOLMLP_MAXR + 256 * VE];
+    float* s_hid = s_pool + PF_POOLMLP_MAXC;
+    float* s_part = s_hid + PF_POOLMLP_MAXR;   // [256 threads][VE] per-thread partial sums
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x;
+    // phase 1: channel means.  thread -> (channel vector cv, pixel row prow); fixed-order reduction
+    // (no atomics) so results are bit-reproducible.  Host guarantees C/VE <= 256.
+    const int CV = a.C / VE;
+    const int nrows = 256 / CV;
+    const int cv = t % CV, prow = t / CV;
+    const T* in = static_cast<const T*>(a.in) + (size_t)b * a.HW * a.ld;
+    {
+        float acc[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+        if (prow < nrows) {
+            for (int p = prow; p < a.HW; p += nrows) {
+                const vec_t x = pf_ldv<T>(in + (size_t)p * a.ld + cv * VE);
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] += (float)x[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s_part[t * VE + e] = acc[e];
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)a.HW;
+    for (int c = t; c < a.C; c += 256) {
+        float s = 0.f;
+        for (int r = 0; r < nrows; ++r) s += s_part[(r * CV + c / VE) * VE + (c % VE)];
+        s_pool[c] = s * inv;
+    }
+    __syncthreads();
+    // phase 2: hidden[r] = act1(w1[r,:] . pooled + b1[r]) -- one wave per output, lanes split C
+    for (int r = wave; r < a.R; r += 4) {
+        const float* w = a.w1 + (size_t)r * a.C;
+        float s = 0.f;
+        for (int k = lane; k < a.C; k += 64) s = fmaf(w[k], s_pool[k], s);
+        for (int mask = 1; mask < 64; mask <<= 1) s += pf_shfl_xor_f32(s, mask);
+        if (lane == 0) {
+            s = pf_act(s + (a.b1 ? a.b1[r] : 0.f), a.act1);
+            if (a.s2) s = pf_act(a.s2[r] * s + a.t2[r], a.act2);
+            s_hid[r] = s;
+        }
+    }
+    __syncthreads();
+    // phase 3: out[n] = act3(w2[n,:] . hidden + b2[n]) -- one thread per output
+    for (int n = t; n < a.N; n += 256) {
+        float s = a.b2 ? a.b2[n] : 0.f;
+        for (int r = 0; r < a.R; ++r) s = fmaf(a.w2t[(size_t)r * a.N + n], s_hid[r], s);
+        a.out[(size_t)b * a.N + n] = pf_act(s, a.act3);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Depthwise conv, TX outputs per thread along x: input taps are loaded once per row and reused across
+// the TX outputs and the K horizontal taps (the per-output variant above issues K*K 16-byte loads per
+// output vector; this one (TX-1)*S+(K-1)*d+1 per row).
+template <typename T, int K, int S, int TX>
+__global__ __launch_bounds__(256) void dw_conv_tiled_kernel(DwArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int CV = a.C / VE;
+    const int xtiles = (a.outW + TX - 1) / TX;
+    const long long total = (long long)a.B * a.outH * xtiles * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    long long t2 = idx / CV;
+    const int xt = (int)(t2 % xtiles);
+    t2 /= xtiles;
+    const int oy = (int)(t2 % a.outH);
+    const int b = (int)(t2 / a.outH);
+    const int ox0 = xt * TX;
+    const T* in = static_cast<const T*>(a.in) + (size_t)b * a.inH * a.inW * a.inLd + cv * VE;
+    const T* wt = static_cast<const T*>(a.wt) + cv * VE;
+    float acc[TX][VE];
+#pragma unroll
+    for (int j = 0; j < TX; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) acc[j][e] = a.bias[cv * VE + e];
+    const int dil = a.dil;
+    const int ix_base = ox0 * S - a.pad;
+    for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - a.pad + ky * dil;
+        if ((unsigned)iy >= (unsigned)a.inH) continue;
+        const T* row = in + (size_t)iy * a.inW * a.inLd;
+        vec_t w[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) w[kx] = pf_ldv<T>(wt + (size_t)(ky * K + kx) * a.C);
+        if (dil == 1) {
+            constexpr int SPAN = (TX - 1) * S + K;
+            vec_t x[SPAN];
+#pragma unroll
+            for (int i = 0; i < SPAN; ++i) {
+                const int ix = ix_base + i;
+                x[i] = (unsigned)ix < (unsigned)a.inW ? pf_ldv<T>(row + (size_t)ix * a.inLd) : pf_zero_vec<T>();
+            }
+#pragma unroll
+            for (int j = 0; j < TX; ++j)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[j][e] = fmaf((float)x[j * S + kx][e], (float)w[kx][e], acc[j][e]);
+        } else {
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+                for (int j = 0; j < TX; ++j) {
+                    const int ix = ix_base + j * S + kx * dil;
+                    if ((unsigned)ix < (unsigned)a.inW) {
+                        const vec_t xv = pf_ldv<T>(row + (size_t)ix * a.inLd);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) acc[j][e] = fmaf((float)xv[e], (float)w[kx][e], acc[j][e]);
+                    }
+                }
+            }
+        }
+    }
+    T* out = static_cast<T*>(a.out) + ((size_t)(b * a.outH + oy) * a.outW) * a.outLd + cv * VE;
+#pragma unroll
+    for (int j = 0; j < TX; ++j) {
+        if (ox0 + j < a.outW) {
+            vec_t o;
+#pragma unroll
+            for (int e = 0; e < VE; ++e) o[e] = (T)pf_act(acc[j][e], a.act);
+            pf_stv<T>(out + (size_t)(ox0 + j) * a.outLd, o);
+        }
+    }
+}

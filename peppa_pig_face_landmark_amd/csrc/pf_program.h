@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 3
+#define PF_PROGRAM_VERSION 4
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -35,7 +35,7 @@ struct PfOpRec {
 };
 
 enum PfOpCode : int32_t {
-    PF_OP_STEM = 1,     // f: in_t(-1 = program input) out_t wt bias act
+    PF_OP_STEM = 1,     // f: in_t(-1 = program input) out_t wt(u8 input, 1/255 folded) bias act wt(f32 input)
     PF_OP_CONV = 2,     // f: in_t out_t wt bias res_t gate_buf fbias_buf KH KW stride pad dil Cpad Npad N act
                         //    outCs amax_val_buf amax_idx_buf amaxN store_out cfg
     PF_OP_DW = 3,       // f: in_t out_t wt bias K stride pad dil act
@@ -47,6 +47,7 @@ enum PfOpCode : int32_t {
     PF_OP_MAXPOOL = 9,  // f: in_t out_t            (2x2 stride 2, ceil mode)
     PF_OP_COPY = 10,    // f: in_t out_t out_cs up  (channel-strided copy, optional nearest x2 upsample)
     PF_OP_DETDEC = 11,  // f: in_t rows_buf row0 stride anchors(wt off, 6 floats) nrows_total
+    PF_OP_POOLMLP = 12, // f: in_t out_buf w1 b1 R act1 s2 t2 act2 w2t b2 N act3
 };
 
 // tile configurations of conv_gemm_kernel (index = cfg field)
