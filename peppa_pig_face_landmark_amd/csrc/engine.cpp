@@ -176,7 +176,10 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.inH = ti.H; a.inW = ti.W; a.C = ti.C; a.inLd = ti.ld;
                 a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
                 a.K = f[4]; a.stride = f[5]; a.pad = f[6]; a.dil = f[7]; a.act = f[8];
-                ProfScope ps(h, "dw_conv");
+                char tagbuf[64];
+                tagbuf[0] = 0;
+                if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "dw%dx%ds%dd%d_c%d_%dx%d", a.K, a.K, a.stride, a.dil, a.C, a.outH, a.outW);
+                ProfScope ps(h, tagbuf);
                 constexpr int TX = 4;
                 const long long tiled = (long long)B * to.H * ((to.W + TX - 1) / TX) * (ti.C / VE);
                 const dim3 tg((unsigned)((tiled + 255) / 256));
@@ -212,20 +215,6 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 PF_LAUNCH((gap_kernel<T>), dim3(pf_div_up(ti.C / VE, 8), B), dim3(256), h->stream, a);
                 break;
             }
-            case PF_OP_POOLMLP: {
-                const PfTensorRec& ti = p.tens[f[0]];
-                PoolMlpArgs a{};
-                a.in = p.tensor_ptr(f[0]); a.out = (float*)p.buf_ptr(f[1]);
-                a.w1 = (const float*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]); a.R = f[4]; a.act1 = f[5];
-                a.s2 = (const float*)p.cptr(f[6]); a.t2 = (const float*)p.cptr(f[7]); a.act2 = f[8];
-                a.w2t = (const float*)p.cptr(f[9]); a.b2 = (const float*)p.cptr(f[10]); a.N = f[11]; a.act3 = f[12];
-                a.B = B; a.HW = ti.H * ti.W; a.C = ti.C; a.ld = ti.ld;
-                if (a.C > PF_POOLMLP_MAXC || a.R > PF_POOLMLP_MAXR || a.C / VE > 256 || a.C / VE < 1)
-                    PF_FAIL(h, "pool_mlp: C=%d R=%d outside kernel limits", a.C, a.R);
-                ProfScope ps(h, "pool_mlp");
-                PF_LAUNCH((pool_mlp_kernel<T>), dim3(B), dim3(256), h->stream, a);
-                break;
-            }
             case PF_OP_FC: {
                 FcArgs a{};
                 a.x = (const float*)p.buf_ptr(f[0]); a.y = (float*)p.buf_ptr(f[1]);
@@ -233,7 +222,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.K = f[4]; a.N = f[5]; a.act = f[6];
                 a.scale2 = (const float*)p.cptr(f[7]); a.shift2 = (const float*)p.cptr(f[8]); a.act2 = f[9];
                 ProfScope ps(h, "fc");
-                PF_LAUNCH(fc_kernel, dim3(pf_div_up(a.N, 256), B), dim3(256), h->stream, a);
+                PF_LAUNCH(fc_kernel, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
                 break;
             }
             case PF_OP_SCSE: {

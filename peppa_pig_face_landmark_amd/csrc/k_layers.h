@@ -220,16 +220,50 @@ struct FcArgs {
     int B, K, N, act, act2;
 };
 
+// Block = 64 outputs x 16 batch items: every weight is read once per 16 items (consecutive threads ->
+// consecutive n, coalesced), the x tile is staged through LDS in chunks of 128 k.
+#define PF_FC_BN 64
+#define PF_FC_BB 16
+#define PF_FC_KT 128
 __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (n >= a.N) return;
-    const float* x = a.x + (size_t)b * a.K;
-    float acc = a.bias ? a.bias[n] : 0.f;
-    for (int k = 0; k < a.K; ++k) acc = fmaf(a.wt[(size_t)k * a.N + n], x[k], acc);
-    acc = pf_act(acc, a.act);
-    if (a.scale2) acc = pf_act(a.scale2[n] * acc + a.shift2[n], a.act2);
-    a.y[(size_t)b * a.N + n] = acc;
+    __shared__ float xs[PF_FC_BB][PF_FC_KT];
+    const int t = threadIdx.x;
+    const int nl = t & (PF_FC_BN - 1);     // output within the tile
+    const int bg = t >> 6;                 // 4 groups of 4 batch items
+    const int n = blockIdx.x * PF_FC_BN + nl;
+    const int b0 = blockIdx.y * PF_FC_BB;
+    const bool nok = n < a.N;
+    float acc[4];
+    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = bias;
+    for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
+        const int kt = a.K - k0 < PF_FC_KT ? a.K - k0 : PF_FC_KT;
+        for (int i = t; i < PF_FC_BB * PF_FC_KT; i += 256) {
+            const int bb = i / PF_FC_KT, kk = i - bb * PF_FC_KT;
+            xs[bb][kk] = (b0 + bb < a.B && kk < kt) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
+        }
+        __syncthreads();
+        if (nok) {
+            const float* w = a.wt + (size_t)k0 * a.N + n;
+#pragma unroll 8
+            for (int kk = 0; kk < kt; ++kk) {
+                const float wv = w[(size_t)kk * a.N];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv, xs[bg * 4 + i][kk], acc[i]);
+            }
+        }
+        __syncthreads();
+    }
+    if (!nok) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = b0 + bg * 4 + i;
+        if (b >= a.B) continue;
+        float v = pf_act(acc[i], a.act);
+        if (a.scale2) v = pf_act(a.scale2[n] * v + a.shift2[n], a.act2);
+        a.y[(size_t)b * a.N + n] = v;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -447,84 +481,6 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DetDecArgs a) {
     float* out = a.rows + ((size_t)b * a.nrows_total + a.row0 + ((size_t)an * a.ny + y) * a.nx + x) * 16;
 #pragma unroll
     for (int o = 0; o < 16; o += 4) *reinterpret_cast<pf_f32x4*>(out + o) = pf_f32x4{r[o], r[o + 1], r[o + 2], r[o + 3]};
-}
-
-// --------------------------------------------------------------------------------------------
-// Fused squeeze-excite style gate: global average pool -> FC -> act [-> affine -> act] -> FC -> act,
-// one workgroup per batch item, pooled / hidden vectors never leave LDS.  Covers timm SqueezeExcite
-// (mean -> conv_reduce -> ReLU -> conv_expand -> hard_sigmoid), SCSEModule.cSE (model.py:119-125) and the
-// ASPP pooling branch folded into a per-face bias of the project conv (model.py:46-61,92-96).
-struct PoolMlpArgs {
-    const void* in;       // T [B][HW][ld], channels [0, C)
-    float* out;           // [B][N]
-    const float* w1;      // [R][C]
-    const float* b1;      // [R] or nullptr
-    const float* s2;      // optional affine on the hidden vector: h = act2(s2*h + t2)
-    const float* t2;
-    const float* w2t;     // [R][N]  (transposed: consecutive threads read consecutive n)
-    const float* b2;      // [N] or nullptr
-    int B, HW, C, ld, R, N, act1, act2, act3;
-};
-
-#define PF_POOLMLP_MAXC 1024
-#define PF_POOLMLP_MAXR 256
-
-template <typename T>
-__global__ __launch_bounds__(256) void pool_mlp_kernel(PoolMlpArgs a) {
-    typedef typename PfVec<T>::type vec_t;
-    constexpr int VE = PfVec<T>::N;
-    __shared__ float s_pool[PF_POOLMLP_MAXC + PF_POOLMLP_MAXR + 256 * VE];
-    float* s_hid = s_pool + PF_POOLMLP_MAXC;
-    float* s_part = s_hid + PF_POOLMLP_MAXR;   // [256 threads][VE] per-thread partial sums
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int b = blockIdx.x;
-    // phase 1: channel means.  thread -> (channel vector cv, pixel row prow); fixed-order reduction
-    // (no atomics) so results are bit-reproducible.  Host guarantees C/VE <= 256.
-    const int CV = a.C / VE;
-    const int nrows = 256 / CV;
-    const int cv = t % CV, prow = t / CV;
-    const T* in = static_cast<const T*>(a.in) + (size_t)b * a.HW * a.ld;
-    {
-        float acc[VE];
-#pragma unroll
-        for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-        if (prow < nrows) {
-            for (int p = prow; p < a.HW; p += nrows) {
-                const vec_t x = pf_ldv<T>(in + (size_t)p * a.ld + cv * VE);
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[e] += (float)x[e];
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < VE; ++e) s_part[t * VE + e] = acc[e];
-    }
-    __syncthreads();
-    const float inv = 1.0f / (float)a.HW;
-    for (int c = t; c < a.C; c += 256) {
-        float s = 0.f;
-        for (int r = 0; r < nrows; ++r) s += s_part[(r * CV + c / VE) * VE + (c % VE)];
-        s_pool[c] = s * inv;
-    }
-    __syncthreads();
-    // phase 2: hidden[r] = act1(w1[r,:] . pooled + b1[r]) -- one wave per output, lanes split C
-    for (int r = wave; r < a.R; r += 4) {
-        const float* w = a.w1 + (size_t)r * a.C;
-        float s = 0.f;
-        for (int k = lane; k < a.C; k += 64) s = fmaf(w[k], s_pool[k], s);
-        for (int mask = 1; mask < 64; mask <<= 1) s += pf_shfl_xor_f32(s, mask);
-        if (lane == 0) {
-            s = pf_act(s + (a.b1 ? a.b1[r] : 0.f), a.act1);
-            if (a.s2) s = pf_act(a.s2[r] * s + a.t2[r], a.act2);
-            s_hid[r] = s;
-        }
-    }
-    __syncthreads();
-    // phase 3: out[n] = act3(w2[n,:] . hidden + b2[n]) -- one thread per output
-    for (int n = t; n < a.N; n += 256) {
-        float s = a.b2 ? a.b2[n] : 0.f;
-        for (int r = 0; r < a.R; ++r) s = fmaf(a.w2t[(size_t)r * a.N + n], s_hid[r], s);
-        a.out[(size_t)b * a.N + n] = pf_act(s, a.act3);
-    }
 }
 
 // --------------------------------------------------------------------------------------------

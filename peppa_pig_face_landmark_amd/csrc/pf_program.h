@@ -47,7 +47,6 @@ enum PfOpCode : int32_t {
     PF_OP_MAXPOOL = 9,  // f: in_t out_t            (2x2 stride 2, ceil mode)
     PF_OP_COPY = 10,    // f: in_t out_t out_cs up  (channel-strided copy, optional nearest x2 upsample)
     PF_OP_DETDEC = 11,  // f: in_t rows_buf row0 stride anchors(wt off, 6 floats) nrows_total
-    PF_OP_POOLMLP = 12, // f: in_t out_buf w1 b1 R act1 s2 t2 act2 w2t b2 N act3
 };
 
 // tile configurations of conv_gemm_kernel (index = cfg field)

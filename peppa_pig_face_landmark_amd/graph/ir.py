@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32 = 0, 1
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_POOLMLP = range(1, 13)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC = range(1, 12)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -216,23 +216,6 @@ class ProgramBuilder:
         s2 = self.const_f32(scale2) if scale2 is not None else -1
         t2 = self.const_f32(shift2) if shift2 is not None else -1
         self._op(OP_FC, [xbuf, out, woff, boff, k, n, ACT[act], s2, t2, ACT[act2]], [xbuf], [out])
-        return out
-
-    def pool_mlp(self, x: int, w1: np.ndarray, b1: Optional[np.ndarray], act1: str, w2: np.ndarray,
-                 b2: Optional[np.ndarray], act3: str, scale2: Optional[np.ndarray] = None,
-                 shift2: Optional[np.ndarray] = None, act2: str = "none") -> int:
-        """Fused gate: out = act3(W2 . post(act1(W1 . mean_hw(x) + b1)) + b2), post = optional affine+act2.
-        w1 [R,C], w2 [N,R]; returns the f32 [N] buffer (one workgroup per batch item on the GPU)."""
-        ti = self.tensors[x]
-        r, c = w1.shape
-        n, r2 = w2.shape
-        assert c == ti.C and r2 == r and c <= 1024 and r <= 256 and c // self.ve <= 256
-        out = self.buffer(n, ELEM_F32, "pool_mlp")
-        f = [x, out, self.const_f32(w1), self.const_f32(b1) if b1 is not None else -1, r, ACT[act1],
-             self.const_f32(scale2) if scale2 is not None else -1, self.const_f32(shift2) if shift2 is not None else -1,
-             ACT[act2], self.const_f32(np.transpose(np.asarray(w2, np.float64), (1, 0))),
-             self.const_f32(b2) if b2 is not None else -1, n, ACT[act3]]
-        self._op(OP_POOLMLP, f, [self._tb(x)], [out])
         return out
 
     def scse(self, x: int, cse_buf: int, sse_w: np.ndarray, sse_b: float, out_name: str = "") -> int:

@@ -86,10 +86,11 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 gate = -1
                 if se:
+                    pooled = pb.gap(x)
                     rd = w[f"{p}.se.conv_reduce.weight"]
                     ex = w[f"{p}.se.conv_expand.weight"]
-                    gate = pb.pool_mlp(x, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu",
-                                       ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
+                    hid = pb.fc(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu")
+                    gate = pb.fc(hid, ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, gate_buf=gate, out_name=f"{p}.out")
             cur_dil = next_dil
@@ -107,10 +108,11 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
         view = pb.view(cat_buf, h16, h16, 64, 64 * j, 192, name=f"{a}.{name}")
         pb.conv(encx16, wj, t_cat[64 * j:64 * j + 64], "relu", pad=pad, dil=dil, out=view)
     cat = pb.view(cat_buf, h16, h16, 192, 0, 192, name=f"{a}.cat192")
+    pooled = pb.gap(encx16)
     wp, bp = ir.fold_bn(w[f"{a}.fm_pool.pool.1.weight"], None, _bn(w, f"{a}.fm_pool.pool.2"))
+    v = pb.fc(pooled, wp.reshape(64, -1), bp, "relu", scale2=s_cat[192:256], shift2=t_cat[192:256], act2="relu")
     wproj, bproj = ir.fold_bn(w[f"{a}.project.0.weight"], None, _bn(w, f"{a}.project.1"))
-    fbias = pb.pool_mlp(encx16, wp.reshape(64, -1), bp, "relu", wproj[:, 192:256, 0, 0], None, "none",
-                        scale2=s_cat[192:256], shift2=t_cat[192:256], act2="relu")
+    fbias = pb.fc(v, wproj[:, 192:256, 0, 0], None, "none")
     x16 = pb.conv(cat, wproj[:, :192], bproj, "relu", fbias_buf=fbias, out_name=f"{a}.out")
 
     # ---- decoder blocks (model.py:133-196) -------------------------------------------------------
@@ -125,9 +127,10 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
             wt, b = ir.fold_bn(w[f"{name}.conv2.0.weight"], w[f"{name}.conv2.0.bias"], _bn(w, f"{name}.conv2.1"))
             x = pb.conv(x, wt, b, "relu", pad=1, out_name=f"{name}.conv2")
         if att:
+            pooled = pb.gap(x)
             w1, w2 = w[f"{name}.attention2.cSE.1.weight"], w[f"{name}.attention2.cSE.3.weight"]
-            cse = pb.pool_mlp(x, w1.reshape(w1.shape[0], -1), w[f"{name}.attention2.cSE.1.bias"], "relu",
-                              w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid")
+            hid = pb.fc(pooled, w1.reshape(w1.shape[0], -1), w[f"{name}.attention2.cSE.1.bias"], "relu")
+            cse = pb.fc(hid, w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid")
             x = pb.scse(x, cse, w[f"{name}.attention2.sSE.0.weight"], float(w[f"{name}.attention2.sSE.0.bias"][0]),
                         out_name=f"{name}.scse")
         return x
