@@ -121,10 +121,24 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     a.outH = to.H; a.outW = to.W; a.N = f[14]; a.Npad = f[13]; a.outLd = to.ld; a.outCs = f[16];
     a.KH = f[7]; a.KW = f[8]; a.stride = f[9]; a.pad = f[10]; a.dil = f[11]; a.Cpad = f[12];
     a.act = f[15]; a.amaxN = f[19]; a.store_out = f[20];
+    // tile configurations: index -> (BM pixels, BN channels).  The channel tile is chosen so that
+    // q tiles of NT*16 channels cover Npad with the least padding (NT <= 8), ties -> fewer tiles.
+    static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256};
+    static const int bn[PF_CONV_NCFG] = {128, 64, 32, 16, 80, 96, 112, 48};
+    static const int cfg_of_nt[9] = {-1, 3, 2, 7, 1, 4, 5, 6, 0};
     int cfg = f[21];
-    if (cfg < 0) cfg = a.Npad > 64 ? 0 : (a.Npad > 32 ? 1 : (a.Npad > 16 ? 2 : 3));
+    if (cfg < 0) {
+        const int t16 = a.Npad / 16;
+        int best_q = 0, best_nt = 0, best_cost = 1 << 30;
+        for (int q = (t16 + 7) / 8; q <= (t16 + 7) / 8 + 3; ++q) {
+            const int nt = (t16 + q - 1) / q;
+            if (nt < 1 || nt > 8) continue;
+            if (q * nt < best_cost) { best_cost = q * nt; best_q = q; best_nt = nt; }
+        }
+        (void)best_q;
+        cfg = cfg_of_nt[best_nt];
+    }
     const int M = B * a.outH * a.outW;
-    static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256}, bn[PF_CONV_NCFG] = {128, 64, 32, 16};
     if (a.amax_val && ((a.outH * a.outW) % bm[cfg]) != 0) PF_FAIL(h, "argmax conv: H*W=%d not a multiple of BM=%d", a.outH * a.outW, bm[cfg]);
     dim3 grid(pf_div_up(M, bm[cfg]), pf_div_up(a.Npad, bn[cfg]));
     char tagbuf[96];
@@ -137,7 +151,11 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         case 0: PF_LAUNCH((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), h->stream, a); break;
         case 1: PF_LAUNCH((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), h->stream, a); break;
         case 2: PF_LAUNCH((conv_gemm_kernel<T, 256, 32, 4, 1>), grid, dim3(256), h->stream, a); break;
-        default: PF_LAUNCH((conv_gemm_kernel<T, 256, 16, 4, 1>), grid, dim3(256), h->stream, a); break;
+        case 3: PF_LAUNCH((conv_gemm_kernel<T, 256, 16, 4, 1>), grid, dim3(256), h->stream, a); break;
+        case 4: PF_LAUNCH((conv_gemm_kernel<T, 128, 80, 4, 1>), grid, dim3(256), h->stream, a); break;
+        case 5: PF_LAUNCH((conv_gemm_kernel<T, 128, 96, 4, 1>), grid, dim3(256), h->stream, a); break;
+        case 6: PF_LAUNCH((conv_gemm_kernel<T, 128, 112, 4, 1>), grid, dim3(256), h->stream, a); break;
+        default: PF_LAUNCH((conv_gemm_kernel<T, 256, 48, 4, 1>), grid, dim3(256), h->stream, a); break;
     }
     return 0;
 }
@@ -180,13 +198,15 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 tagbuf[0] = 0;
                 if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "dw%dx%ds%dd%d_c%d_%dx%d", a.K, a.K, a.stride, a.dil, a.C, a.outH, a.outW);
                 ProfScope ps(h, tagbuf);
-                constexpr int TX = 4;
-                const long long tiled = (long long)B * to.H * ((to.W + TX - 1) / TX) * (ti.C / VE);
-                const dim3 tg((unsigned)((tiled + 255) / 256));
-                if (a.K == 3 && a.stride == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 1, TX>), tg, dim3(256), h->stream, a);
-                else if (a.K == 3 && a.stride == 2) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 2, TX>), tg, dim3(256), h->stream, a);
-                else if (a.K == 5 && a.stride == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 1, TX>), tg, dim3(256), h->stream, a);
-                else if (a.K == 5 && a.stride == 2) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 2, TX>), tg, dim3(256), h->stream, a);
+                auto tgrid = [&](int tx) {
+                    const long long n = (long long)B * to.H * ((to.W + tx - 1) / tx) * (ti.C / VE);
+                    return dim3((unsigned)((n + 255) / 256));
+                };
+                if (a.K == 3 && a.stride == 1 && a.dil == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 1, 1, 4>), tgrid(4), dim3(256), h->stream, a);
+                else if (a.K == 3 && a.stride == 2 && a.dil == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 3, 2, 1, 4>), tgrid(4), dim3(256), h->stream, a);
+                else if (a.K == 5 && a.stride == 1 && a.dil == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 1, 1, 4>), tgrid(4), dim3(256), h->stream, a);
+                else if (a.K == 5 && a.stride == 2 && a.dil == 1) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 2, 1, 4>), tgrid(4), dim3(256), h->stream, a);
+                else if (a.K == 5 && a.stride == 1 && a.dil == 2) PF_LAUNCH((dw_conv_tiled_kernel<T, 5, 1, 2, 8>), tgrid(8), dim3(256), h->stream, a);
                 else {
                     const long long total = (long long)B * to.H * to.W * (ti.C / VE);
                     PF_LAUNCH((dw_conv_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);

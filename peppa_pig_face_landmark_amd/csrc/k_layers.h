@@ -220,49 +220,59 @@ struct FcArgs {
     int B, K, N, act, act2;
 };
 
-// Block = 64 outputs x 16 batch items: every weight is read once per 16 items (consecutive threads ->
-// consecutive n, coalesced), the x tile is staged through LDS in chunks of 128 k.
+// Block = 64 outputs x 16 batch items; the 4 waves split every 128-wide K chunk four ways (32 k
+// each) so four times as many weight loads are in flight per CU; every weight is read once per 16
+// items (consecutive lanes -> consecutive n, coalesced); x is staged through LDS and read as float4.
 #define PF_FC_BN 64
 #define PF_FC_BB 16
 #define PF_FC_KT 128
 __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
-    __shared__ float xs[PF_FC_BB][PF_FC_KT];
+    __shared__ __attribute__((aligned(16))) float smem[PF_FC_BB * PF_FC_KT + 4 * PF_FC_BB * PF_FC_BN];
+    float(*xs)[PF_FC_KT] = reinterpret_cast<float(*)[PF_FC_KT]>(smem);
+    float* red = smem + PF_FC_BB * PF_FC_KT;   // [4 k-slices][16 items][64 outputs]
     const int t = threadIdx.x;
-    const int nl = t & (PF_FC_BN - 1);     // output within the tile
-    const int bg = t >> 6;                 // 4 groups of 4 batch items
+    const int nl = t & (PF_FC_BN - 1);
+    const int ks = t >> 6;
     const int n = blockIdx.x * PF_FC_BN + nl;
     const int b0 = blockIdx.y * PF_FC_BB;
     const bool nok = n < a.N;
-    float acc[4];
-    const float bias = (nok && a.bias) ? a.bias[n] : 0.f;
+    float acc[PF_FC_BB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = bias;
+    for (int i = 0; i < PF_FC_BB; ++i) acc[i] = 0.f;
     for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
-        const int kt = a.K - k0 < PF_FC_KT ? a.K - k0 : PF_FC_KT;
         for (int i = t; i < PF_FC_BB * PF_FC_KT; i += 256) {
             const int bb = i / PF_FC_KT, kk = i - bb * PF_FC_KT;
-            xs[bb][kk] = (b0 + bb < a.B && kk < kt) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
+            xs[bb][kk] = (b0 + bb < a.B && k0 + kk < a.K) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
         }
         __syncthreads();
         if (nok) {
-            const float* w = a.wt + (size_t)k0 * a.N + n;
-#pragma unroll 8
-            for (int kk = 0; kk < kt; ++kk) {
-                const float wv = w[(size_t)kk * a.N];
+#pragma unroll 2
+            for (int kk = ks * 32; kk < ks * 32 + 32; kk += 4) {
+                float wv[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = fmaf(wv, xs[bg * 4 + i][kk], acc[i]);
+                for (int j = 0; j < 4; ++j) wv[j] = (k0 + kk + j < a.K) ? a.wt[(size_t)(k0 + kk + j) * a.N + n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < PF_FC_BB; ++i) {
+                    const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[i][kk]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i] = fmaf(wv[j], xv[j], acc[i]);
+                }
             }
         }
         __syncthreads();
     }
-    if (!nok) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int b = b0 + bg * 4 + i;
-        if (b >= a.B) continue;
-        float v = pf_act(acc[i], a.act);
-        if (a.scale2) v = pf_act(a.scale2[n] * v + a.shift2[n], a.act2);
-        a.y[(size_t)b * a.N + n] = v;
+    for (int i = 0; i < PF_FC_BB; ++i) red[(ks * PF_FC_BB + i) * PF_FC_BN + nl] = acc[i];
+    __syncthreads();
+    for (int o = t; o < PF_FC_BB * PF_FC_BN; o += 256) {
+        const int i = o / PF_FC_BN, nn = o - i * PF_FC_BN;
+        const int b = b0 + i, ng = blockIdx.x * PF_FC_BN + nn;
+        if (b >= a.B || ng >= a.N) continue;
+        float v = (a.bias ? a.bias[ng] : 0.f) + ((red[(0 * PF_FC_BB + i) * PF_FC_BN + nn] + red[(1 * PF_FC_BB + i) * PF_FC_BN + nn]) +
+                                                 (red[(2 * PF_FC_BB + i) * PF_FC_BN + nn] + red[(3 * PF_FC_BB + i) * PF_FC_BN + nn]));
+        v = pf_act(v, a.act);
+        if (a.scale2) v = pf_act(a.scale2[ng] * v + a.shift2[ng], a.act2);
+        a.y[(size_t)b * a.N + ng] = v;
     }
 }
 
@@ -486,8 +496,8 @@ __global__ __launch_bounds__(256) void detect_decode_kernel(DetDecArgs a) {
 // --------------------------------------------------------------------------------------------
 // Depthwise conv, TX outputs per thread along x: input taps are loaded once per row and reused across
 // the TX outputs and the K horizontal taps (the per-output variant above issues K*K 16-byte loads per
-// output vector; this one (TX-1)*S+(K-1)*d+1 per row).
-template <typename T, int K, int S, int TX>
+// output vector; this one (TX-1)*S+(K-1)*DIL+1 per row).
+template <typename T, int K, int S, int DIL, int TX>
 __global__ __launch_bounds__(256) void dw_conv_tiled_kernel(DwArgs a) {
     typedef typename PfVec<T>::type vec_t;
     constexpr int VE = PfVec<T>::N;
@@ -510,43 +520,27 @@ __global__ __launch_bounds__(256) void dw_conv_tiled_kernel(DwArgs a) {
     for (int j = 0; j < TX; ++j)
 #pragma unroll
         for (int e = 0; e < VE; ++e) acc[j][e] = a.bias[cv * VE + e];
-    const int dil = a.dil;
     const int ix_base = ox0 * S - a.pad;
+    constexpr int SPAN = (TX - 1) * S + (K - 1) * DIL + 1;
     for (int ky = 0; ky < K; ++ky) {
-        const int iy = oy * S - a.pad + ky * dil;
+        const int iy = oy * S - a.pad + ky * DIL;
         if ((unsigned)iy >= (unsigned)a.inH) continue;
         const T* row = in + (size_t)iy * a.inW * a.inLd;
         vec_t w[K];
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) w[kx] = pf_ldv<T>(wt + (size_t)(ky * K + kx) * a.C);
-        if (dil == 1) {
-            constexpr int SPAN = (TX - 1) * S + K;
-            vec_t x[SPAN];
+        vec_t x[SPAN];
 #pragma unroll
-            for (int i = 0; i < SPAN; ++i) {
-                const int ix = ix_base + i;
-                x[i] = (unsigned)ix < (unsigned)a.inW ? pf_ldv<T>(row + (size_t)ix * a.inLd) : pf_zero_vec<T>();
-            }
-#pragma unroll
-            for (int j = 0; j < TX; ++j)
-#pragma unroll
-                for (int kx = 0; kx < K; ++kx)
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) acc[j][e] = fmaf((float)x[j * S + kx][e], (float)w[kx][e], acc[j][e]);
-        } else {
-#pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-#pragma unroll
-                for (int j = 0; j < TX; ++j) {
-                    const int ix = ix_base + j * S + kx * dil;
-                    if ((unsigned)ix < (unsigned)a.inW) {
-                        const vec_t xv = pf_ldv<T>(row + (size_t)ix * a.inLd);
-#pragma unroll
-                        for (int e = 0; e < VE; ++e) acc[j][e] = fmaf((float)xv[e], (float)w[kx][e], acc[j][e]);
-                    }
-                }
-            }
+        for (int i = 0; i < SPAN; ++i) {
+            const int ix = ix_base + i;
+            x[i] = (unsigned)ix < (unsigned)a.inW ? pf_ldv<T>(row + (size_t)ix * a.inLd) : pf_zero_vec<T>();
         }
+#pragma unroll
+        for (int j = 0; j < TX; ++j)
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[j][e] = fmaf((float)x[j * S + kx * DIL][e], (float)w[kx][e], acc[j][e]);
     }
     T* out = static_cast<T*>(a.out) + ((size_t)(b * a.outH + oy) * a.outW) * a.outLd + cv * VE;
 #pragma unroll
