@@ -147,16 +147,24 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         snprintf(tagbuf, sizeof(tagbuf), "conv%dx%d%s_c%d_n%d_%dx%d", a.KH, a.KW, a.amax_val ? "_argmax" : "", a.inC, a.N,
                  a.outH, a.outW);
     ProfScope ps(h, tagbuf);
+    const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+#define PF_CONV_CASE(idx, BM_, BN_, WM_, WN_)                                                              \
+    case idx:                                                                                           \
+        if (pointwise) PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
+        else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
+        break;
     switch (cfg) {
-        case 0: PF_LAUNCH((conv_gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), h->stream, a); break;
-        case 1: PF_LAUNCH((conv_gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), h->stream, a); break;
-        case 2: PF_LAUNCH((conv_gemm_kernel<T, 256, 32, 4, 1>), grid, dim3(256), h->stream, a); break;
-        case 3: PF_LAUNCH((conv_gemm_kernel<T, 256, 16, 4, 1>), grid, dim3(256), h->stream, a); break;
-        case 4: PF_LAUNCH((conv_gemm_kernel<T, 128, 80, 4, 1>), grid, dim3(256), h->stream, a); break;
-        case 5: PF_LAUNCH((conv_gemm_kernel<T, 128, 96, 4, 1>), grid, dim3(256), h->stream, a); break;
-        case 6: PF_LAUNCH((conv_gemm_kernel<T, 128, 112, 4, 1>), grid, dim3(256), h->stream, a); break;
-        default: PF_LAUNCH((conv_gemm_kernel<T, 256, 48, 4, 1>), grid, dim3(256), h->stream, a); break;
+        PF_CONV_CASE(0, 128, 128, 2, 2)
+        PF_CONV_CASE(1, 128, 64, 2, 2)
+        PF_CONV_CASE(2, 256, 32, 4, 1)
+        PF_CONV_CASE(3, 256, 16, 4, 1)
+        PF_CONV_CASE(4, 128, 80, 4, 1)
+        PF_CONV_CASE(5, 128, 96, 4, 1)
+        PF_CONV_CASE(6, 128, 112, 4, 1)
+        default:
+            PF_CONV_CASE(7, 256, 48, 4, 1)
     }
+#undef PF_CONV_CASE
     return 0;
 }
 

@@ -59,7 +59,9 @@ __device__ __forceinline__ int pf_lds_chunk_off(int row, int chunk) {
     return row * 64 + (((chunk + 2 * (row >> 2)) & 3) << 4);
 }
 
-template <typename T, int BM, int BN, int WARPS_M, int WARPS_N>
+// KS = 1: pointwise conv (1x1, stride 1, no padding) -- tap arithmetic compiled out;
+// KS = 3: general kxk conv (any kernel size / stride / dilation / padding).
+template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, int KS>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     typedef typename PfVec<T>::type vec_t;
     constexpr int VE = PfVec<T>::N;       // elements per 16-byte chunk
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         const int oy = rem / a.outW;
         const int ox = rem - oy * a.outW;
         xb[r] = b;
-        xiy0[r] = oy * a.stride - a.pad;
-        xix0[r] = ox * a.stride - a.pad;
+        xiy0[r] = KS == 1 ? oy : oy * a.stride - a.pad;
+        xix0[r] = KS == 1 ? ox : ox * a.stride - a.pad;
     }
-    const int taps = a.KH * a.KW;
+    const int taps = KS == 1 ? 1 : a.KH * a.KW;
     const int cchunks = a.Cpad / KE;
     const int nk = taps * cchunks;
     const size_t wrow_stride = (size_t)taps * a.Cpad;
@@ -111,15 +113,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     vec_t xreg[XROWS], wreg[WROWS];
 
     auto load_tile = [&](int tap, int cc) {
-        const int ky = tap / a.KW;
-        const int kx = tap - ky * a.KW;
+        const int ky = KS == 1 ? 0 : tap / a.KW;
+        const int kx = KS == 1 ? 0 : tap - ky * a.KW;
         const int kelem = cc * KE + chunk * VE;
         const bool kok = kelem < a.inC;
 #pragma unroll
         for (int r = 0; r < XROWS; ++r) {
-            const int iy = xiy0[r] + ky * a.dil;
-            const int ix = xix0[r] + kx * a.dil;
-            const bool ok = xvalid[r] && kok && (unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW;
+            const int iy = KS == 1 ? xiy0[r] : xiy0[r] + ky * a.dil;
+            const int ix = KS == 1 ? xix0[r] : xix0[r] + kx * a.dil;
+            const bool ok = xvalid[r] && kok && (KS == 1 || ((unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW));
             vec_t v = pf_zero_vec<T>();
             if (ok) {
                 const size_t off = ((size_t)(xb[r] * a.inH + iy) * a.inW + ix) * a.inLd + kelem;
