@@ -80,7 +80,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = wave % WARPS_M, wn = wave / WARPS_M;
-    const int m0 = blockIdx.x * BM;
+    // XCD-aware tile order for kxk convs: workgroup b runs on XCD b % 8 (private 4 MiB L2 each), so
+    // give every XCD a contiguous run of pixel tiles -- vertically adjacent tiles, which share their
+    // halo rows, then meet in the same L2.  Pure speed choice; any mapping is correct.
+    int mtile = blockIdx.x;
+    if (KS != 1 && (gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int m0 = mtile * BM;
     const int n0 = blockIdx.y * BN;
     const int OHW = a.outH * a.outW;
     const int M = a.B * OHW;
@@ -172,7 +177,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         if (more) {
-            if (++cc == cchunks) { cc = 0; ++tap; }
+            // channel-chunk outer, tap inner: the KH*KW shifted reads of one 64-byte channel chunk are
+            // issued back to back, so the halo re-reads hit L1/L2 instead of going back to the fabric
+            if (++tap == taps) { tap = 0; ++cc; }
             load_tile(tap, cc);
         }
         const unsigned char* xs = smem + cur * STAGE_BYTES;
