@@ -142,12 +142,21 @@ def main():
     prof = state.profile(3)
     hero_ms, hero_n = prof.get(HERO_TAG, (0.0, 0))
     roofline = None
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
+    if args.dtype == "f32" and os.path.exists(pmc_path):
+        # HBM bytes of the hero launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
+        # separate runs, gfx950 FETCH correction applied), scaled to this run's faces per launch
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        traffic = int(pmc["traffic_bytes_per_launch"] * faces_per_step / pmc["faces_per_launch"])
     if hero_n:
         avg_ms = hero_ms / hero_n
         achieved = HERO_FLOP_PER_FACE * faces_per_step / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128> %s" % (args.dtype, HERO_TAG),
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
+                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_step) if args.dtype == "f32" else int(2 * 64 * 64 * 128 * 2 * faces_per_step),
                     "avg_launch_ms": round(avg_ms, 4), "launches": hero_n}
 
     if args.dump_profile and rank == 0:

@@ -43,15 +43,15 @@ struct ConvGemmArgs {
 
 template <typename T> struct ConvMma;
 template <> struct ConvMma<pf_half> {
-    __device__ static __forceinline__ pf_f32x4 run(pf_half8 w, pf_half8 x, pf_f32x4 c) {
+    static constexpr int KSUB = 1;   // one v_mfma_f32_16x16x32_f16 consumes the whole 64-byte K step
+    __device__ static __forceinline__ pf_f32x4 step(pf_half8 w, pf_half8 x, pf_f32x4 c, int) {
         return pf_mfma_16x16x32_f16(w, x, c);
     }
 };
 template <> struct ConvMma<float> {
-    __device__ static __forceinline__ pf_f32x4 run(pf_f32x4 w, pf_f32x4 x, pf_f32x4 c) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c = pf_mfma_16x16x4_f32(w[j], x[j], c);
-        return c;
+    static constexpr int KSUB = 4;   // four v_mfma_f32_16x16x4_f32 per 64-byte K step
+    __device__ static __forceinline__ pf_f32x4 step(pf_f32x4 w, pf_f32x4 x, pf_f32x4 c, int ks) {
+        return pf_mfma_16x16x4_f32(w[ks], x[ks], c);
     }
 };
 
@@ -191,10 +191,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
             wf[j] = *reinterpret_cast<const vec_t*>(ws + pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk));
+        // issue order: all (j,i) accumulators for one k sub-step before the next sub-step, so that
+        // consecutive MFMAs never depend on each other (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle
+        // dependent latency)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+        for (int ks = 0; ks < ConvMma<T>::KSUB; ++ks)
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = ConvMma<T>::run(wf[j], xf[i], acc[j][i]);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < MT; ++i) acc[j][i] = ConvMma<T>::step(wf[j], xf[i], acc[j][i], ks);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
