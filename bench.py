@@ -29,7 +29,10 @@ if ROOT not in sys.path:
 
 GFLOP_PER_FACE = 2.968       # Student@256 inference graph, SURVEY.md section 8(d) (1 484.1 M MAC)
 GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstream figure)
-PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0}   # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" = f32 tensors, split-precision convs: every product
+# is 3 v_mfma_f32_16x16x32_f16 instructions (hi*hi + hi*lo + lo*hi), so it is priced against the f16 pipe.
+PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
+MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
 HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
 
@@ -43,7 +46,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=256, help="faces per step per GPU (landmark workload)")
     ap.add_argument("--frames", type=int, default=32, help="1080p frames per step per GPU (pipeline workload)")
     ap.add_argument("--faces-per-frame", type=int, default=8)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"])
+    ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
+                    help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
+                         "(same accuracy); f16: f16 storage fast mode (parity not claimed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=48)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
@@ -144,7 +149,7 @@ def main():
     roofline = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
-    if args.dtype == "f32" and os.path.exists(pmc_path):
+    if args.dtype in ("f32", "f32s") and os.path.exists(pmc_path):
         # HBM bytes of the hero launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
         # separate runs, gfx950 FETCH correction applied), scaled to this run's faces per launch
         with open(pmc_path) as f:
@@ -153,11 +158,13 @@ def main():
     if hero_n:
         avg_ms = hero_ms / hero_n
         achieved = HERO_FLOP_PER_FACE * faces_per_step / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel<%s,128,128> %s" % (args.dtype, HERO_TAG),
+        roofline = {"bound": "mfma", "kernel": "%s<128,128> %s" % ("conv_gemm_split_kernel" if args.dtype == "f32s" else "conv_gemm_kernel<%s>" % args.dtype, HERO_TAG),
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_step) if args.dtype == "f32" else int(2 * 64 * 64 * 128 * 2 * faces_per_step),
-                    "avg_launch_ms": round(avg_ms, 4), "launches": hero_n}
+                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_step) if args.dtype != "f16" else int(2 * 64 * 64 * 128 * 2 * faces_per_step),
+                    "avg_launch_ms": round(avg_ms, 4), "launches": hero_n,
+                    "executed_mfma_tflops": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype], 2),
+                    "executed_mfma_frac": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype] / PEAK_TFLOPS[args.dtype], 4)}
 
     if args.dump_profile and rank == 0:
         with open(args.dump_profile, "w") as f:
@@ -171,7 +178,8 @@ def main():
         "metric": "faces/sec (whole node), Student@256" + (" 1080px8-face full pipeline" if workload == "pipeline" else " landmark-only"),
         "value": round(value, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": {"f32": "f32", "f16": "f16", "f32s": "f32 (tensors f32; convs = 3x f16-MFMA split precision, f32 accumulate)"}[args.dtype],
+        "data": "synthetic",
         "config": {"workload": ("configs[2] full pipeline: %d x 1080p frames x %d planted faces per GPU per step" % (args.frames, args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
                    "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d, no data-path collective" % world,

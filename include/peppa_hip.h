@@ -34,7 +34,7 @@ typedef struct pf_handle pf_handle;
 enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1 };
 enum { PF_NET_LANDMARK = 0, PF_NET_DETECTOR = 1, PF_NET_SLOTS = 4 };
 enum { PF_INPUT_U8_NHWC = 0, PF_INPUT_F32_NCHW = 1 };
-enum { PF_DTYPE_F16 = 0, PF_DTYPE_F32 = 1 };
+enum { PF_DTYPE_F16 = 0, PF_DTYPE_F32 = 1, PF_DTYPE_F32_SPLIT = 2 };  /* 2: f32 tensors, 3 x f16-MFMA split-precision convs */
 
 /* library / build identification: "peppa-hip <version> gfx950" (or "... simt-emu" for the
  * CPU test build of the same sources, which only tests/ may load) */

@@ -101,7 +101,7 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool SPLIT>
 static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B) {
     const int32_t* f = op.f;
     const PfTensorRec& ti = p.tens[f[0]];
@@ -121,6 +121,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     a.outH = to.H; a.outW = to.W; a.N = f[14]; a.Npad = f[13]; a.outLd = to.ld; a.outCs = f[16];
     a.KH = f[7]; a.KW = f[8]; a.stride = f[9]; a.pad = f[10]; a.dil = f[11]; a.Cpad = f[12];
     a.act = f[15]; a.amaxN = f[19]; a.store_out = f[20];
+    memcpy(&a.acc_scale, &f[22], 4);
     // tile configurations: index -> (BM pixels, BN channels).  The channel tile is chosen so that
     // q tiles of NT*16 channels cover Npad with the least padding (NT <= 8), ties -> fewer tiles.
     static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256};
@@ -150,8 +151,13 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
 #define PF_CONV_CASE(idx, BM_, BN_, WM_, WN_)                                                              \
     case idx:                                                                                           \
-        if (pointwise) PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
-        else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
+        if constexpr (SPLIT) {                                                                          \
+            if (pointwise) PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
+            else PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
+        } else {                                                                                        \
+            if (pointwise) PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
+            else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
+        }                                                                                               \
         break;
     switch (cfg) {
         PF_CONV_CASE(0, 128, 128, 2, 2)
@@ -168,7 +174,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     return 0;
 }
 
-template <typename T>
+template <typename T, bool SPLIT>
 static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
     Program& p = h->prog[slot];
     constexpr int VE = PfVec<T>::N;
@@ -191,7 +197,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 break;
             }
             case PF_OP_CONV:
-                if (launch_conv<T>(h, p, op, B)) return 1;
+                if (launch_conv<T, SPLIT>(h, p, op, B)) return 1;
                 break;
             case PF_OP_DW: {
                 const PfTensorRec& ti = p.tens[f[0]];
@@ -329,8 +335,9 @@ static int run_program(pf_handle* h, int slot, const void* d_input, int input_ki
     Program& p = h->prog[slot];
     if (!p.loaded) PF_FAIL(h, "no program loaded in slot %d", slot);
     if (B < 1 || B > p.max_batch) PF_FAIL(h, "batch %d outside [1, %d]", B, p.max_batch);
-    return p.hdr.dtype == PF_DTYPE_F16 ? run_program_t<pf_half>(h, slot, d_input, input_kind, B)
-                                       : run_program_t<float>(h, slot, d_input, input_kind, B);
+    if (p.hdr.dtype == PF_DTYPE_F16) return run_program_t<pf_half, false>(h, slot, d_input, input_kind, B);
+    if (p.hdr.dtype == PF_DTYPE_F32_SPLIT) return run_program_t<float, true>(h, slot, d_input, input_kind, B);
+    return run_program_t<float, false>(h, slot, d_input, input_kind, B);
 }
 
 static int ensure_stage(pf_handle* h, size_t bytes) {
@@ -403,7 +410,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     memcpy(&hd, blob, sizeof(hd));
     if (hd.magic != PF_PROGRAM_MAGIC) PF_FAIL(h, "bad program magic 0x%08x", hd.magic);
     if (hd.version != PF_PROGRAM_VERSION) PF_FAIL(h, "program version %d, engine expects %d", hd.version, PF_PROGRAM_VERSION);
-    if (hd.dtype != PF_DTYPE_F16 && hd.dtype != PF_DTYPE_F32) PF_FAIL(h, "bad dtype %d", hd.dtype);
+    if (hd.dtype != PF_DTYPE_F16 && hd.dtype != PF_DTYPE_F32 && hd.dtype != PF_DTYPE_F32_SPLIT) PF_FAIL(h, "bad dtype %d", hd.dtype);
     size_t off = sizeof(PfHeader);
     const size_t need = off + (size_t)hd.n_bufs * sizeof(PfBufRec) + (size_t)hd.n_tensors * sizeof(PfTensorRec) +
                         (size_t)hd.n_ops * sizeof(PfOpRec);

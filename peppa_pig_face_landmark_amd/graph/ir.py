@@ -20,7 +20,7 @@ MAGIC = 0x47504650
 VERSION = 4
 OP_FIELDS = 39
 
-DTYPE_F16, DTYPE_F32 = 0, 1
+DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
@@ -64,12 +64,13 @@ class _Tensor:
 
 class ProgramBuilder:
     def __init__(self, dtype: str, in_h: int, in_w: int, keep_all: bool = False):
-        assert dtype in ("f16", "f32")
-        self.dtype = DTYPE_F16 if dtype == "f16" else DTYPE_F32
+        assert dtype in ("f16", "f32", "f32s")
+        self.dtype = {"f16": DTYPE_F16, "f32": DTYPE_F32, "f32s": DTYPE_F32_SPLIT}[dtype]
+        self.split = dtype == "f32s"         # f32 tensors, split-precision (3 x f16 MFMA) dense convs
         self.np_act = np.float16 if dtype == "f16" else np.float32
         self.esize = 2 if dtype == "f16" else 4
         self.ve = 16 // self.esize          # elements per 16-byte vector
-        self.ke = 64 // self.esize          # elements per 64-byte K step
+        self.ke = 32 if self.split else 64 // self.esize   # elements per K step of the GEMM
         self.in_h, self.in_w = in_h, in_w
         self.keep_all = keep_all
         self.bufs: List[_Buf] = []
@@ -147,13 +148,23 @@ class ProgramBuilder:
         self._op(OP_STEM, [-1, out, off_u8, off_b, ACT[act], off_f32], [], [self._tb(out)])
         return out
 
-    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int]:
-        """[N,Cin,KH,KW] -> const offset of [Npad][KH*KW][Cpad] in the activation dtype."""
+    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int, float]:
+        """[N,Cin,KH,KW] -> (const offset, Npad, Cpad, acc_scale).
+        direct modes: [Npad][KH*KW][Cpad] in the activation dtype, acc_scale 1;
+        split mode  : [Npad][KH*KW][Cpad/32][hi 32 x f16 | lo 32 x f16] of w * 2^s, acc_scale 2^-s."""
         n, cin, kh, kw = weight.shape
         npad, cpad = _round_up(n, 16), _round_up(cin, self.ke)
         w = np.zeros((npad, kh * kw, cpad), np.float64)
         w[:n, :, :cin] = np.transpose(weight.astype(np.float64), (0, 2, 3, 1)).reshape(n, kh * kw, cin)
-        return self.const_act(w), npad, cpad
+        if not self.split:
+            return self.const_act(w), npad, cpad, 1.0
+        wmax = float(np.abs(w).max())
+        s = 0 if wmax == 0.0 else int(np.floor(np.log2(16384.0 / wmax)))   # max |w * 2^s| in [2^13, 2^14]
+        ws = (w * (2.0 ** s)).astype(np.float32)
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        blocks = np.stack([hi.reshape(npad, kh * kw, cpad // 32, 32), lo.reshape(npad, kh * kw, cpad // 32, 32)], axis=3)
+        return self.const(np.ascontiguousarray(blocks)), npad, cpad, float(2.0 ** (-s))
 
     def conv(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
              dil: int = 1, out: Optional[int] = None, res: int = -1, gate_buf: int = -1, fbias_buf: int = -1,
@@ -169,13 +180,14 @@ class ProgramBuilder:
             out = self.tensor(oh, ow, _round_up(n, self.ve), name=out_name)
         to = self.tensors[out]
         assert (to.H, to.W) == (oh, ow), ((to.H, to.W), (oh, ow))
-        woff, npad, cpad = self.pack_conv_weight(weight)
+        woff, npad, cpad, acc_scale = self.pack_conv_weight(weight)
         b = np.zeros(npad, np.float64)
         b[:n] = bias
         boff = self.const_f32(b)
         av, ai, an = amax if amax is not None else (-1, -1, 0)
         self._op(OP_CONV, [x, out, woff, boff, res, gate_buf, fbias_buf, kh, kw, stride, pad, dil, cpad, npad, n,
-                           ACT[act], out_cs, av, ai, an, 1 if store_out else 0, cfg],
+                           ACT[act], out_cs, av, ai, an, 1 if store_out else 0, cfg,
+                           struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
                  [self._tb(x), self._tb(res), gate_buf, fbias_buf], [self._tb(out), av, ai])
         return out
 

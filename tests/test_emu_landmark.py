@@ -13,10 +13,11 @@ from peppa_pig_face_landmark_amd.graph.student import build_student_program
 from tests import helpers
 
 
-@pytest.mark.parametrize("size", [64, 128])
-def test_student_f32_layers_and_landmarks(emu_engine, student_weights, size):
+@pytest.mark.parametrize("size,dtype", [(64, "f32"), (128, "f32"), (64, "f32s"), (128, "f32s")])
+def test_student_f32_layers_and_landmarks(emu_engine, student_weights, size, dtype):
+    """f32 = exact v_mfma_f32 path; f32s = f32 tensors with split-precision (3 x f16 MFMA) convs."""
     B = 2
-    blob, info = build_student_program(student_weights, size, "f32", keep_all=True, debug_full_hm=True)
+    blob, info = build_student_program(student_weights, size, dtype, keep_all=True, debug_full_hm=True)
     emu_engine.load_program(0, blob, B)
     crops = sw.smooth_blob_images(B, size, seed=1000 + size)
     loc, score = emu_engine.landmark_forward(crops)

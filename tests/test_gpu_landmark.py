@@ -28,9 +28,11 @@ def _layer_report(eng, info, taps, batch, ve):
     return worst
 
 
-@pytest.mark.parametrize("size,batch", [(256, 4), (128, 3)])
-def test_student_f32_matches_oracle(gpu_engine, student_weights, size, batch):
-    blob, info = build_student_program(student_weights, size, "f32", keep_all=True, debug_full_hm=True)
+@pytest.mark.parametrize("size,batch,dtype", [(256, 4, "f32"), (128, 3, "f32"), (256, 4, "f32s"), (128, 3, "f32s")])
+def test_student_f32_matches_oracle(gpu_engine, student_weights, size, batch, dtype):
+    """f32: exact v_mfma_f32_16x16x4_f32 convs.  f32s: f32 tensors, split-precision convs
+    (hi/lo f16 operands, 3 x v_mfma_f32_16x16x32_f16, f32 accumulate) -- same tolerance."""
+    blob, info = build_student_program(student_weights, size, dtype, keep_all=True, debug_full_hm=True)
     gpu_engine.load_program(0, blob, batch)
     crops = sw.smooth_blob_images(batch, size, seed=4000 + size)
     loc, score = gpu_engine.landmark_forward(crops)
@@ -61,11 +63,12 @@ def test_student_f32_production_program_equals_debug_program(gpu_engine, student
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
-def test_student_f32_batch_256_is_batch_independent(gpu_engine, student_weights):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_student_f32_batch_256_is_batch_independent(gpu_engine, student_weights, dtype):
     """BASELINE config 2 size (256 crops): every face's result is independent of its batch-mates
     (size-independent property; the oracle cannot run 256 faces in seconds)."""
     size = 256
-    blob, _ = build_student_program(student_weights, size, "f32")
+    blob, _ = build_student_program(student_weights, size, dtype)
     gpu_engine.load_program(0, blob, 256)
     base = sw.smooth_blob_images(8, size, seed=21)
     big = np.concatenate([base] * 32, 0)

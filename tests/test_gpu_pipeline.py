@@ -21,8 +21,9 @@ def frame1080():
     return make_frame(1080, 1920, 8, seed=7)
 
 
-def test_detector_384x640_matches_oracle(gpu_engine, detector_weights):
-    blob, info = build_detector_program(detector_weights, (384, 640), "f32", keep_all=True)
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_detector_384x640_matches_oracle(gpu_engine, detector_weights, dtype):
+    blob, info = build_detector_program(detector_weights, (384, 640), dtype, keep_all=True)
     assert info["rows"] == 15120                       # face_detector.py:31
     gpu_engine.load_program(1, blob, 2)
     img = sw.smooth_blob_images(2, 640, seed=9)[:, :384]
@@ -82,12 +83,13 @@ def test_crops_256_bit_exact(gpu_engine, frame1080):
             assert np.array_equal(crops[i], pp.landmark_crop(frame, ci, (256, 256))), i
 
 
-def test_run_frames_1080p_x8_planted(gpu_engine, student_weights, detector_weights, frame1080):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_run_frames_1080p_x8_planted(gpu_engine, student_weights, detector_weights, frame1080, dtype):
     """BASELINE configs[2] shape: 1080p frames x 8 faces, detector net running, planted detections."""
     F, K = 2, 8
-    blob, _ = build_student_program(student_weights, 256, "f32")
+    blob, _ = build_student_program(student_weights, 256, dtype)
     gpu_engine.load_program(0, blob, F * K)
-    blob, _ = build_detector_program(detector_weights, (384, 640), "f32")
+    blob, _ = build_detector_program(detector_weights, (384, 640), dtype)
     gpu_engine.load_program(1, blob, F)
     frames, rows_all = [], []
     for f in range(F):
