@@ -149,11 +149,12 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
                  a.outH, a.outW);
     ProfScope ps(h, tagbuf);
     const bool pointwise = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0;
+    const bool use_split = f[23] != 0;   // per-conv choice made by the packer (weights are laid out accordingly)
 #define PF_CONV_CASE(idx, BM_, BN_, WM_, WN_)                                                              \
     case idx:                                                                                           \
-        if constexpr (SPLIT) {                                                                          \
-            if (pointwise) PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
-            else PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
+        if (SPLIT && use_split) {   /* 8 waves per workgroup: twice the M-waves of the direct kernel */ \
+            if (pointwise) PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, 2 * WM_, WN_, 1>), grid, dim3(512), h->stream, a); \
+            else PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, 2 * WM_, WN_, 3>), grid, dim3(512), h->stream, a);          \
         } else {                                                                                        \
             if (pointwise) PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 1>), grid, dim3(256), h->stream, a); \
             else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \

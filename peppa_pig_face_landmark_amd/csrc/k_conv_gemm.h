@@ -321,14 +321,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // K step = 32 elements: per row 64 B of hi + 64 B of lo in LDS (same chunk rotation as above).
 // Weight rows in HBM: [taps][Cpad/32][hi: 32 x f16 | lo: 32 x f16].
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS>
-__global__ __launch_bounds__(256) void conv_gemm_split_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel(ConvGemmArgs a) {
+    constexpr int NTHR = WARPS_M * WARPS_N * 64;       // 256 or 512 threads (8 waves hide the staging latency)
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int XUNITS = BM * 4 / 256;               // (row, 8-float unit) pairs staged per thread
-    constexpr int WCHUNKS = (BN * 8 + 255) / 256;      // 16-byte weight chunks staged per thread
+    constexpr int XUNITS = (BM * 4 + NTHR - 1) / NTHR; // (row, 8-float unit) pairs staged per thread
+    constexpr int XROWSTEP = NTHR / 4;                 // rows covered by one pass of the block
+    constexpr int WCHUNKS = (BN * 8 + NTHR - 1) / NTHR;  // 16-byte weight chunks staged per thread
     constexpr int PLANE_X = BM * 64, PLANE_W = BN * 64;
     constexpr int STAGE_BYTES = 2 * PLANE_X + 2 * PLANE_W;
-    static_assert(WARPS_M * WARPS_N == 4 && BM % 64 == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+    static_assert((NTHR == 256 || NTHR == 512) && WM % 16 == 0 && WN % 16 == 0 && WM > 0 && WN > 0, "tile shape");
+    static_assert((BM * 4) % NTHR == 0, "pixel tile must split evenly over the block");
 
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
 
@@ -345,14 +348,14 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(ConvGemmArgs a) {
     const float* __restrict__ in = static_cast<const float*>(a.in);
     const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
 
-    // pixel staging: unit u of this thread = row (t>>2) + 64u, floats [8*(t&3), 8*(t&3)+8) of the K step
+    // pixel staging: unit u of this thread = row (t>>2) + XROWSTEP*u, floats [8*(t&3), 8*(t&3)+8) of the K step
     const int xc = t & 3;
     const int xrow0 = t >> 2;
     int xb[XUNITS], xiy0[XUNITS], xix0[XUNITS];
     bool xvalid[XUNITS];
 #pragma unroll
     for (int u = 0; u < XUNITS; ++u) {
-        const int m = m0 + xrow0 + 64 * u;
+        const int m = m0 + xrow0 + XROWSTEP * u;
         xvalid[u] = m < M;
         const int mm = xvalid[u] ? m : 0;
         const int b = mm / OHW;
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(ConvGemmArgs a) {
         }
 #pragma unroll
         for (int c = 0; c < WCHUNKS; ++c) {
-            const int q = t + 256 * c;         // chunk id: row = q >> 3, piece = q & 7 (0..3 hi, 4..7 lo)
+            const int q = t + NTHR * c;        // chunk id: row = q >> 3, piece = q & 7 (0..3 hi, 4..7 lo)
             const int row = q >> 3;
             const int n = n0 + row;
             pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -421,13 +424,13 @@ __global__ __launch_bounds__(256) void conv_gemm_split_kernel(ConvGemmArgs a) {
                 hi[e] = hv;
                 lo[e] = (pf_half)(v - (float)hv);
             }
-            const int off = pf_lds_chunk_off(xrow0 + 64 * u, xc);
+            const int off = pf_lds_chunk_off(xrow0 + XROWSTEP * u, xc);
             *reinterpret_cast<pf_half8*>(xh + off) = hi;
             *reinterpret_cast<pf_half8*>(xl + off) = lo;
         }
 #pragma unroll
         for (int c = 0; c < WCHUNKS; ++c) {
-            const int q = t + 256 * c;
+            const int q = t + NTHR * c;
             const int row = q >> 3, piece = q & 7;
             if (row < BN) *reinterpret_cast<pf_f32x4*>((piece < 4 ? wh : wl) + pf_lds_chunk_off(row, piece & 3)) = wreg[c];
         }

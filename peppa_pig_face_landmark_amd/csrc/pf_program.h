@@ -37,7 +37,7 @@ struct PfOpRec {
 enum PfOpCode : int32_t {
     PF_OP_STEM = 1,     // f: in_t(-1 = program input) out_t wt(u8 input, 1/255 folded) bias act wt(f32 input)
     PF_OP_CONV = 2,     // f: in_t out_t wt bias res_t gate_buf fbias_buf KH KW stride pad dil Cpad Npad N act
-                        //    outCs amax_val_buf amax_idx_buf amaxN store_out cfg acc_scale(float bits)
+                        //    outCs amax_val_buf amax_idx_buf amaxN store_out cfg acc_scale(float bits) use_split
     PF_OP_DW = 3,       // f: in_t out_t wt bias K stride pad dil act
     PF_OP_UPCAT = 4,    // f: lo_t skip_t out_t
     PF_OP_GAP = 5,      // f: in_t out_buf

@@ -70,7 +70,7 @@ class ProgramBuilder:
         self.np_act = np.float16 if dtype == "f16" else np.float32
         self.esize = 2 if dtype == "f16" else 4
         self.ve = 16 // self.esize          # elements per 16-byte vector
-        self.ke = 32 if self.split else 64 // self.esize   # elements per K step of the GEMM
+        self.ke = 64 // self.esize          # elements per 64-byte K step of the direct GEMM
         self.in_h, self.in_w = in_h, in_w
         self.keep_all = keep_all
         self.bufs: List[_Buf] = []
@@ -148,23 +148,30 @@ class ProgramBuilder:
         self._op(OP_STEM, [-1, out, off_u8, off_b, ACT[act], off_f32], [], [self._tb(out)])
         return out
 
-    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int, float]:
-        """[N,Cin,KH,KW] -> (const offset, Npad, Cpad, acc_scale).
-        direct modes: [Npad][KH*KW][Cpad] in the activation dtype, acc_scale 1;
-        split mode  : [Npad][KH*KW][Cpad/32][hi 32 x f16 | lo 32 x f16] of w * 2^s, acc_scale 2^-s."""
+    SPLIT_MIN_CIN = 64   # below this a conv is bandwidth-bound: the exact-f32 direct kernel is as fast
+
+    def conv_uses_split(self, cin: int) -> bool:
+        return self.split and cin >= self.SPLIT_MIN_CIN
+
+    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int, float, bool]:
+        """[N,Cin,KH,KW] -> (const offset, Npad, Cpad, acc_scale, use_split).
+        direct kernels: [Npad][KH*KW][Cpad] in the activation dtype (64-byte K steps), acc_scale 1;
+        split kernels : [Npad][KH*KW][Cpad/32][hi 32 x f16 | lo 32 x f16] of w * 2^s, acc_scale 2^-s."""
         n, cin, kh, kw = weight.shape
-        npad, cpad = _round_up(n, 16), _round_up(cin, self.ke)
+        use_split = self.conv_uses_split(cin)
+        ke = 32 if use_split else 64 // self.esize
+        npad, cpad = _round_up(n, 16), _round_up(cin, ke)
         w = np.zeros((npad, kh * kw, cpad), np.float64)
         w[:n, :, :cin] = np.transpose(weight.astype(np.float64), (0, 2, 3, 1)).reshape(n, kh * kw, cin)
-        if not self.split:
-            return self.const_act(w), npad, cpad, 1.0
+        if not use_split:
+            return self.const_act(w), npad, cpad, 1.0, False
         wmax = float(np.abs(w).max())
         s = 0 if wmax == 0.0 else int(np.floor(np.log2(16384.0 / wmax)))   # max |w * 2^s| in [2^13, 2^14]
         ws = (w * (2.0 ** s)).astype(np.float32)
         hi = ws.astype(np.float16)
         lo = (ws - hi.astype(np.float32)).astype(np.float16)
         blocks = np.stack([hi.reshape(npad, kh * kw, cpad // 32, 32), lo.reshape(npad, kh * kw, cpad // 32, 32)], axis=3)
-        return self.const(np.ascontiguousarray(blocks)), npad, cpad, float(2.0 ** (-s))
+        return self.const(np.ascontiguousarray(blocks)), npad, cpad, float(2.0 ** (-s)), True
 
     def conv(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
              dil: int = 1, out: Optional[int] = None, res: int = -1, gate_buf: int = -1, fbias_buf: int = -1,
@@ -180,14 +187,14 @@ class ProgramBuilder:
             out = self.tensor(oh, ow, _round_up(n, self.ve), name=out_name)
         to = self.tensors[out]
         assert (to.H, to.W) == (oh, ow), ((to.H, to.W), (oh, ow))
-        woff, npad, cpad, acc_scale = self.pack_conv_weight(weight)
+        woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(weight)
         b = np.zeros(npad, np.float64)
         b[:n] = bias
         boff = self.const_f32(b)
         av, ai, an = amax if amax is not None else (-1, -1, 0)
         self._op(OP_CONV, [x, out, woff, boff, res, gate_buf, fbias_buf, kh, kw, stride, pad, dil, cpad, npad, n,
                            ACT[act], out_cs, av, ai, an, 1 if store_out else 0, cfg,
-                           struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
+                           struct.unpack("<i", struct.pack("<f", acc_scale))[0], 1 if use_split else 0],
                  [self._tb(x), self._tb(res), gate_buf, fbias_buf], [self._tb(out), av, ai])
         return out
 

@@ -146,6 +146,8 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
     if debug_full_hm:
         info["hm_full"] = pb.conv(decx4, hw, hb, "none", out_name="hm")
     bm, _, warps_m = ir.CONV_CFGS[0]
+    if pb.conv_uses_split(128):
+        warps_m *= 2       # the split-precision kernels run 8 waves (2x the M-waves) per workgroup
     assert (h4 * h4) % bm == 0, "heat-map area must be a multiple of the GEMM pixel tile"
     nslots = (h4 * h4 // bm) * warps_m
     val = pb.buffer(NUM_POINTS * nslots, ir.ELEM_F32, "amax_val")
