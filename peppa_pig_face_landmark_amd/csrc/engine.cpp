@@ -200,6 +200,34 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
             case PF_OP_CONV:
                 if (launch_conv<T, SPLIT>(h, p, op, B)) return 1;
                 break;
+            case PF_OP_SEPUP: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused upsample+depthwise+pointwise op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& tl = p.tens[f[0]];
+                    const PfTensorRec& tk = p.tens[f[1]];
+                    const PfTensorRec& to = p.tens[f[2]];
+                    ConvGemmArgs a{};
+                    a.up_lo = (const float*)p.tensor_ptr(f[0]); a.up_skip = (const float*)p.tensor_ptr(f[1]);
+                    a.out = p.tensor_ptr(f[2]);
+                    a.dw_w = (const float*)p.cptr(f[3]); a.dw_b = (const float*)p.cptr(f[4]);
+                    a.wt = p.cptr(f[5]); a.bias = (const float*)p.cptr(f[6]);
+                    a.Cpad = f[7]; a.Npad = f[8]; a.N = f[9]; a.act = f[10]; memcpy(&a.acc_scale, &f[11], 4);
+                    a.loH = tl.H; a.loW = tl.W; a.C1 = tl.C; a.loLd = tl.ld; a.skipLd = tk.ld;
+                    a.B = B; a.inH = to.H; a.inW = to.W; a.inC = tl.C + tk.C; a.inLd = 0;
+                    a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1;
+                    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
+                    if (to.H != 2 * tl.H || to.W != 2 * tl.W || tk.H != to.H || tk.W != to.W || (tl.C % 32) != 0)
+                        PF_FAIL(h, "sepup: inconsistent tensor shapes");
+                    dim3 grid(pf_div_up(B * to.H * to.W, 128), pf_div_up(a.Npad, 128));
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "sepup_c%d_n%d_%dx%d", a.inC, a.N, to.H, to.W);
+                    ProfScope ps(h, tagbuf);
+                    PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 1>), grid, dim3(512), h->stream, a);
+                }
+                break;
+            }
             case PF_OP_DW: {
                 const PfTensorRec& ti = p.tens[f[0]];
                 const PfTensorRec& to = p.tens[f[1]];

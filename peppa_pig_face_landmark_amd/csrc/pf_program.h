@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 4
+#define PF_PROGRAM_VERSION 5
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -47,6 +47,8 @@ enum PfOpCode : int32_t {
     PF_OP_MAXPOOL = 9,  // f: in_t out_t            (2x2 stride 2, ceil mode)
     PF_OP_COPY = 10,    // f: in_t out_t out_cs up  (channel-strided copy, optional nearest x2 upsample)
     PF_OP_DETDEC = 11,  // f: in_t rows_buf row0 stride anchors(wt off, 6 floats) nrows_total
+    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dw_w dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits)
+                        //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };
 
 // tile configurations of conv_gemm_kernel (index = cfg field)

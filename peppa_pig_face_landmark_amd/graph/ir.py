@@ -17,14 +17,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 4
+VERSION = 5
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC = range(1, 12)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP = range(1, 13)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -217,6 +217,27 @@ class ProgramBuilder:
         assert (ts.H, ts.W) == (2 * tl.H, 2 * tl.W)
         out = self.tensor(ts.H, ts.W, tl.C + ts.C, name=out_name)
         self._op(OP_UPCAT, [lo, skip, out], [self._tb(lo), self._tb(skip)], [self._tb(out)])
+        return out
+
+    def sepconv_up(self, lo: int, skip: int, dw_weight: np.ndarray, dw_bias: np.ndarray, pw_weight: np.ndarray,
+                   pw_bias: np.ndarray, act: str, out_name: str = "") -> int:
+        """Fused DecoderBlock front end: cat(bilinear_x2(lo), skip) -> depthwise 3x3 (+bias, BN folded) ->
+        1x1 conv (+bias, BN folded) -> act, in one split-precision GEMM launch (f32s programs only)."""
+        assert self.split
+        tl, ts = self.tensors[lo], self.tensors[skip]
+        c = tl.C + ts.C
+        n, cin, kh, kw = pw_weight.shape
+        assert (ts.H, ts.W) == (2 * tl.H, 2 * tl.W) and cin == c and kh == kw == 1 and tl.C % 32 == 0
+        assert dw_weight.shape == (c, 1, 3, 3) and self.conv_uses_split(c)
+        out = self.tensor(ts.H, ts.W, _round_up(n, self.ve), name=out_name)
+        woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(pw_weight)
+        assert use_split
+        b = np.zeros(npad, np.float64)
+        b[:n] = pw_bias
+        dww = self.const_f32(np.transpose(dw_weight.astype(np.float64).reshape(c, 9), (1, 0)))
+        self._op(OP_SEPUP, [lo, skip, out, dww, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
+                 [self._tb(lo), self._tb(skip)], [self._tb(out)])
         return out
 
     def gap(self, x: int) -> int:

@@ -117,12 +117,16 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
 
     # ---- decoder blocks (model.py:133-196) -------------------------------------------------------
     def decoder_block(lo, skip, name, second, att):
-        x = pb.upcat(lo, skip, out_name=f"{name}.cat")
-        wt, b = ir.fold_bn(w[f"{name}.conv1.0.conv_dw.0.weight"], w[f"{name}.conv1.0.conv_dw.0.bias"],
-                           _bn(w, f"{name}.conv1.0.conv_dw.1"))
-        x = pb.dw(x, wt, b, "none", pad=1, out_name=f"{name}.dw")
-        wt, b = ir.fold_bn(w[f"{name}.conv1.0.conv_pw.weight"], None, _bn(w, f"{name}.conv1.1"))
-        x = pb.conv(x, wt, b, "relu", out_name=f"{name}.pw")
+        wd, bd = ir.fold_bn(w[f"{name}.conv1.0.conv_dw.0.weight"], w[f"{name}.conv1.0.conv_dw.0.bias"],
+                            _bn(w, f"{name}.conv1.0.conv_dw.1"))
+        wp, bp = ir.fold_bn(w[f"{name}.conv1.0.conv_pw.weight"], None, _bn(w, f"{name}.conv1.1"))
+        if pb.split and not keep_all:
+            # one launch: upsample + concat + depthwise + pointwise (the 280/296-channel tensors never reach HBM)
+            x = pb.sepconv_up(lo, skip, wd, bd, wp, bp, "relu", out_name=f"{name}.pw")
+        else:
+            x = pb.upcat(lo, skip, out_name=f"{name}.cat")
+            x = pb.dw(x, wd, bd, "none", pad=1, out_name=f"{name}.dw")
+            x = pb.conv(x, wp, bp, "relu", out_name=f"{name}.pw")
         if second:
             wt, b = ir.fold_bn(w[f"{name}.conv2.0.weight"], w[f"{name}.conv2.0.bias"], _bn(w, f"{name}.conv2.1"))
             x = pb.conv(x, wt, b, "relu", pad=1, out_name=f"{name}.conv2")
