@@ -210,14 +210,14 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     ConvGemmArgs a{};
                     a.up_lo = (const float*)p.tensor_ptr(f[0]); a.up_skip = (const float*)p.tensor_ptr(f[1]);
                     a.out = p.tensor_ptr(f[2]);
-                    a.dw_w = (const float*)p.cptr(f[3]); a.dw_b = (const float*)p.cptr(f[4]);
+                    a.dw_w = (const float*)p.cptr(f[3]); a.dw_b = (const float*)p.cptr(f[4]); a.dw_w2 = (const float*)p.cptr(f[12]);
                     a.wt = p.cptr(f[5]); a.bias = (const float*)p.cptr(f[6]);
                     a.Cpad = f[7]; a.Npad = f[8]; a.N = f[9]; a.act = f[10]; memcpy(&a.acc_scale, &f[11], 4);
                     a.loH = tl.H; a.loW = tl.W; a.C1 = tl.C; a.loLd = tl.ld; a.skipLd = tk.ld;
                     a.B = B; a.inH = to.H; a.inW = to.W; a.inC = tl.C + tk.C; a.inLd = 0;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
-                    if (to.H != 2 * tl.H || to.W != 2 * tl.W || tk.H != to.H || tk.W != to.W || (tl.C % 32) != 0)
+                    if (to.H != 2 * tl.H || to.W != 2 * tl.W || tk.H != to.H || tk.W != to.W || (tl.C % 32) != 0 || to.H < 6 || to.W < 6)
                         PF_FAIL(h, "sepup: inconsistent tensor shapes");
                     dim3 grid(pf_div_up(B * to.H * to.W, 128), pf_div_up(a.Npad, 128));
                     char tagbuf[96];

@@ -44,7 +44,8 @@ struct ConvGemmArgs {
     // (DecoderBlock.forward model.py:184-189 + SeparableConv2d.conv_dw :21-27), STAGE == 1 kernels only
     const float* up_lo;   // [B][loH][loW][loLd]  channels [0, C1)   -> upsampled
     const float* up_skip; // [B][2loH][2loW][skipLd] channels [C1, C1+C2)
-    const float* dw_w;    // [9][C1+C2] depthwise weights (BN folded)
+    const float* dw_w;    // [16 position classes][9][C1]: upsample (x) depthwise collapsed onto the low-res grid
+    const float* dw_w2;   // [9][C2] plain depthwise weights of the skip channels (BN folded)
     const float* dw_b;    // [C1+C2]
     int loH, loW, C1, loLd, skipLd;
 };
@@ -397,69 +398,39 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel
                 const int y = xiy0[u], x = xix0[u];           // output pixel (KS == 1: no stride / padding)
                 const int H = 2 * a.loH, W = 2 * a.loW;
                 if (xvalid[u] && kelem < a.inC) {
-                    const float* wd = a.dw_w + kelem;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = a.dw_b[kelem + e];
                     if (kelem < a.C1) {
-                        // 3x3 patch of the low-res map around (y>>1, x>>1) covers every bilinear tap of the 3x3
-                        // depthwise window; A[k][j] = weight of patch row j in (virtual) input row y-1+k
+                        // The bilinear taps of the whole 3x3 depthwise window live in the 3x3 low-res patch around
+                        // (y>>1, x>>1) (coordinates clamped), so upsample + depthwise collapse into ONE 3x3 filter
+                        // on the low-res map whose weights depend only on the position class of (y, x):
+                        // first / last / even / odd row  x  first / last / even / odd column  (16 classes,
+                        // precomputed at pack time: E = A_cls^T . Wdw . B_cls, zero padding included).
                         const int my = y >> 1, mx = x >> 1;
-                        float A[3][3], Bm[3][3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) { A[k][j] = 0.f; Bm[k][j] = 0.f; }
-                            const int yy = y - 1 + k, xx = x - 1 + k;
-                            if ((unsigned)yy < (unsigned)H) {
-                                float sy = (yy + 0.5f) * 0.5f - 0.5f; if (sy < 0.f) sy = 0.f;
-                                const int y0 = (int)sy, y1 = y0 + (y0 < a.loH - 1 ? 1 : 0);
-                                const float ly = sy - y0;
-#pragma unroll
-                                for (int j = 0; j < 3; ++j)
-                                    A[k][j] = (y0 - my + 1 == j ? 1.f - ly : 0.f) + (y1 - my + 1 == j ? ly : 0.f);
-                            }
-                            if ((unsigned)xx < (unsigned)W) {
-                                float sx = (xx + 0.5f) * 0.5f - 0.5f; if (sx < 0.f) sx = 0.f;
-                                const int x0 = (int)sx, x1 = x0 + (x0 < a.loW - 1 ? 1 : 0);
-                                const float lx = sx - x0;
-#pragma unroll
-                                for (int j = 0; j < 3; ++j)
-                                    Bm[k][j] = (x0 - mx + 1 == j ? 1.f - lx : 0.f) + (x1 - mx + 1 == j ? lx : 0.f);
-                            }
-                        }
+                        const int ycls = y == 0 ? 0 : (y == H - 1 ? 1 : 2 + (y & 1));
+                        const int xcls = x == 0 ? 0 : (x == W - 1 ? 1 : 2 + (x & 1));
+                        const float* we = a.dw_w + (size_t)((ycls * 4 + xcls) * 9) * a.C1 + kelem;
                         const float* lo = a.up_lo + (size_t)xb[u] * a.loH * a.loW * a.loLd + kelem;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            // rows of the patch, interpolated horizontally to the 3 tap columns: T[j][kx]
-                            float T[3][3][4];
+                        for (int j = 0; j < 3; ++j) {
+                            const int ry = min(max(my - 1 + j, 0), a.loH - 1);
 #pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const int ry = min(max(my - 1 + j, 0), a.loH - 1);
-                                pf_f32x4 P[3];
+                            for (int i = 0; i < 3; ++i) {
+                                const int rx = min(max(mx - 1 + i, 0), a.loW - 1);
+                                const float* pp = lo + ((size_t)ry * a.loW + rx) * a.loLd;
+                                const float* ww = we + (size_t)(j * 3 + i) * a.C1;
 #pragma unroll
-                                for (int i = 0; i < 3; ++i) {
-                                    const int rx = min(max(mx - 1 + i, 0), a.loW - 1);
-                                    P[i] = *reinterpret_cast<const pf_f32x4*>(lo + ((size_t)ry * a.loW + rx) * a.loLd + 4 * h);
+                                for (int h = 0; h < 2; ++h) {
+                                    const pf_f32x4 v4 = *reinterpret_cast<const pf_f32x4*>(pp + 4 * h);
+                                    const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(ww + 4 * h);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) o[4 * h + e] = fmaf(w4[e], v4[e], o[4 * h + e]);
                                 }
-#pragma unroll
-                                for (int k2 = 0; k2 < 3; ++k2)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        T[j][k2][e] = Bm[k2][0] * P[0][e] + Bm[k2][1] * P[1][e] + Bm[k2][2] * P[2][e];
                             }
-#pragma unroll
-                            for (int k1 = 0; k1 < 3; ++k1)
-#pragma unroll
-                                for (int k2 = 0; k2 < 3; ++k2) {
-                                    const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(wd + (size_t)(k1 * 3 + k2) * a.inC + 4 * h);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const float v = A[k1][0] * T[0][k2][e] + A[k1][1] * T[1][k2][e] + A[k1][2] * T[2][k2][e];
-                                        o[4 * h + e] = fmaf(w4[e], v, o[4 * h + e]);
-                                    }
-                                }
                         }
                     } else {
+                        const int C2 = a.inC - a.C1;
+                        const float* wd = a.dw_w2 + (kelem - a.C1);
                         const float* sk = a.up_skip + (size_t)xb[u] * H * W * a.skipLd + (kelem - a.C1);
 #pragma unroll
                         for (int k1 = 0; k1 < 3; ++k1) {
@@ -472,7 +443,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     const pf_f32x4 v4 = *reinterpret_cast<const pf_f32x4*>(sk + ((size_t)yy * W + xx) * a.skipLd + 4 * h);
-                                    const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(wd + (size_t)(k1 * 3 + k2) * a.inC + 4 * h);
+                                    const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(wd + (size_t)(k1 * 3 + k2) * C2 + 4 * h);
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) o[4 * h + e] = fmaf(w4[e], v4[e], o[4 * h + e]);
                                 }

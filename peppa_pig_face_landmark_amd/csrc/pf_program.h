@@ -47,7 +47,7 @@ enum PfOpCode : int32_t {
     PF_OP_MAXPOOL = 9,  // f: in_t out_t            (2x2 stride 2, ceil mode)
     PF_OP_COPY = 10,    // f: in_t out_t out_cs up  (channel-strided copy, optional nearest x2 upsample)
     PF_OP_DETDEC = 11,  // f: in_t rows_buf row0 stride anchors(wt off, 6 floats) nrows_total
-    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dw_w dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits)
+    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip)
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };
 

@@ -54,6 +54,24 @@ def bn_affine(bn: Dict[str, np.ndarray], eps: float = 1e-5) -> Tuple[np.ndarray,
     return s, t
 
 
+def _upsample_tap_matrix(y: int, H: int, lo_h: int) -> np.ndarray:
+    """A[k][j]: weight of low-res patch row j (rows (y>>1)-1+j, clamped) in the bilinear x2 upsampled
+    row y-1+k (torch align_corners=False, source index clamped at 0); all-zero row if y-1+k is padding."""
+    A = np.zeros((3, 3), np.float64)
+    m = y >> 1
+    for k in range(3):
+        yy = y - 1 + k
+        if yy < 0 or yy >= H:
+            continue
+        sy = max((yy + 0.5) * 0.5 - 0.5, 0.0)
+        y0 = int(sy)
+        y1 = y0 + (1 if y0 < lo_h - 1 else 0)
+        ly = sy - y0
+        A[k][y0 - m + 1] += 1.0 - ly
+        A[k][y1 - m + 1] += ly
+    return A
+
+
 class _Buf:
     __slots__ = ("etype", "elems", "first", "last", "pinned", "offset_units", "name")
 
@@ -234,9 +252,22 @@ class ProgramBuilder:
         assert use_split
         b = np.zeros(npad, np.float64)
         b[:n] = pw_bias
-        dww = self.const_f32(np.transpose(dw_weight.astype(np.float64).reshape(c, 9), (1, 0)))
-        self._op(OP_SEPUP, [lo, skip, out, dww, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
-                            struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
+        wdw = dw_weight.astype(np.float64).reshape(c, 3, 3)
+        c1 = tl.C
+        assert ts.H >= 6 and ts.W >= 6
+        # upsample (bilinear x2, align_corners=False) followed by the zero-padded depthwise 3x3 == one 3x3
+        # filter on the low-res map with position-class dependent weights  E = A^T . W . B
+        ay = [_upsample_tap_matrix(y, ts.H, tl.H) for y in (0, ts.H - 1, 2, 3)]   # classes first/last/even/odd
+        ax = [_upsample_tap_matrix(x, ts.W, tl.W) for x in (0, ts.W - 1, 2, 3)]
+        E = np.zeros((4, 4, 3, 3, c1), np.float64)
+        for cy in range(4):
+            for cx in range(4):
+                # E[j,i,c] = sum_ky sum_kx A[ky,j] * B[kx,i] * W[c,ky,kx]
+                E[cy, cx] = np.einsum("kj,li,ckl->jic", ay[cy], ax[cx], wdw[:c1])
+        dwe = self.const_f32(E.reshape(16 * 9, c1))
+        dws = self.const_f32(np.transpose(wdw[c1:].reshape(c - c1, 9), (1, 0)))
+        self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws],
                  [self._tb(lo), self._tb(skip)], [self._tb(out)])
         return out
 
