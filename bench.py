@@ -88,7 +88,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -99,7 +100,7 @@ def main():
 
     if rank == 0:
         pbuild.build_hip()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     eng = Engine(local_rank)
 
@@ -111,7 +112,7 @@ def main():
     t0 = time.time()
     blobs = bs.build_programs(workload, args.dtype) if rank == 0 else None
     bcast_ms = 0.0
-    if world > 1:
+    if use_dist:
         blobs, bcast_ms = bs.broadcast_blobs(blobs, dev, rank)
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
     bs.load_programs(eng, blobs, workload, faces_per_step, args.frames)
@@ -124,7 +125,7 @@ def main():
         state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -136,7 +137,7 @@ def main():
         state.step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -194,7 +195,7 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(workload, args.cpu_faces)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -150,3 +150,26 @@ def test_faceana_facade(hip_library, student_weights, detector_weights, frame108
     facer.reset()
     assert facer.track_box is None and facer.previous_image is None
     facer.engine.close()
+
+
+def test_config1_plumbing_student128_single_face(hip_library, student_weights, detector_weights):
+    """BASELINE configs[0]: one 1080p frame, one face, Student@128 through FaceAna.run()
+    (Keypoints.input_shape is honoured exactly like face_landmark.py:29,97-98)."""
+    from Skps import FaceAna
+    from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+    cfg = get_cfg()
+    cfg["Skps"]["Keypoints"]["input_shape"] = [128, 128, 3]
+    facer = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=hip_library)
+    frame, boxes = make_frame(1080, 1920, 1, seed=5)
+    # the detector has random weights, so drive the landmark stage with the known box (plumbing check)
+    lm, states = facer.face_landmark(frame, boxes)
+    assert lm.shape == (1, 98, 2) and states.shape == (1, 98)
+    ci = pp.landmark_crop_box(boxes[0], 1080, 1920)
+    crop = pp.landmark_crop(frame, ci, (128, 128))
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
+    ref = pp.landmark_backproject(oloc[0], ci)
+    safe = helpers.heat_margins(taps)[0] > 2e-3
+    assert np.abs(lm[0] - ref)[safe].max() < 1e-3 * max(ci.w_crop, ci.h_crop)
+    res = facer.run(frame)
+    assert isinstance(res, list)
+    facer.engine.close()
