@@ -49,11 +49,20 @@ class _StudentEncoderStub(nn.Module):
 
 
 class _TeacherEncoderStub(nn.Module):
+    """Stands in for timm hrnet_w18 features (model.py:306-311).  With ``weights`` set it runs the
+    oracle's restated HRNet-W18; otherwise a cheap shape-compatible dummy (the teacher's output is
+    discarded when ``inference='student'``)."""
+
     def __init__(self):
         super().__init__()
         self.convs = nn.ModuleList([nn.Conv2d(3, c, 1) for c in (64, 128, 256, 512)])
+        self.weights: Dict[str, torch.Tensor] = {}
 
     def forward(self, x):
+        if self.weights:
+            from . import teacher_net as tn
+
+            return tn.encoder_forward(self.weights, x)
         outs = []
         for i, c in enumerate(self.convs):
             s = 2 << i
@@ -85,9 +94,10 @@ def _install_stubs():
         sys.modules["torchvision.models.mobilenetv3"] = tvmm
 
 
-def load_reference_cotrain(weights_np: Dict[str, np.ndarray]):
-    """Instantiate the reference's ``COTRAIN(inference='student')`` and load ``weights_np``
-    (keys relative to ``student.``) into it.  Returns the nn.Module in eval mode."""
+def load_reference_cotrain(weights_np: Dict[str, np.ndarray], teacher_np: Dict[str, np.ndarray] = None,
+                           inference: str = "student"):
+    """Instantiate the reference's ``COTRAIN(inference=...)`` and load ``weights_np`` (keys relative to
+    ``student.``) and optionally ``teacher_np`` (keys relative to ``teacher.``) into it."""
     assert available(), "reference checkout not present"
     sys.dont_write_bytecode = True
     _install_stubs()
@@ -96,7 +106,7 @@ def load_reference_cotrain(weights_np: Dict[str, np.ndarray]):
     from lib.core.base_trainer.model import COTRAIN  # the reference's own class
 
     torch.manual_seed(0)
-    model = COTRAIN(inference="student", inp_size=(256, 256))
+    model = COTRAIN(inference=inference, inp_size=(256, 256))
     model.eval()
     sd = model.state_dict()
     own = {k: torch.from_numpy(v) for k, v in weights_np.items()}
@@ -119,6 +129,17 @@ def load_reference_cotrain(weights_np: Dict[str, np.ndarray]):
                  and not k.endswith("num_batches_tracked") and not k.startswith("student.encoder.")}
     own_names = {k for k in own if not k.startswith("encoder.")}
     assert ref_names == own_names, (sorted(ref_names ^ own_names))
+    if teacher_np is not None:
+        town = {k: torch.from_numpy(v) for k, v in teacher_np.items()}
+        sd = model.state_dict()
+        for k in list(sd.keys()):
+            if not k.startswith("teacher.") or k.startswith("teacher.encoder.") or k.endswith("num_batches_tracked"):
+                continue
+            rel = k[len("teacher."):]
+            assert rel in town and tuple(sd[k].shape) == tuple(town[rel].shape), rel
+            sd[k] = town[rel].clone()
+        model.load_state_dict(sd)
+        model.teacher.encoder.weights = {k: v for k, v in town.items() if k.startswith("encoder.")}
     return model
 
 

@@ -126,3 +126,30 @@ def detector_weights(seed: int = SEED + 7, cache: bool = True) -> Dict[str, np.n
     if cache:
         np.savez(path, **w)
     return w
+
+
+def teacher_weights(seed: int = SEED + 13, cache: bool = True) -> Dict[str, np.ndarray]:
+    """Synthetic weights for ``COTRAIN.teacher`` (HRNet-W18 encoder + decoder + hm head)."""
+    from . import landmark_net as ln
+    from . import teacher_net as tn
+
+    path = os.path.join(_cache_dir(), f"teacher_{seed}.npz")
+    if cache and os.path.exists(path):
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+    w = draw_inventory(tn.param_inventory(), seed)
+    calib = smooth_blob_images(4, 128, seed=seed + 1).astype(np.float32) / 255.0
+    calib_t = torch.from_numpy(calib).permute(0, 3, 1, 2).contiguous()
+    W = {k: torch.from_numpy(v).double() for k, v in w.items()}
+    ln._CALIBRATING = []
+    tn._CALIBRATING = []
+    try:
+        with torch.no_grad():
+            tn.teacher_forward(W, calib_t.double())
+    finally:
+        ln._CALIBRATING = None
+        tn._CALIBRATING = None
+    w = {k: v.float().numpy().copy() for k, v in W.items()}
+    if cache:
+        np.savez(path, **w)
+    return w

@@ -119,6 +119,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     a.amax_idx = f[18] >= 0 ? (int*)p.buf_ptr(f[18]) : nullptr;
     a.B = B; a.inH = ti.H; a.inW = ti.W; a.inC = ti.C; a.inLd = ti.ld;
     a.outH = to.H; a.outW = to.W; a.N = f[14]; a.Npad = f[13]; a.outLd = to.ld; a.outCs = f[16];
+    a.outCpad = f[16] == 1 ? to.C : f[14];
     a.KH = f[7]; a.KW = f[8]; a.stride = f[9]; a.pad = f[10]; a.dil = f[11]; a.Cpad = f[12];
     a.act = f[15]; a.amaxN = f[19]; a.store_out = f[20];
     memcpy(&a.acc_scale, &f[22], 4);
@@ -192,9 +193,10 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.bias = (const float*)p.cptr(f[3]);
                 a.out = p.tensor_ptr(f[1]);
                 a.B = B; a.inH = p.hdr.in_h; a.inW = p.hdr.in_w;
-                a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.act = f[4];
+                a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.act = f[4]; a.CO = to.C;
+                if (to.C % 16) PF_FAIL(h, "stem conv needs a multiple of 16 output channels, got %d", to.C);
                 ProfScope ps(h, "stem_conv");
-                PF_LAUNCH((stem_conv_kernel<T>), dim3(pf_div_up(B * to.H * to.W, 256)), dim3(256), h->stream, a);
+                PF_LAUNCH((stem_conv_kernel<T>), dim3(pf_div_up(B * to.H * to.W, 256), to.C / 16), dim3(256), h->stream, a);
                 break;
             }
             case PF_OP_CONV:
@@ -215,7 +217,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.Cpad = f[7]; a.Npad = f[8]; a.N = f[9]; a.act = f[10]; memcpy(&a.acc_scale, &f[11], 4);
                     a.loH = tl.H; a.loW = tl.W; a.C1 = tl.C; a.loLd = tl.ld; a.skipLd = tk.ld;
                     a.B = B; a.inH = to.H; a.inW = to.W; a.inC = tl.C + tk.C; a.inLd = 0;
-                    a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1;
+                    a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
                     if (to.H != 2 * tl.H || to.W != 2 * tl.W || tk.H != to.H || tk.W != to.W || (tl.C % 32) != 0 || to.H < 6 || to.W < 6)
                         PF_FAIL(h, "sepup: inconsistent tensor shapes");
@@ -314,6 +316,21 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.H = tf.H; a.W = tf.W; a.C = tf.C; a.featLd = tf.ld;
                 ProfScope ps(h, "hm_decode");
                 PF_LAUNCH((hm_decode_kernel<T>), dim3(pf_div_up(B * a.P, 4)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_ADDUP: {
+                const PfTensorRec& ta = p.tens[f[0]];
+                const PfTensorRec& tb = p.tens[f[1]];
+                const PfTensorRec& to = p.tens[f[2]];
+                AddUpArgs a{};
+                a.a = p.tensor_ptr(f[0]); a.b = p.tensor_ptr(f[1]); a.out = p.tensor_ptr(f[2]);
+                a.B = B; a.H = ta.H; a.W = ta.W; a.C = ta.C; a.aLd = ta.ld; a.bLd = tb.ld; a.outLd = to.ld;
+                a.shift = f[3]; a.act = f[4];
+                if ((tb.H << a.shift) != ta.H || (tb.W << a.shift) != ta.W || tb.C != ta.C || to.C != ta.C)
+                    PF_FAIL(h, "addup: inconsistent shapes");
+                const long long total = (long long)B * ta.H * ta.W * (ta.C / VE);
+                ProfScope ps(h, "add_upsample");
+                PF_LAUNCH((add_upsample_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
                 break;
             }
             case PF_OP_MAXPOOL: {

@@ -34,6 +34,7 @@ struct ConvGemmArgs {
     int* amax_idx;
     int B, inH, inW, inC, inLd;
     int outH, outW, N, Npad, outLd, outCs;  // channel n is stored at element n*outCs of the pixel row
+    int outCpad;          // channels [N, outCpad) of the output view are written as zeros (vector padding)
     int resLd;
     int KH, KW, stride, pad, dil, Cpad;
     int act;
@@ -133,8 +134,10 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                    for (int r = 0; r < 4; ++r) {
                         if (n + r < a.N) o[(size_t)(n + r) * a.outCs] = (T)v[r];
+                        else if (n + r < a.outCpad) o[(size_t)(n + r) * a.outCs] = (T)0.f;
+                    }
                 }
             }
         }

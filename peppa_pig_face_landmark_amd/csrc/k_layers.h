@@ -17,11 +17,11 @@
 // --------------------------------------------------------------------------------------------
 struct StemArgs {
     const void* in;       // u8 [B][H][W][3]  or  f32 [B][3][H][W]
-    const float* wt;      // [27][16] f32, index (ky*3+kx)*3+ci ; 1/255 folded for u8 input
-    const float* bias;    // [16]
-    void* out;            // T [B][outH][outW][16]
+    const float* wt;      // [27][CO] f32, index ((ky*3+kx)*3+ci)*CO + co ; 1/255 folded for u8 input
+    const float* bias;    // [CO]
+    void* out;            // T [B][outH][outW][CO]   (CO = 16 * gridDim.y: one 16-channel group per blockIdx.y)
     int in_f32_nchw;
-    int B, inH, inW, outH, outW, outLd, act;
+    int B, inH, inW, outH, outW, outLd, act, CO;
 };
 
 template <typename T>
@@ -33,9 +33,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
     const int b = idx / (a.outH * a.outW);
     const int rem = idx - b * a.outH * a.outW;
     const int oy = rem / a.outW, ox = rem - oy * a.outW;
+    const int g0 = blockIdx.y * CO;   // first output channel of this workgroup's 16-channel group (wave-uniform)
     float acc[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = a.bias[c];
+    for (int c = 0; c < CO; ++c) acc[c] = a.bias[g0 + c];
     const unsigned char* in8 = static_cast<const unsigned char*>(a.in);
     const float* inf = static_cast<const float*>(a.in);
     const size_t plane = (size_t)a.inH * a.inW;
@@ -55,14 +56,14 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
                 const size_t o = ((size_t)b * plane + (size_t)iy * a.inW + ix) * 3;
                 px[0] = (float)in8[o]; px[1] = (float)in8[o + 1]; px[2] = (float)in8[o + 2];
             }
-            const float* w = a.wt + ((ky * 3 + kx) * 3) * CO;
+            const float* w = a.wt + ((ky * 3 + kx) * 3) * a.CO + g0;
 #pragma unroll
             for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-                for (int c = 0; c < CO; ++c) acc[c] = fmaf(px[ci], w[ci * CO + c], acc[c]);
+                for (int c = 0; c < CO; ++c) acc[c] = fmaf(px[ci], w[ci * a.CO + c], acc[c]);
         }
     }
-    T* o = static_cast<T*>(a.out) + (size_t)idx * a.outLd;
+    T* o = static_cast<T*>(a.out) + (size_t)idx * a.outLd + g0;
     constexpr int VE = PfVec<T>::N;
 #pragma unroll
     for (int v = 0; v < CO / VE; ++v) {
@@ -552,4 +553,37 @@ __global__ __launch_bounds__(256) void dw_conv_tiled_kernel(DwArgs a) {
             pf_stv<T>(out + (size_t)(ox0 + j) * a.outLd, o);
         }
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// HRNet fuse layers (timm HighResolutionModule.forward, Teacher encoder model.py:306-311):
+// out = act(a + nearest_upsample(b, 2^shift)), 16-byte channel vectors.
+struct AddUpArgs {
+    const void* a;   // T [B][H][W][aLd]
+    const void* b;   // T [B][H>>shift][W>>shift][bLd]
+    void* out;       // T [B][H][W][outLd]
+    int B, H, W, C, aLd, bLd, outLd, shift, act;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
+    typedef typename PfVec<T>::type vec_t;
+    constexpr int VE = PfVec<T>::N;
+    const int CV = a.C / VE;
+    const long long total = (long long)a.B * a.H * a.W * CV;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int cv = (int)(idx % CV);
+    const long long pix = idx / CV;
+    const int x = (int)(pix % a.W);
+    const long long t2 = pix / a.W;
+    const int y = (int)(t2 % a.H);
+    const int b = (int)(t2 / a.H);
+    const int lh = a.H >> a.shift, lw = a.W >> a.shift;
+    const vec_t va = pf_ldv<T>(static_cast<const T*>(a.a) + (size_t)pix * a.aLd + cv * VE);
+    const vec_t vb = pf_ldv<T>(static_cast<const T*>(a.b) + ((size_t)(b * lh + (y >> a.shift)) * lw + (x >> a.shift)) * a.bLd + cv * VE);
+    vec_t o;
+#pragma unroll
+    for (int e = 0; e < VE; ++e) o[e] = (T)pf_act((float)va[e] + (float)vb[e], a.act);
+    pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
 }

@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP = range(1, 13)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP = range(1, 14)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -77,7 +77,8 @@ class _Buf:
 
 
 class _Tensor:
-    __slots__ = ("buf", "coff", "ld", "H", "W", "C", "name")
+    # C = stored channels (multiple of the 16-byte vector); real_c = meaningful channels (the rest are zeros)
+    __slots__ = ("buf", "coff", "ld", "H", "W", "C", "name", "real_c")
 
 
 class ProgramBuilder:
@@ -112,7 +113,7 @@ class ProgramBuilder:
             buf = self.buffer(H * W * ld, ELEM_ACT, name)
         assert ld is not None and coff % self.ve == 0 and ld % self.ve == 0
         t = _Tensor()
-        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name = buf, coff, ld, H, W, C, name
+        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name, t.real_c = buf, coff, ld, H, W, C, name, C
         self.tensors.append(t)
         tid = len(self.tensors) - 1
         if name:
@@ -126,7 +127,7 @@ class ProgramBuilder:
         """Write-only target for channel-interleaved stores (channel n lands at coff + n*cs): no
         vector-alignment requirement because those stores are scalar."""
         t = _Tensor()
-        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name = base_buf, coff, ld, H, W, C, ""
+        t.buf, t.coff, t.ld, t.H, t.W, t.C, t.name, t.real_c = base_buf, coff, ld, H, W, C, "", C
         self.tensors.append(t)
         return len(self.tensors) - 1
 
@@ -155,11 +156,12 @@ class ProgramBuilder:
 
     # ---- ops --------------------------------------------------------------------------------
     def stem(self, weight: np.ndarray, bias: np.ndarray, act: str, out_name: str = "") -> int:
-        """3x3 stride-2 pad-1 conv on the 3-channel program input; weight [16,3,3,3] (BN folded)."""
-        assert weight.shape == (16, 3, 3, 3)
+        """3x3 stride-2 pad-1 conv on the 3-channel program input; weight [CO,3,3,3] (BN folded), CO % 16 == 0."""
+        co = weight.shape[0]
+        assert weight.shape == (co, 3, 3, 3) and co % 16 == 0
         oh, ow = (self.in_h + 1) // 2, (self.in_w + 1) // 2
-        out = self.tensor(oh, ow, 16, name=out_name)
-        w = np.transpose(weight.astype(np.float64), (2, 3, 1, 0)).reshape(27, 16)  # [(ky,kx,ci)][co]
+        out = self.tensor(oh, ow, co, name=out_name)
+        w = np.transpose(weight.astype(np.float64), (2, 3, 1, 0)).reshape(27, co)  # [(ky,kx,ci)][co]
         off_u8 = self.const_f32(w / 255.0)
         off_f32 = self.const_f32(w)
         off_b = self.const_f32(bias)
@@ -198,11 +200,12 @@ class ProgramBuilder:
         """Dense conv as MFMA implicit GEMM.  weight [N,Cin,KH,KW] float (already BN-folded)."""
         ti = self.tensors[x]
         n, cin, kh, kw = weight.shape
-        assert cin == ti.C, (cin, ti.C)
+        assert cin == ti.real_c, (cin, ti.real_c)
         oh = (ti.H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
         ow = (ti.W + 2 * pad - dil * (kw - 1) - 1) // stride + 1
         if out is None:
             out = self.tensor(oh, ow, _round_up(n, self.ve), name=out_name)
+            self.tensors[out].real_c = n          # channels [n, C) are written as zeros by the epilogue
         to = self.tensors[out]
         assert (to.H, to.W) == (oh, ow), ((to.H, to.W), (oh, ow))
         woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(weight)
@@ -269,6 +272,15 @@ class ProgramBuilder:
         self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
                             struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws],
                  [self._tb(lo), self._tb(skip)], [self._tb(out)])
+        return out
+
+    def add_up(self, a: int, b: int, shift: int, act: str, out_name: str = "") -> int:
+        """out = act(a + nearest_upsample(b, 2**shift)) (HRNet fuse layers)."""
+        ta, tb = self.tensors[a], self.tensors[b]
+        assert (tb.H << shift, tb.W << shift, tb.C) == (ta.H, ta.W, ta.C)
+        out = self.tensor(ta.H, ta.W, ta.C, name=out_name)
+        self.tensors[out].real_c = ta.real_c
+        self._op(OP_ADDUP, [a, b, out, shift, ACT[act]], [self._tb(a), self._tb(b)], [self._tb(out)])
         return out
 
     def gap(self, x: int) -> int:

@@ -47,57 +47,12 @@ def _bn(w: Dict[str, np.ndarray], prefix: str) -> Dict[str, np.ndarray]:
     return {k: w[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
 
 
-def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
-                          keep_all: bool = False, debug_full_hm: bool = False):
-    """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
-    ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
-    assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
-    w = weights
-    pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
-
-    # ---- encoder (timm MobileNetV3Features; output_stride 16 => stage 5 runs dilated) ---------
-    wt, b = ir.fold_bn(w["encoder.conv_stem.weight"], None, _bn(w, "encoder.bn1"))
-    x = pb.stem(wt, b, "hswish", out_name="encoder.stem")
-    cin, cur_stride, cur_dil = 16, 2, 1
-    feats = {}
-    for si, stack in enumerate(_STAGES):
-        for bi, (kind, k, s, e, cout, se, act) in enumerate(stack):
-            if bi >= 1:
-                s = 1
-            next_dil = cur_dil
-            if s > 1:
-                if cur_stride * s > 16:
-                    next_dil, s = cur_dil * s, 1
-                else:
-                    cur_stride *= s
-            pad = ((s - 1) + cur_dil * (k - 1)) // 2
-            p = f"encoder.blocks.{si}.{bi}"
-            inp = x
-            skip = (s == 1 and cin == cout)
-            if kind == "ds":
-                wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn1"))
-                x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
-                wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
-                x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
-            else:
-                wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
-                x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")
-                wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
-                x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
-                gate = -1
-                if se:
-                    pooled = pb.gap(x)
-                    rd = w[f"{p}.se.conv_reduce.weight"]
-                    ex = w[f"{p}.se.conv_expand.weight"]
-                    hid = pb.fc(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu")
-                    gate = pb.fc(hid, ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
-                wt, b = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
-                x = pb.conv(x, wt, b, "none", res=inp if skip else -1, gate_buf=gate, out_name=f"{p}.out")
-            cur_dil = next_dil
-            cin = cout
-        feats[si] = x
-    encx4, encx8, encx16 = feats[1], feats[2], feats[5]
+def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], encx4: int, encx8: int, encx16: int,
+                           input_size: int, keep_all: bool, debug_full_hm: bool):
+    """Decoder (ASPP + two DecoderBlocks, model.py:212-244) + hm head + fused decode; shared by the
+    Student (mobilenetv3 features 24/40/160 ch) and the Teacher (hrnet_w18 features 128/256/512 ch)."""
     h16 = input_size // 16
+    c16 = pb.tensors[encx16].C
 
     # ---- ASPP (model.py:64-96) ----------------------------------------------------------------
     a = "decoder.aspp"
@@ -161,6 +116,59 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
     pb.conv(decx4, hw[:NUM_POINTS], hb[:NUM_POINTS], "none", out=dummy, amax=(val, idx, NUM_POINTS),
             store_out=False, cfg=0)
     loc, score = pb.hmdec(val, idx, decx4, hw[NUM_POINTS:, :, 0, 0], hb[NUM_POINTS:], NUM_POINTS, nslots)
+    return loc, score, info
+
+
+def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
+                          keep_all: bool = False, debug_full_hm: bool = False):
+    """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
+    ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
+    assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
+    w = weights
+    pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
+
+    # ---- encoder (timm MobileNetV3Features; output_stride 16 => stage 5 runs dilated) ---------
+    wt, b = ir.fold_bn(w["encoder.conv_stem.weight"], None, _bn(w, "encoder.bn1"))
+    x = pb.stem(wt, b, "hswish", out_name="encoder.stem")
+    cin, cur_stride, cur_dil = 16, 2, 1
+    feats = {}
+    for si, stack in enumerate(_STAGES):
+        for bi, (kind, k, s, e, cout, se, act) in enumerate(stack):
+            if bi >= 1:
+                s = 1
+            next_dil = cur_dil
+            if s > 1:
+                if cur_stride * s > 16:
+                    next_dil, s = cur_dil * s, 1
+                else:
+                    cur_stride *= s
+            pad = ((s - 1) + cur_dil * (k - 1)) // 2
+            p = f"encoder.blocks.{si}.{bi}"
+            inp = x
+            skip = (s == 1 and cin == cout)
+            if kind == "ds":
+                wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn1"))
+                x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
+                wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
+                x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
+            else:
+                wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
+                x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")
+                wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
+                x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
+                gate = -1
+                if se:
+                    pooled = pb.gap(x)
+                    rd = w[f"{p}.se.conv_reduce.weight"]
+                    ex = w[f"{p}.se.conv_expand.weight"]
+                    hid = pb.fc(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu")
+                    gate = pb.fc(hid, ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
+                wt, b = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
+                x = pb.conv(x, wt, b, "none", res=inp if skip else -1, gate_buf=gate, out_name=f"{p}.out")
+            cur_dil = next_dil
+            cin = cout
+        feats[si] = x
+    loc, score, info = build_decoder_and_head(pb, w, feats[1], feats[2], feats[5], input_size, keep_all, debug_full_hm)
     blob = pb.finish([loc, score])
     info.update({"tensors": dict(pb.tensor_names), "input_size": input_size, "dtype": dtype,
                  "n_ops": len(pb.ops), "const_bytes": len(pb.consts)})

@@ -1,0 +1,101 @@
+"""Teacher landmark regressor (HRNet-W18 encoder) -> packed HIP program.
+
+Graph source: ``TeacherNet`` (TRAIN/face_landmark/lib/core/base_trainer/model.py:302-345): timm
+``hrnet_w18`` features (out_indices [0,1,2,3], model.py:306-311) + the shared ``Decoder`` / ``hm`` head /
+``postp`` (see ``graph/student.py::build_decoder_and_head``).  BASELINE config 5.
+
+HRNet-W18 (timm 0.6.11 ``HighResolutionNetFeatures``, feature_location='incre'; not vendored in the
+reference, restated): stem 3x3 s2 (feature /2) -> 3x3 s2 -> layer1 (4 Bottlenecks) -> 3 multi-branch
+stages (18/36/72/144 channels at /4../32) with fuse layers -> one Bottleneck "incre" head per branch
+(128/256/512 channels at /4,/8,/16; the /32 head is not requested and never built).
+``weights``: ``{name: ndarray}`` with ``COTRAIN.teacher`` state_dict names.
+
+Channel counts that are not a multiple of the 16-byte vector (18 -> 20 f32 / 24 f16) are padded; the conv
+epilogue writes the padding as zeros so downstream vector kernels stay exact.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import numpy as np
+
+from . import ir
+from .student import build_decoder_and_head
+
+BRANCH_CH = [18, 36, 72, 144]
+STAGES = [(2, 1, 2), (3, 4, 3), (4, 3, 4)]  # (stage index, modules, branches)
+
+
+def _bn(w, prefix):
+    return {k: w[f"{prefix}.{k}"] for k in ("weight", "bias", "running_mean", "running_var")}
+
+
+def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f32s",
+                          keep_all: bool = False, debug_full_hm: bool = False):
+    assert input_size % 64 == 0
+    w = weights
+    pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
+
+    def cb(x, pc, pbn, act, stride=1, res=-1, name=""):
+        wt, b = ir.fold_bn(w[f"{pc}.weight"], None, _bn(w, pbn))
+        k = wt.shape[-1]
+        return pb.conv(x, wt, b, act, stride=stride, pad=k // 2, res=res, out_name=name)
+
+    def basic(x, p):
+        y = cb(x, f"{p}.conv1", f"{p}.bn1", "relu")
+        return cb(y, f"{p}.conv2", f"{p}.bn2", "relu", res=x)          # relu(bn2(conv2) + x)
+
+    def bottleneck(x, p, name=""):
+        sc = cb(x, f"{p}.downsample.0", f"{p}.downsample.1", "none") if f"{p}.downsample.0.weight" in w else x
+        y = cb(x, f"{p}.conv1", f"{p}.bn1", "relu")
+        y = cb(y, f"{p}.conv2", f"{p}.bn2", "relu")
+        return cb(y, f"{p}.conv3", f"{p}.bn3", "relu", res=sc, name=name)
+
+    e = "encoder"
+    wt, b = ir.fold_bn(w[f"{e}.conv1.weight"], None, _bn(w, f"{e}.bn1"))
+    f0 = pb.stem(wt, b, "relu", out_name="encoder.stem")   # 3 -> 64, 3x3 stride 2 (feature /2, unused by the decoder)
+    x = cb(f0, f"{e}.conv2", f"{e}.bn2", "relu", stride=2)
+    for blk in range(4):
+        x = bottleneck(x, f"{e}.layer1.{blk}", name="encoder.layer1" if blk == 3 else "")
+    xs: List[int] = [cb(x, f"{e}.transition1.0.0", f"{e}.transition1.0.1", "relu"),
+                     cb(x, f"{e}.transition1.1.0.0", f"{e}.transition1.1.0.1", "relu", stride=2)]
+    for si, modules, nb in STAGES:
+        if si > 2:
+            xs = xs + [cb(xs[-1], f"{e}.transition{si - 1}.{nb - 1}.0.0", f"{e}.transition{si - 1}.{nb - 1}.0.1", "relu", stride=2)]
+        for m in range(modules):
+            p = f"{e}.stage{si}.{m}"
+            for br in range(nb):
+                for blk in range(4):
+                    xs[br] = basic(xs[br], f"{p}.branches.{br}.{blk}")
+            fused = []
+            for i in range(nb):
+                last_stage_module = (m == modules - 1)
+                name = f"encoder.stage{si}.branch{i}" if last_stage_module else ""
+                down = [j for j in range(nb) if j < i]
+                up = [j for j in range(nb) if j > i]
+                y = xs[i]
+                n_terms = len(down) + len(up)
+                done = 0
+                for j in down:     # strided 3x3 chains; the last conv of each chain accumulates into y
+                    t = xs[j]
+                    for k in range(i - j):
+                        lastc = k == i - j - 1
+                        done += 1 if lastc else 0
+                        final = lastc and done == n_terms
+                        t = cb(t, f"{p}.fuse_layers.{i}.{j}.{k}.0", f"{p}.fuse_layers.{i}.{j}.{k}.1",
+                               ("relu" if final else "none") if lastc else "relu", stride=2, res=y if lastc else -1,
+                               name=name if final else "")
+                    y = t
+                for j in up:       # 1x1 conv at low resolution, nearest upsample, add
+                    t = cb(xs[j], f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", "none")
+                    done += 1
+                    final = done == n_terms
+                    y = pb.add_up(y, t, j - i, "relu" if final else "none", out_name=name if final else "")
+                fused.append(y)
+            xs = fused
+    feats = [bottleneck(xs[i], f"{e}.incre_modules.{i}.0", name=f"encoder.incre{i}") for i in range(3)]
+    loc, score, info = build_decoder_and_head(pb, w, feats[0], feats[1], feats[2], input_size, keep_all, debug_full_hm)
+    blob = pb.finish([loc, score])
+    info.update({"tensors": dict(pb.tensor_names), "input_size": input_size, "dtype": dtype,
+                 "n_ops": len(pb.ops), "const_bytes": len(pb.consts)})
+    return blob, info

@@ -120,3 +120,38 @@ def test_student_f16_fast_mode(gpu_engine, student_weights):
     assert corr > 0.98
     if safe.any():
         assert d[safe].max() < 4 * hm_err / 64 + 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_teacher_256_matches_oracle(gpu_engine, dtype):
+    """BASELINE config 5 model: Teacher@256 (HRNet-W18 encoder, model.py:302-345) vs the oracle."""
+    import torch
+    from oracle import landmark_net as ln
+    from oracle import teacher_net as tn
+    from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program
+    weights = sw.teacher_weights()
+    size, batch = 256, 3
+    blob, info = build_teacher_program(weights, size, dtype, keep_all=True, debug_full_hm=True)
+    gpu_engine.load_program(0, blob, batch)
+    crops = sw.smooth_blob_images(batch, size, seed=77)
+    loc, score = gpu_engine.landmark_forward(crops)
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    taps = {}
+    with torch.no_grad():
+        oloc, oscore = tn.teacher_forward(ln.to_torch(weights), x, taps)
+    worst = ("", 0.0)
+    for name in info["tensors"]:
+        if name in taps and taps[name].dtype.is_floating_point:
+            ref = helpers.tap_nhwc(taps, name)
+            got = helpers.read_engine_tensor(gpu_engine, 0, info, name, batch, ref.shape[1:], 4)
+            rel = float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-12))
+            worst = max(worst, (name, rel), key=lambda t: t[1])
+    assert worst[1] < 1e-3, worst
+    safe = helpers.heat_margins(taps) > 2e-3
+    d = np.abs(loc - oloc.numpy()).reshape(batch, 98, 2).max(2)
+    assert d[safe].max() < 2e-4 < LANDMARK_TOL
+    # production build (arena reuse, fused head / decoder front end) gives the same landmarks
+    blob, _ = build_teacher_program(weights, size, dtype)
+    gpu_engine.load_program(0, blob, batch)
+    loc2, _ = gpu_engine.landmark_forward(crops)
+    assert np.abs(loc2 - oloc.numpy()).reshape(batch, 98, 2).max(2)[safe].max() < 2e-4
