@@ -89,10 +89,22 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    dev = torch.device("cuda", local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on
+        # stdout, so stdout is pointed at stderr while the communicator comes up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.all_reduce(torch.zeros(1, device=dev))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     from peppa_pig_face_landmark_amd import build as pbuild
     from peppa_pig_face_landmark_amd._native import Engine, PF_INPUT_U8_NHWC
