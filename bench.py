@@ -44,7 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "landmark", "pipeline"])
     ap.add_argument("--batch", type=int, default=256, help="faces per step per GPU (landmark workload)")
-    ap.add_argument("--frames", type=int, default=32, help="1080p frames per step per GPU (pipeline workload)")
+    ap.add_argument("--frames", type=int, default=64, help="1080p frames per step per GPU (pipeline workload)")
+    ap.add_argument("--lanes", type=int, default=2, help="concurrent HIP streams (engines) per GPU sharing a step's frames")
     ap.add_argument("--faces-per-frame", type=int, default=8)
     ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
                     help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
@@ -127,14 +128,21 @@ def main():
     if use_dist:
         blobs, bcast_ms = bs.broadcast_blobs(blobs, dev, rank)
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
-    bs.load_programs(eng, blobs, workload, faces_per_step, args.frames)
+    lanes = args.lanes if workload == "pipeline" else 1
+    if lanes == 1:
+        bs.load_programs(eng, blobs, workload, faces_per_step, args.frames)
     setup_s = time.time() - t0
 
     # ---- synthetic inputs, resident in HBM ----------------------------------------------------------
     if workload == "landmark":
         state = bs.LandmarkWorkload(eng, dev, args.batch, seed=1234 + rank)
-    else:
+    elif lanes == 1:
         state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank)
+    else:
+        eng.close()
+        state = bs.MultiLanePipeline(lambda: Engine(local_rank), blobs, dev, args.frames, args.faces_per_frame,
+                                     seed=7 + rank, lanes=lanes)
+        eng = state.lanes[0].eng
 
     def barrier():
         if use_dist:
@@ -159,6 +167,7 @@ def main():
     # ---- per-kernel device time (HIP events on the engine's own stream), dominant kernel roofline ---
     prof = state.profile(3)
     hero_ms, hero_n = prof.get(HERO_TAG, (0.0, 0))
+    faces_per_launch = faces_per_step // lanes      # the profiled lane processes 1/lanes of the step
     roofline = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
@@ -167,14 +176,15 @@ def main():
         # separate runs, gfx950 FETCH correction applied), scaled to this run's faces per launch
         with open(pmc_path) as f:
             pmc = json.load(f)
-        traffic = int(pmc["traffic_bytes_per_launch"] * faces_per_step / pmc["faces_per_launch"])
+        traffic = int(pmc["traffic_bytes_per_launch"] * (faces_per_step // (args.lanes if workload == "pipeline" else 1)) / pmc["faces_per_launch"])
     if hero_n:
         avg_ms = hero_ms / hero_n
-        achieved = HERO_FLOP_PER_FACE * faces_per_step / (avg_ms * 1e-3) / 1e12
+        achieved = HERO_FLOP_PER_FACE * faces_per_launch / (avg_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "%s<128,128> %s" % ("conv_gemm_split_kernel" if args.dtype == "f32s" else "conv_gemm_kernel<%s>" % args.dtype, HERO_TAG),
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_step) if args.dtype != "f16" else int(2 * 64 * 64 * 128 * 2 * faces_per_step),
+                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_launch) if args.dtype != "f16" else int(2 * 64 * 64 * 128 * 2 * faces_per_launch),
+                    "faces_per_launch": faces_per_launch,
                     "avg_launch_ms": round(avg_ms, 4), "launches": hero_n,
                     "executed_mfma_tflops": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype], 2),
                     "executed_mfma_frac": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype] / PEAK_TFLOPS[args.dtype], 4)}
@@ -195,7 +205,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": ("configs[2] full pipeline: %d x 1080p frames x %d planted faces per GPU per step" % (args.frames, args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
-                   "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d, no data-path collective" % world,
+                   "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
                    "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast %.2f ms" % bcast_ms},
         "roofline": roofline,
         "cpu_baseline": None,
@@ -203,7 +213,7 @@ def main():
                   "algorithmic_tflops": round(value * GFLOP_PER_FACE / 1e3, 2),
                   "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE / 1e3 / PEAK_TFLOPS[args.dtype], 4),
                   "setup_s": round(setup_s, 2),
-                  "kernel_ms_per_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
+                  "kernel_ms_per_lane_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(workload, args.cpu_faces)
@@ -212,7 +222,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    eng.close()
+    if hasattr(state, "close"):
+        state.close()
+    else:
+        eng.close()
 
 
 if __name__ == "__main__":

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // fly -- bilinear x2 upsample of up_lo / pass-through of up_skip, depthwise 3x3 (+bias) -- so the
 // concatenated and the depthwise tensors never exist in HBM.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+    // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves)
     constexpr int NTHR = WARPS_M * WARPS_N * 64;       // 256 or 512 threads (8 waves hide the staging latency)
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -414,8 +415,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel
                         const int xcls = x == 0 ? 0 : (x == W - 1 ? 1 : 2 + (x & 1));
                         const float* we = a.dw_w + (size_t)((ycls * 4 + xcls) * 9) * a.C1 + kelem;
                         const float* lo = a.up_lo + (size_t)xb[u] * a.loH * a.loW * a.loLd + kelem;
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
+#pragma unroll 1
+                        for (int j = 0; j < 3; ++j) {   // one patch row at a time keeps the live loads (and VGPRs) bounded
                             const int ry = min(max(my - 1 + j, 0), a.loH - 1);
 #pragma unroll
                             for (int i = 0; i < 3; ++i) {
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64) void conv_gemm_split_kernel
                         const int C2 = a.inC - a.C1;
                         const float* wd = a.dw_w2 + (kelem - a.C1);
                         const float* sk = a.up_skip + (size_t)xb[u] * H * W * a.skipLd + (kelem - a.C1);
-#pragma unroll
+#pragma unroll 1
                         for (int k1 = 0; k1 < 3; ++k1) {
                             const int yy = y - 1 + k1;
                             if ((unsigned)yy >= (unsigned)H) continue;
