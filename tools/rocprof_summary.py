@@ -51,7 +51,7 @@ def main():
                 lines.append("| %s | %s | %d | %.4g | %.4g |" % (k, c, n, v, v / max(n, 1)))
         lines.append("")
     # hero kernel (up2.conv2 = the only kxk launch of the 128x128 tile): per-dispatch numbers
-    hero = "conv_gemm_kernel<float, 128, 128, 2, 2, 3>"
+    hero = "conv_gemm_split_kernel<128, 128, 4, 2, 3, 0>" if any("split_kernel<128, 128, 4, 2, 3, 0>" in open(p).read() for p in glob.glob(os.path.join(d, "**", "*.csv"), recursive=True)) else "conv_gemm_kernel<float, 128, 128, 2, 2, 3>"
     for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
         durs = []
         with open(path) as f:
