@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
                     help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
                          "(same accuracy); f16: f16 storage fast mode (parity not claimed)")
+    ap.add_argument("--model", default="student", choices=["student", "teacher"],
+                    help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=48)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
@@ -123,7 +125,7 @@ def main():
 
     # ---- weights: packed on rank 0, broadcast once over RCCL / xGMI -----------------------------
     t0 = time.time()
-    blobs = bs.build_programs(workload, args.dtype) if rank == 0 else None
+    blobs = bs.build_programs(workload, args.dtype, args.model) if rank == 0 else None
     bcast_ms = 0.0
     if use_dist:
         blobs, bcast_ms = bs.broadcast_blobs(blobs, dev, rank)
@@ -198,7 +200,7 @@ def main():
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
     out = {
-        "metric": "faces/sec (whole node), Student@256" + (" 1080px8-face full pipeline" if workload == "pipeline" else " landmark-only"),
+        "metric": "faces/sec (whole node), %s@256" % args.model.capitalize() + (" 1080px8-face full pipeline" if workload == "pipeline" else " landmark-only"),
         "value": round(value, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "f16": "f16", "f32s": "f32 (tensors f32; convs = 3x f16-MFMA split precision, f32 accumulate)"}[args.dtype],

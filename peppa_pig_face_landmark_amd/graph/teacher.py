@@ -99,3 +99,85 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
     info.update({"tensors": dict(pb.tensor_names), "input_size": input_size, "dtype": dtype,
                  "n_ops": len(pb.ops), "const_bytes": len(pb.consts)})
     return blob, info
+
+
+def teacher_param_shapes():
+    """(name, shape, kind) of every tensor of ``COTRAIN.teacher`` used at inference (kind: conv/bias/bn)."""
+    out = []
+
+    def cb(pc, pbn, cin, cout, k):
+        out.extend([(f"{pc}.weight", (cout, cin, k, k), "conv"), (pbn, (cout,), "bn")])
+
+    def bottleneck(p, cin, planes):
+        cb(f"{p}.conv1", f"{p}.bn1", cin, planes, 1); cb(f"{p}.conv2", f"{p}.bn2", planes, planes, 3)
+        cb(f"{p}.conv3", f"{p}.bn3", planes, planes * 4, 1)
+        if cin != planes * 4:
+            cb(f"{p}.downsample.0", f"{p}.downsample.1", cin, planes * 4, 1)
+
+    e = "encoder"
+    cb(f"{e}.conv1", f"{e}.bn1", 3, 64, 3); cb(f"{e}.conv2", f"{e}.bn2", 64, 64, 3)
+    cin = 64
+    for b in range(4):
+        bottleneck(f"{e}.layer1.{b}", cin, 64)
+        cin = 256
+    cb(f"{e}.transition1.0.0", f"{e}.transition1.0.1", 256, 18, 3)
+    cb(f"{e}.transition1.1.0.0", f"{e}.transition1.1.0.1", 256, 36, 3)
+    for si, modules, nb in STAGES:
+        if si > 2:
+            cb(f"{e}.transition{si - 1}.{nb - 1}.0.0", f"{e}.transition{si - 1}.{nb - 1}.0.1", BRANCH_CH[nb - 2], BRANCH_CH[nb - 1], 3)
+        for m in range(modules):
+            p = f"{e}.stage{si}.{m}"
+            for br in range(nb):
+                for blk in range(4):
+                    q = f"{p}.branches.{br}.{blk}"
+                    cb(f"{q}.conv1", f"{q}.bn1", BRANCH_CH[br], BRANCH_CH[br], 3)
+                    cb(f"{q}.conv2", f"{q}.bn2", BRANCH_CH[br], BRANCH_CH[br], 3)
+            for i in range(nb):
+                for j in range(nb):
+                    if j > i:
+                        cb(f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", BRANCH_CH[j], BRANCH_CH[i], 1)
+                    elif j < i:
+                        for k in range(i - j):
+                            cout = BRANCH_CH[i] if k == i - j - 1 else BRANCH_CH[j]
+                            cb(f"{p}.fuse_layers.{i}.{j}.{k}.0", f"{p}.fuse_layers.{i}.{j}.{k}.1", BRANCH_CH[j], cout, 3)
+    for i, planes in enumerate((32, 64, 128)):
+        bottleneck(f"{e}.incre_modules.{i}.0", BRANCH_CH[i], planes)
+    a = "decoder.aspp"
+    out.extend([(f"{a}.conv1.weight", (64, 512, 1, 1), "conv"), (f"{a}.conv2.weight", (64, 512, 3, 3), "conv"),
+                (f"{a}.conv3.weight", (64, 512, 3, 3), "conv"), (f"{a}.bn_act.0", (256,), "bn"),
+                (f"{a}.fm_pool.pool.1.weight", (64, 512, 1, 1), "conv"), (f"{a}.fm_pool.pool.2", (64,), "bn"),
+                (f"{a}.project.0.weight", (256, 256, 1, 1), "conv"), (f"{a}.project.1", (256,), "bn")])
+    for name, c_in, c_out, second, att in (("decoder.upsampler1", 512, 256, False, True), ("decoder.upsampler2", 384, 128, True, False)):
+        out.extend([(f"{name}.conv1.0.conv_dw.0.weight", (c_in, 1, 3, 3), "conv"), (f"{name}.conv1.0.conv_dw.0.bias", (c_in,), "bias"),
+                    (f"{name}.conv1.0.conv_dw.1", (c_in,), "bn"), (f"{name}.conv1.0.conv_pw.weight", (c_out, c_in, 1, 1), "conv"),
+                    (f"{name}.conv1.1", (c_out,), "bn")])
+        if second:
+            out.extend([(f"{name}.conv2.0.weight", (c_out, c_out, 3, 3), "conv"), (f"{name}.conv2.0.bias", (c_out,), "bias"),
+                        (f"{name}.conv2.1", (c_out,), "bn")])
+        if att:
+            out.extend([(f"{name}.attention2.cSE.1.weight", (c_out // 4, c_out, 1, 1), "conv"), (f"{name}.attention2.cSE.1.bias", (c_out // 4,), "bias"),
+                        (f"{name}.attention2.cSE.3.weight", (c_out, c_out // 4, 1, 1), "conv"), (f"{name}.attention2.cSE.3.bias", (c_out,), "bias"),
+                        (f"{name}.attention2.sSE.0.weight", (1, c_out, 1, 1), "conv"), (f"{name}.attention2.sSE.0.bias", (1,), "bias")])
+    out.extend([("hm.weight", (294, 128, 1, 1), "conv"), ("hm.bias", (294,), "bias")])
+    return out
+
+
+def random_teacher_weights(seed: int = 2) -> Dict[str, np.ndarray]:
+    """Random-init weights of the exact architecture (benchmarks only; see graph/random_init.py)."""
+    rng = np.random.default_rng(seed)
+    w: Dict[str, np.ndarray] = {}
+    last_var = 1.0
+    for name, shape, kind in teacher_param_shapes():
+        if kind == "conv":
+            cout, cin_g, kh, kw = shape
+            std = np.sqrt(2.0 / (cout * kh * kw))
+            w[name] = (rng.standard_normal(shape) * std).astype(np.float32)
+            last_var = max(cin_g * kh * kw * std * std * 0.6, 1e-3)
+        elif kind == "bias":
+            w[name] = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        else:
+            w[f"{name}.weight"] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+            w[f"{name}.bias"] = (rng.standard_normal(shape) * 0.3).astype(np.float32)
+            w[f"{name}.running_mean"] = np.zeros(shape, np.float32)
+            w[f"{name}.running_var"] = np.full(shape, last_var, np.float32)
+    return w
