@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GFLOP_PER_FACE = 2.968       # Student@256 inference graph, SURVEY.md section 8(d) (1 484.1 M MAC)
+GFLOP_PER_FACE = {"student": 2.968, "teacher": 11.9}   # 1 484.1 M MAC; Teacher from README 5.53 GiMAC
 GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstream figure)
 # dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" = f32 tensors, split-precision convs: every product
 # is 3 v_mfma_f32_16x16x32_f16 instructions (hi*hi + hi*lo + lo*hi), so it is priced against the f16 pipe.
@@ -212,8 +212,8 @@ def main():
         "roofline": roofline,
         "cpu_baseline": None,
         "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
-                  "algorithmic_tflops": round(value * GFLOP_PER_FACE / 1e3, 2),
-                  "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE / 1e3 / PEAK_TFLOPS[args.dtype], 4),
+                  "algorithmic_tflops": round(value * GFLOP_PER_FACE[args.model] / 1e3, 2),
+                  "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE[args.model] / 1e3 / PEAK_TFLOPS[args.dtype], 4),
                   "setup_s": round(setup_s, 2),
                   "kernel_ms_per_lane_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
     }

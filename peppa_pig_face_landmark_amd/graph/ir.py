@@ -168,17 +168,18 @@ class ProgramBuilder:
         self._op(OP_STEM, [-1, out, off_u8, off_b, ACT[act], off_f32], [], [self._tb(out)])
         return out
 
-    SPLIT_MIN_CIN = 64   # below this a conv is bandwidth-bound: the exact-f32 direct kernel is as fast
+    SPLIT_MIN_CIN = 64       # pointwise convs below this are bandwidth-bound: the exact-f32 direct kernel is as fast
+    SPLIT_MIN_CIN_KXK = 16   # kxk convs are matrix-core bound much earlier (HRNet's 18/36-channel 3x3 stacks)
 
-    def conv_uses_split(self, cin: int) -> bool:
-        return self.split and cin >= self.SPLIT_MIN_CIN
+    def conv_uses_split(self, cin: int, taps: int = 1) -> bool:
+        return self.split and (cin >= self.SPLIT_MIN_CIN or (taps > 1 and cin >= self.SPLIT_MIN_CIN_KXK))
 
     def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int, float, bool]:
         """[N,Cin,KH,KW] -> (const offset, Npad, Cpad, acc_scale, use_split).
         direct kernels: [Npad][KH*KW][Cpad] in the activation dtype (64-byte K steps), acc_scale 1;
         split kernels : [Npad][KH*KW][Cpad/32][hi 32 x f16 | lo 32 x f16] of w * 2^s, acc_scale 2^-s."""
         n, cin, kh, kw = weight.shape
-        use_split = self.conv_uses_split(cin)
+        use_split = self.conv_uses_split(cin, kh * kw)
         ke = 32 if use_split else 64 // self.esize
         npad, cpad = _round_up(n, 16), _round_up(cin, ke)
         w = np.zeros((npad, kh * kw, cpad), np.float64)
