@@ -31,7 +31,7 @@ extern "C" {
 
 typedef struct pf_handle pf_handle;
 
-enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1 };
+enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1, PF_MEM_RESIDENT = 2 };  /* 2: the frame stored by pf_set_frame (bgr may be NULL) */
 enum { PF_NET_LANDMARK = 0, PF_NET_DETECTOR = 1, PF_NET_SLOTS = 4 };
 enum { PF_INPUT_U8_NHWC = 0, PF_INPUT_F32_NCHW = 1 };
 enum { PF_DTYPE_F16 = 0, PF_DTYPE_F32 = 1, PF_DTYPE_F32_SPLIT = 2 };  /* 2: f32 tensors, 3 x f16-MFMA split-precision convs */
@@ -114,6 +114,16 @@ int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, f
                 float score_thres, float iou_thres, float* kept, int max_n, int* n_out);
 int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                   const float* boxes, int n, int out_size, uint8_t* crops_host, int* params_host);
+
+/* Video mode (FaceAna.run on a stream, facer.py:52-85): upload the frame ONCE, keep it resident for the
+ * following pf_detect / pf_landmarks calls (pass mem = PF_MEM_RESIDENT), and evaluate the frame-difference
+ * gate of FaceAna.diff_frames (facer.py:98-118) on the device against the previous resident frame:
+ * *abs_diff_sum = sum |prev - cur| over all H*W*3 bytes (the caller divides by H*W*3 and compares with 5),
+ * *has_prev = 0 when there is no previous frame of the same shape.  row_stride must equal 3*width.
+ * pf_forget_frames == FaceAna.reset() for the resident frames (facer.py:200-208). */
+int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 unsigned long long* abs_diff_sum, int* has_prev);
+int pf_forget_frames(pf_handle* h);
 
 /* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream
  * when profiling is enabled.  names: '\n'-separated kernel tags; ms: same order. */

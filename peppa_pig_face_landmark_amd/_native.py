@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-PF_MEM_HOST, PF_MEM_DEVICE = 0, 1
+PF_MEM_HOST, PF_MEM_DEVICE, PF_MEM_RESIDENT = 0, 1, 2
 PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 
@@ -47,11 +47,13 @@ def _declare(lib):
     lib.pf_letterbox.argtypes = [vp, vp, i, i, i, i, i, i, vp, fp]
     lib.pf_nms_rows.argtypes = [vp, fp, i, f, f, f, f, f, fp, i, ip]
     lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
+    lib.pf_set_frame.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_ulonglong), ip]
+    lib.pf_forget_frames.argtypes = [vp]
     lib.pf_profile_enable.argtypes = [vp, i]
     lib.pf_profile_fetch.argtypes = [vp, C.c_char_p, sz, fp, ip, i, ip]
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
                  "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
-                 "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces"):
+                 "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces", "pf_set_frame", "pf_forget_frames"):
         getattr(lib, name).restype = i
     return lib
 
@@ -162,27 +164,59 @@ class Engine:
                                             out.ctypes.data_as(C.POINTER(C.c_float)), out.size), "pf_read_tensor")
         return out
 
-    # ---- pipeline seams -----------------------------------------------------------------------
-    def detect(self, image_bgr: np.ndarray, score_thres: float, iou_thres: float, max_n: int = 1024) -> np.ndarray:
+    # ---- video mode: resident frame + frame-difference gate ------------------------------------------
+    def set_frame(self, image_bgr: np.ndarray):
+        """Upload the frame once and keep it resident; returns the mean absolute difference to the
+        previous resident frame exactly as FaceAna.diff_frames computes it (facer.py:111-113), or None
+        when there is no previous frame of the same shape."""
         img = np.ascontiguousarray(image_bgr)
         assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        total = C.c_ulonglong(0)
+        has_prev = C.c_int(0)
+        self._check(self.lib.pf_set_frame(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                          C.byref(total), C.byref(has_prev)), "pf_set_frame")
+        self._resident_shape = img.shape
+        if not has_prev.value:
+            return None
+        return total.value / img.shape[0] / img.shape[1] / 3.0
+
+    def forget_frames(self):
+        self._check(self.lib.pf_forget_frames(self.h), "pf_forget_frames")
+        self._resident_shape = None
+
+    def _frame_args(self, image_bgr):
+        """(pointer, mem, H, W, row_stride) for a host frame, or for the resident one when image is None."""
+        if image_bgr is None:
+            shp = getattr(self, "_resident_shape", None)
+            if shp is None:
+                raise PeppaHipError("no resident frame: call set_frame() first")
+            return None, PF_MEM_RESIDENT, shp[0], shp[1], shp[1] * 3, None
+        img = np.ascontiguousarray(image_bgr)
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        return _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0], img
+
+    # ---- pipeline seams -----------------------------------------------------------------------
+    def detect(self, image_bgr, score_thres: float, iou_thres: float, max_n: int = 1024) -> np.ndarray:
+        """image_bgr: HxWx3 uint8, or None to use the frame stored by set_frame()."""
+        ptr, mem, H, W, stride, _keep = self._frame_args(image_bgr)
         boxes = np.empty((max_n, 16), np.float32)
         n = C.c_int(0)
-        self._check(self.lib.pf_detect(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+        self._check(self.lib.pf_detect(self.h, ptr, mem, H, W, stride,
                                        score_thres, iou_thres, boxes.ctypes.data_as(C.POINTER(C.c_float)), max_n,
                                        C.byref(n)), "pf_detect")
         return boxes[:n.value].copy()
 
-    def landmarks(self, image_bgr: np.ndarray, boxes: np.ndarray):
-        img = np.ascontiguousarray(image_bgr)
+    def landmarks(self, image_bgr, boxes: np.ndarray):
+        """image_bgr: HxWx3 uint8, or None to use the frame stored by set_frame()."""
+        ptr, mem, H, W, stride, _keep = self._frame_args(image_bgr)
         b = np.ascontiguousarray(np.asarray(boxes, np.float32)[:, :4])
         n = b.shape[0]
         kps = np.zeros((n, 98, 2), np.float32)
         scores = np.zeros((n, 98), np.float32)
         valid = np.zeros((n,), np.int32)
         if n:
-            self._check(self.lib.pf_landmarks(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1],
-                                              img.strides[0], b.ctypes.data_as(C.POINTER(C.c_float)), n,
+            self._check(self.lib.pf_landmarks(self.h, ptr, mem, H, W,
+                                              stride, b.ctypes.data_as(C.POINTER(C.c_float)), n,
                                               kps.ctypes.data_as(C.POINTER(C.c_float)),
                                               scores.ctypes.data_as(C.POINTER(C.c_float)),
                                               valid.ctypes.data_as(C.POINTER(C.c_int))), "pf_landmarks")

@@ -22,7 +22,8 @@ class FaceDetector:
                                max_batch=max_batch, engine=engine, library=library)
         self.engine = self.model.engine
 
-    def __call__(self, image: np.ndarray) -> np.ndarray:
+    def __call__(self, image) -> np.ndarray:
+        """image: BGR uint8 frame, or None for the frame made resident by Engine.set_frame()."""
         t0 = time.time()
         boxes = self.engine.detect(image, float(self.score_thrs), float(self.iou_thrs))
         logger.info("detect done, time consume: %.5f", time.time() - t0)

@@ -29,7 +29,8 @@ class FaceLandmark:
                                max_batch=max_batch, engine=engine, library=library)
         self.engine = self.model.engine
 
-    def __call__(self, img: np.ndarray, bboxes):
+    def __call__(self, img, bboxes):
+        """img: BGR uint8 frame, or None for the frame made resident by Engine.set_frame()."""
         bboxes = np.asarray(bboxes, np.float32).reshape(-1, np.asarray(bboxes).shape[-1] if len(bboxes) else 4)
         if bboxes.shape[0] == 0:
             return np.array([]), np.array([])

@@ -83,17 +83,20 @@ class FaceAna:
 
     # ---- per-frame entry ---------------------------------------------------------------------------
     def run(self, image: np.ndarray):
-        if self.diff_frames(self.previous_image, image):
-            boxes = self.face_detector(image)
-            self.previous_image = image
+        # one host->device copy per frame: the frame stays resident for the gate, the detector and the
+        # landmark stage; the frame-difference gate (facer.py:98-118) is evaluated on the GPU against the
+        # previous resident frame (exact integer sum, same decision as the numpy code in diff_frames()).
+        diff = self.engine.set_frame(image)
+        self.previous_image = image
+        if diff is None or self.track_box is None or diff > self.diff_thres:
+            boxes = self.face_detector(None)
             boxes = self.judge_boxs(self.track_box, boxes)
             self.trace.previous_landmarks_set = None     # detector ran: smoothing history is dropped
         else:
             boxes = self.track_box
-            self.previous_image = image
         boxes = self.sort_and_filter(boxes)
         boxes_return = np.array(boxes)
-        landmarks, states = self.face_landmark(image, boxes)
+        landmarks, states = self.face_landmark(None, boxes)
         landmarks = self.trace.calculate(image, landmarks)
         hulls = [[np.min(l[:, 0]), np.min(l[:, 1]), np.max(l[:, 0]), np.max(l[:, 1])] for l in landmarks]
         self.track_box = self.judge_boxs(boxes_return, np.array(hulls))
@@ -142,3 +145,4 @@ class FaceAna:
         self.track_box = None
         self.previous_image = None
         self.previous_box = None
+        self.engine.forget_frames()

@@ -23,6 +23,12 @@ struct PipelineScratch {
     // device scratch owned by the handle (allocated lazily by pipeline.inl)
     unsigned char* d_frames = nullptr; size_t frames_bytes = 0;
     unsigned char* d_letterbox = nullptr; size_t letterbox_bytes = 0;
+    // resident current / previous frame of a video stream (pf_set_frame; FaceAna.diff_frames, facer.py:98-118)
+    unsigned char* d_cur = nullptr; size_t cur_bytes = 0;
+    unsigned char* d_prev = nullptr; size_t prev_bytes = 0;
+    unsigned long long* d_diff_sum = nullptr;
+    int cur_h = 0, cur_w = 0, prev_h = 0, prev_w = 0;
+    bool have_cur = false, have_prev = false;
     unsigned char* d_crops = nullptr; size_t crops_bytes = 0;
     float* d_rows_planted = nullptr; size_t rows_planted_bytes = 0;
     float* d_lbinfo = nullptr;       // [4] scale,left,top,pad
@@ -38,7 +44,7 @@ struct PipelineScratch {
     unsigned char* d_nms_flags = nullptr;      // [F][cap]
     int cap_frames = 0, cap_faces = 0, cap_keep = 0, cap_topk = 0, cap_rows = 0;
     void release() {
-        void* ptrs[] = {d_frames, d_letterbox, d_crops, d_rows_planted, d_lbinfo, d_keep_rows, d_keep_count,
+        void* ptrs[] = {d_cur, d_prev, d_diff_sum, d_frames, d_letterbox, d_crops, d_rows_planted, d_lbinfo, d_keep_rows, d_keep_count,
                         d_sel_boxes, d_sel_count, d_crop_params, d_cropf, d_kps, d_nms_keys, d_nms_flags};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = PipelineScratch();
@@ -366,4 +372,38 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(CropResizeArgs a) {
                        pf_padded_px(src, a.row_stride, a.H, a.W, ys + ty.i1, xs + tx.i1, add, c) * tx.a1;
         o[c] = (unsigned char)pf_cv_vmix(h0, h1, ty.a0, ty.a1);
     }
+}
+
+// --------------------------------------------------------------------------------------------
+// K13: frame-difference gate of FaceAna.diff_frames (facer.py:111-115): sum |prev - cur| over all bytes.
+// Integer sum (exact, order independent); the host divides by H*W*3 like the reference does.
+struct AbsDiffArgs {
+    const unsigned char* a;
+    const unsigned char* b;
+    unsigned long long* sum;   // zeroed before the launch
+    size_t n;                  // bytes
+};
+
+__global__ __launch_bounds__(256) void absdiff_sum_kernel(AbsDiffArgs a) {
+    __shared__ unsigned int s_part[4];
+    const size_t nvec = a.n / 16;
+    unsigned int acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (size_t)gridDim.x * 256) {
+        const uint4 x = *reinterpret_cast<const uint4*>(a.a + i * 16);
+        const uint4 y = *reinterpret_cast<const uint4*>(a.b + i * 16);
+        const unsigned int xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int d = (int)((xs[w] >> (8 * k)) & 0xFF) - (int)((ys[w] >> (8 * k)) & 0xFF);
+                acc += (unsigned int)(d < 0 ? -d : d);
+            }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = nvec * 16; i < a.n; ++i) { const int d = (int)a.a[i] - (int)a.b[i]; acc += (unsigned int)(d < 0 ? -d : d); }
+    for (int mask = 1; mask < 64; mask <<= 1) acc += (unsigned int)pf_shfl_xor_i32((int)acc, mask);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(a.sum, (unsigned long long)s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }

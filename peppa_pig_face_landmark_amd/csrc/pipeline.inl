@@ -76,6 +76,12 @@ LetterboxGeom letterbox_geom(int H, int W, int outH, int outW) {
 // frames (host or device) -> device pointer
 int stage_frames(pf_handle* h, const uint8_t* frames, int mem, size_t bytes, const unsigned char** d_out) {
     if (mem == PF_MEM_DEVICE) { *d_out = frames; return 0; }
+    if (mem == PF_MEM_RESIDENT) {
+        if (!h->pipe.have_cur || (size_t)h->pipe.cur_h * h->pipe.cur_w * 3 != bytes)
+            PF_FAIL(h, "no resident frame of this size (call pf_set_frame first)");
+        *d_out = h->pipe.d_cur;
+        return 0;
+    }
     if (ensure_dev(h, h->pipe.d_frames, h->pipe.frames_bytes, bytes)) return 1;
     PF_HIP(h, hipMemcpyAsync(h->pipe.d_frames, frames, bytes, hipMemcpyHostToDevice, h->stream));
     *d_out = h->pipe.d_frames;
@@ -164,7 +170,7 @@ int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, 
     if (!h) return 1;
     Program& det = h->prog[PF_NET_DETECTOR];
     if (!det.loaded) PF_FAIL(h, "detector program not loaded");
-    if (!bgr || !boxes || !n_out || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_detect: bad arguments");
+    if ((!bgr && mem != PF_MEM_RESIDENT) || !boxes || !n_out || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_detect: bad arguments");
     PF_HIP(h, hipSetDevice(h->device));
     const int rows = det.bufs[det.hdr.out_buf0].elems_per_item / 16;
     if (ensure_pipeline(h, 1, 0, 1, rows)) return 1;
@@ -187,7 +193,7 @@ int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     if (!h) return 1;
     Program& lm = h->prog[PF_NET_LANDMARK];
     if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
-    if (n < 0 || !bgr || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_landmarks: bad arguments");
+    if (n < 0 || (!bgr && mem != PF_MEM_RESIDENT) || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_landmarks: bad arguments");
     if (n == 0) return 0;
     PF_HIP(h, hipSetDevice(h->device));
     if (ensure_pipeline(h, 1, n, n, 2)) return 1;
@@ -254,6 +260,46 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
     if (scores) PF_HIP(h, hipMemcpyAsync(scores, lm.buf_ptr(lm.hdr.out_buf1), (size_t)faces * kNumPoints * sizeof(float), kind, h->stream));
     if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                 unsigned long long* abs_diff_sum, int* has_prev) {
+    if (!h) return 1;
+    if (!bgr || height < 1 || width < 1 || row_stride != width * 3 || mem == PF_MEM_RESIDENT) PF_FAIL(h, "pf_set_frame: bad arguments (packed BGR rows required)");
+    PF_HIP(h, hipSetDevice(h->device));
+    PipelineScratch& s = h->pipe;
+    const size_t bytes = (size_t)height * row_stride;
+    // rotate: the current resident frame becomes the previous one
+    std::swap(s.d_cur, s.d_prev);
+    std::swap(s.cur_bytes, s.prev_bytes);
+    s.prev_h = s.cur_h; s.prev_w = s.cur_w; s.have_prev = s.have_cur;
+    if (ensure_dev(h, s.d_cur, s.cur_bytes, bytes)) return 1;
+    if (!s.d_diff_sum) PF_HIP(h, hipMalloc((void**)&s.d_diff_sum, sizeof(unsigned long long)));
+    PF_HIP(h, hipMemcpyAsync(s.d_cur, bgr, bytes, mem == PF_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+    s.cur_h = height; s.cur_w = width; s.have_cur = true;
+    const bool comparable = s.have_prev && s.prev_h == height && s.prev_w == width;
+    if (has_prev) *has_prev = comparable ? 1 : 0;
+    if (abs_diff_sum) *abs_diff_sum = 0;
+    if (comparable && abs_diff_sum) {
+        PF_HIP(h, hipMemsetAsync(s.d_diff_sum, 0, sizeof(unsigned long long), h->stream));
+        AbsDiffArgs a{};
+        a.a = s.d_cur; a.b = s.d_prev; a.sum = s.d_diff_sum; a.n = bytes;
+        const unsigned blocks = (unsigned)std::min<size_t>(2048, (bytes / 16 + 255) / 256 + 1);
+        {
+            ProfScope ps(h, "absdiff_sum");
+            PF_LAUNCH(absdiff_sum_kernel, dim3(blocks), dim3(256), h->stream, a);
+        }
+        PF_HIP(h, hipMemcpyAsync(abs_diff_sum, s.d_diff_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+    }
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int pf_forget_frames(pf_handle* h) {
+    if (!h) return 1;
+    h->pipe.have_cur = false;
+    h->pipe.have_prev = false;
     return 0;
 }
 

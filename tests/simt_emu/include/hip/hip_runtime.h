@@ -186,6 +186,8 @@ inline float atomicAdd(float* p, float v) {
 }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+struct uint4 { unsigned x, y, z, w; };
 inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
     unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

@@ -157,3 +157,26 @@ def test_landmarks_no_boxes_and_detect_rejects_bad_args(emu_engine, student_weig
         emu_engine.landmarks(frame, np.tile(np.array([[10, 10, 90, 100]], np.float32), (3, 1)))
     with pytest.raises(PeppaHipError):                         # detector program not loaded
         emu_engine.detect(frame, 0.5, 0.3)
+
+
+def test_resident_frame_and_diff_gate(emu_engine, student_weights):
+    """pf_set_frame: exact |prev - cur| sum (FaceAna.diff_frames, facer.py:111-115) and resident-frame reuse."""
+    rng = np.random.default_rng(0)
+    f0 = rng.integers(0, 256, (123, 211, 3), dtype=np.uint8)
+    f1 = np.clip(f0.astype(np.int16) + rng.integers(-9, 10, f0.shape), 0, 255).astype(np.uint8)
+    assert emu_engine.set_frame(f0) is None
+    d = emu_engine.set_frame(f1)
+    ref = np.abs(f0.astype(np.int64) - f1.astype(np.int64)).sum() / 123 / 211 / 3.0
+    assert d == ref
+    assert emu_engine.set_frame(f1) == 0.0
+    assert emu_engine.set_frame(rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)) is None   # shape change
+    emu_engine.forget_frames()
+    assert emu_engine.set_frame(f0) is None
+    # resident frame feeds the landmark stage exactly like a host frame
+    blob, _ = build_student_program(student_weights, 64, "f32")
+    emu_engine.load_program(0, blob, 2)
+    frame, boxes = make_frame(270, 480, 2, seed=4, face_w=300, face_h=400)
+    a = emu_engine.landmarks(frame, boxes)
+    emu_engine.set_frame(frame)
+    b = emu_engine.landmarks(None, boxes)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

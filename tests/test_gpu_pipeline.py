@@ -173,3 +173,15 @@ def test_config1_plumbing_student128_single_face(hip_library, student_weights, d
     res = facer.run(frame)
     assert isinstance(res, list)
     facer.engine.close()
+
+
+def test_frame_diff_gate_1080p(gpu_engine, frame1080):
+    """K13 / SURVEY 8f N1: FaceAna.diff_frames (facer.py:98-118) on the device, exact integer sum."""
+    frame, _ = frame1080
+    rng = np.random.default_rng(1)
+    other = np.clip(frame.astype(np.int16) + rng.integers(-12, 13, frame.shape), 0, 255).astype(np.uint8)
+    assert gpu_engine.set_frame(frame) is None
+    d = gpu_engine.set_frame(other)
+    ref = np.abs(frame.astype(np.int64) - other.astype(np.int64)).sum() / 1080 / 1920 / 3.0
+    assert d == ref
+    assert gpu_engine.set_frame(other) == 0.0
