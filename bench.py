@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
                     help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
                          "(same accuracy); f16: f16 storage fast mode (parity not claimed)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--model", default="student", choices=["student", "teacher"],
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -139,11 +140,11 @@ def main():
     if workload == "landmark":
         state = bs.LandmarkWorkload(eng, dev, args.batch, seed=1234 + rank)
     elif lanes == 1:
-        state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank)
+        state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank, graph=not args.no_graph)
     else:
         eng.close()
         state = bs.MultiLanePipeline(lambda: Engine(local_rank), blobs, dev, args.frames, args.faces_per_frame,
-                                     seed=7 + rank, lanes=lanes)
+                                     seed=7 + rank, lanes=lanes, graph=not args.no_graph)
         eng = state.lanes[0].eng
 
     def barrier():

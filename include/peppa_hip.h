@@ -125,6 +125,11 @@ int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
                  unsigned long long* abs_diff_sum, int* has_prev);
 int pf_forget_frames(pf_handle* h);
 
+/* Engine options.  PF_OPT_HIP_GRAPH = 1: pf_run_frames* calls whose buffers all live on the device are captured
+ * into a hipGraph per distinct (pointers, shapes, thresholds) and replayed (launch-latency bound small batches). */
+enum { PF_OPT_HIP_GRAPH = 1 };
+int pf_set_option(pf_handle* h, int option, int value);
+
 /* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream
  * when profiling is enabled.  names: '\n'-separated kernel tags; ms: same order. */
 int pf_profile_enable(pf_handle* h, int on);

@@ -14,6 +14,7 @@ import numpy as np
 PF_MEM_HOST, PF_MEM_DEVICE, PF_MEM_RESIDENT = 0, 1, 2
 PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
+PF_OPT_HIP_GRAPH = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libpeppa_hip.so")
@@ -49,11 +50,12 @@ def _declare(lib):
     lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
     lib.pf_set_frame.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_ulonglong), ip]
     lib.pf_forget_frames.argtypes = [vp]
+    lib.pf_set_option.argtypes = [vp, i, i]
     lib.pf_profile_enable.argtypes = [vp, i]
     lib.pf_profile_fetch.argtypes = [vp, C.c_char_p, sz, fp, ip, i, ip]
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
                  "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
-                 "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces", "pf_set_frame", "pf_forget_frames"):
+                 "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces", "pf_set_frame", "pf_forget_frames", "pf_set_option"):
         getattr(lib, name).restype = i
     return lib
 
@@ -285,6 +287,10 @@ class Engine:
                                            b.ctypes.data_as(C.POINTER(C.c_float)), n, out_size, _ptr(crops),
                                            params.ctypes.data_as(C.POINTER(C.c_int))), "pf_crop_faces")
         return crops, params
+
+    def set_option(self, option: int, value: int):
+        """PF_OPT_HIP_GRAPH (1): replay device-resident run_frames calls from a captured hipGraph."""
+        self._check(self.lib.pf_set_option(self.h, int(option), int(value)), "pf_set_option")
 
     # ---- profiling ----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

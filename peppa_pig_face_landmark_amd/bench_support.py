@@ -142,10 +142,11 @@ class PipelineWorkload:
 
     H, W, ROWS = 1080, 1920, 15120
 
-    def __init__(self, eng, dev, frames: int, faces_per_frame: int, seed: int):
+    def __init__(self, eng, dev, frames: int, faces_per_frame: int, seed: int, graph: bool = True):
         import torch
         from .synth import make_frame, plant_rows
         self.eng, self.F, self.K = eng, frames, faces_per_frame
+        eng.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)   # replay the step from a captured hipGraph
         base_frames, base_rows = [], []
         for i in range(min(frames, 2)):
             fr, boxes = make_frame(self.H, self.W, faces_per_frame, seed=seed + i)
@@ -182,14 +183,15 @@ class MultiLanePipeline:
     host thread lets the GPU overlap the many small kernels of one lane (detector, gates, NMS) with the
     large ones of the other: +7 % faces/s at 2 lanes on MI355X (tools/try_two_streams.py)."""
 
-    def __init__(self, make_engine, blobs, dev, frames: int, faces_per_frame: int, seed: int, lanes: int = 2):
+    def __init__(self, make_engine, blobs, dev, frames: int, faces_per_frame: int, seed: int, lanes: int = 2,
+                 graph: bool = True):
         assert frames % lanes == 0
         self.lanes = []
         per = frames // lanes
         for i in range(lanes):
             eng = make_engine()
             load_programs(eng, blobs, "pipeline", per * faces_per_frame, per)
-            self.lanes.append(PipelineWorkload(eng, dev, per, faces_per_frame, seed + 101 * i))
+            self.lanes.append(PipelineWorkload(eng, dev, per, faces_per_frame, seed + 101 * i, graph=graph))
 
     def step(self):
         for wl in self.lanes:

@@ -44,6 +44,9 @@ struct Program {
 
 struct ProfEntry { double ms = 0; int count = 0; };
 
+struct GraphKey { const void* p[6]; int i[5]; float f[3]; };
+struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+
 }  // namespace
 
 struct pf_handle {
@@ -56,6 +59,9 @@ struct pf_handle {
     size_t stage_bytes = 0;
     // pipeline scratch (k_prepost)
     PipelineScratch pipe;
+    // hipGraph replay of pf_run_frames* (PF_OPT_HIP_GRAPH)
+    bool use_graphs = false, capturing = false;
+    std::vector<GraphEntry> graphs;
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -426,6 +432,7 @@ void pf_destroy(pf_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (auto& p : h->prog) {
         if (p.d_const) (void)hipFree(p.d_const);
         if (p.d_arena) (void)hipFree(p.d_arena);

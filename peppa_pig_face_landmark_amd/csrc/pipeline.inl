@@ -110,7 +110,8 @@ int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const Lett
                   float score_thres, float iou_thres, float min_face, int top_k, bool select) {
     PipelineScratch& s = h->pipe;
     s.h_lbinfo[0] = (float)g.scale; s.h_lbinfo[1] = (float)g.left; s.h_lbinfo[2] = (float)g.top; s.h_lbinfo[3] = 0.f;
-    PF_HIP(h, hipMemcpyAsync(s.d_lbinfo, s.h_lbinfo, sizeof(s.h_lbinfo), hipMemcpyHostToDevice, h->stream));
+    if (!h->capturing)   // same constants were uploaded by the eager run that precedes every capture
+        PF_HIP(h, hipMemcpyAsync(s.d_lbinfo, s.h_lbinfo, sizeof(s.h_lbinfo), hipMemcpyHostToDevice, h->stream));
     NmsArgs na{};
     na.rows = d_rows; na.lbinfo = s.d_lbinfo; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
     na.sel_boxes = select ? s.d_sel_boxes : nullptr; na.sel_count = s.d_sel_count;
@@ -217,11 +218,10 @@ int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     return 0;
 }
 
-int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
-                          const float* det_rows, int rows, float score_thres, float iou_thres,
-                          float min_face, int top_k,
-                          int* counts, float* boxes, float* kps, float* scores, int out_mem) {
-    if (!h) return 1;
+static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                              const float* det_rows, int rows, float score_thres, float iou_thres,
+                              float min_face, int top_k,
+                              int* counts, float* boxes, float* kps, float* scores, int out_mem) {
     Program& det = h->prog[PF_NET_DETECTOR];
     Program& lm = h->prog[PF_NET_LANDMARK];
     if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
@@ -259,8 +259,64 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     if (boxes) PF_HIP(h, hipMemcpyAsync(boxes, h->pipe.d_sel_boxes, (size_t)faces * 4 * sizeof(float), kind, h->stream));
     if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
     if (scores) PF_HIP(h, hipMemcpyAsync(scores, lm.buf_ptr(lm.hdr.out_buf1), (size_t)faces * kNumPoints * sizeof(float), kind, h->stream));
-    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
     return 0;
+}
+
+// With PF_OPT_HIP_GRAPH on and everything device resident, the ~170 launches of one call are captured
+// into a hipGraph the second time the same (pointers, shapes, thresholds) key is seen and replayed from
+// then on: one graph launch instead of ~170 kernel launches (single-frame latency is launch bound).
+int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                          const float* det_rows, int rows, float score_thres, float iou_thres,
+                          float min_face, int top_k,
+                          int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+    if (!h) return 1;
+    const bool graphable = h->use_graphs && !h->profiling && mem == PF_MEM_DEVICE && out_mem == PF_MEM_DEVICE;
+    if (!graphable) {
+        if (enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
+                               top_k, counts, boxes, kps, scores, out_mem)) return 1;
+        if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+        return 0;
+    }
+    GraphKey key{};
+    key.p[0] = frames; key.p[1] = det_rows; key.p[2] = counts; key.p[3] = boxes; key.p[4] = kps; key.p[5] = scores;
+    key.i[0] = n_frames; key.i[1] = height; key.i[2] = width; key.i[3] = rows; key.i[4] = top_k;
+    key.f[0] = score_thres; key.f[1] = iou_thres; key.f[2] = min_face;
+    GraphEntry* e = nullptr;
+    for (auto& g : h->graphs)
+        if (memcmp(&g.key, &key, sizeof(key)) == 0) { e = &g; break; }
+    if (!e) {   // first sighting: run eagerly (this also performs every lazy allocation / constant upload)
+        if (h->graphs.size() >= 16) {
+            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+        }
+        GraphEntry ne{};
+        ne.key = key;
+        h->graphs.push_back(ne);
+        return enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
+                                  top_k, counts, boxes, kps, scores, out_mem);
+    }
+    if (!e->exec) {
+        PF_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
+        const int rc = enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres,
+                                          min_face, top_k, counts, boxes, kps, scores, out_mem);
+        h->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+        if (ce != hipSuccess || !graph) PF_FAIL(h, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { e->exec = nullptr; PF_FAIL(h, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+    }
+    PF_HIP(h, hipGraphLaunch(e->exec, h->stream));
+    return 0;
+}
+
+int pf_set_option(pf_handle* h, int option, int value) {
+    if (!h) return 1;
+    if (option == PF_OPT_HIP_GRAPH) { h->use_graphs = value != 0; return 0; }
+    PF_FAIL(h, "unknown option %d", option);
 }
 
 int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,

@@ -185,3 +185,42 @@ def test_frame_diff_gate_1080p(gpu_engine, frame1080):
     ref = np.abs(frame.astype(np.int64) - other.astype(np.int64)).sum() / 1080 / 1920 / 3.0
     assert d == ref
     assert gpu_engine.set_frame(other) == 0.0
+
+
+def test_hip_graph_replay_equals_eager(gpu_engine, student_weights, frame1080):
+    """PF_OPT_HIP_GRAPH: the captured graph of a device-resident pf_run_frames call reproduces the eager
+    results bit for bit, also after the inputs change in place."""
+    from peppa_pig_face_landmark_amd import _native
+    F, K = 2, 8
+    blob, _ = build_student_program(student_weights, 256, "f32s")
+    gpu_engine.load_program(0, blob, F * K)
+    dev = torch.device("cuda", 0)
+    frames_np, rows_np = [], []
+    for f in range(F):
+        fr, boxes = make_frame(1080, 1920, K, seed=50 + f)
+        frames_np.append(fr)
+        rows_np.append(plant_rows(boxes, (1080, 1920), 15120, (384, 640), 24, seed=50 + f))
+    frames = torch.from_numpy(np.stack(frames_np)).to(dev)
+    rows = torch.from_numpy(np.stack(rows_np)).to(dev)
+    outs = [torch.zeros(F, dtype=torch.int32, device=dev), torch.zeros(F * K, 4, device=dev),
+            torch.zeros(F * K, 98, 2, device=dev), torch.zeros(F * K, 98, device=dev)]
+
+    def run():
+        gpu_engine.run_frames_device(frames.data_ptr(), F, 1080, 1920, 0.5, 0.3, 1600.0, K, d_planted=rows.data_ptr(),
+                                     rows=15120, d_counts=outs[0].data_ptr(), d_boxes=outs[1].data_ptr(),
+                                     d_kps=outs[2].data_ptr(), d_scores=outs[3].data_ptr())
+        gpu_engine.sync()
+        return [o.clone() for o in outs]
+
+    eager = run()
+    gpu_engine.set_option(_native.PF_OPT_HIP_GRAPH, 1)
+    for _ in range(3):          # eager (first sighting), capture + launch, replay
+        got = run()
+        assert all(torch.equal(a, b) for a, b in zip(eager, got))
+    frames.copy_(torch.flip(frames, dims=[0]))      # new content, same buffers -> replay must see it
+    rows.copy_(torch.flip(rows, dims=[0]))
+    replay = run()
+    gpu_engine.set_option(_native.PF_OPT_HIP_GRAPH, 0)
+    again = run()
+    assert all(torch.equal(a, b) for a, b in zip(again, replay))
+    assert int(replay[0].sum()) == F * K
