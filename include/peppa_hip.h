@@ -94,7 +94,10 @@ int pf_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, in
 /* Same stages as pf_run_frames but detections are supplied by the caller (planted-candidate
  * protocol): det_rows is the decoded detector output [F][rows][16] in letterboxed
  * coordinates; everything downstream (xywh2xyxy, NMS, un-letterbox, top-k, landmarks) runs on
- * the device.  det_rows == NULL means "run the detector network" (== pf_run_frames). */
+ * the device.  det_rows lives where `frames` lives (host or device, per `mem`).  When a detector program
+ * is loaded, letterbox + detector network + decode still run (their cost stays in the call) and only their
+ * output is replaced by det_rows.  det_rows == NULL means "use the detector's own rows" (== pf_run_frames).
+ * Device-side outputs (out_mem == PF_MEM_DEVICE) are complete after pf_sync(). */
 int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
                           const float* det_rows, int rows, float score_thres, float iou_thres,
                           float min_face, int top_k,

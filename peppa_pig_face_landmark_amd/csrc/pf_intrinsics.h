@@ -23,8 +23,6 @@ __device__ __forceinline__ pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32
 }
 __device__ __forceinline__ float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
-__device__ __forceinline__ float pf_rcp(float x) { return 1.0f / x; }
-__device__ __forceinline__ float pf_exp(float x) { return __expf(x); }
 
 #define PF_BUILD_TAG "gfx950"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
