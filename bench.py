@@ -197,6 +197,14 @@ def main():
             json.dump({"steps": 3, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
                        "kernels": {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}, f, indent=1)
+    latency = None
+    if workload == "pipeline":
+        l1 = state.latency_p50(1)
+        lN = state.latency_p50(args.frames // lanes)
+        latency = {"single_frame_call_ms_p50": round(l1[0], 4), "single_frame_call_ms_p99": round(l1[1], 4),
+                   "lane_batch_call_ms_p50": round(lN[0], 4), "lane_batch_frames": args.frames // lanes,
+                   "ms_per_frame_p50_at_lane_batch": round(lN[0] / (args.frames // lanes), 4),
+                   "note": "synchronous pf_run_frames call on one stream, device-resident frames"}
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
@@ -215,6 +223,7 @@ def main():
         "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
                   "algorithmic_tflops": round(value * GFLOP_PER_FACE[args.model] / 1e3, 2),
                   "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE[args.model] / 1e3 / PEAK_TFLOPS[args.dtype], 4),
+                  "latency": latency,
                   "setup_s": round(setup_s, 2),
                   "kernel_ms_per_lane_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
     }

@@ -168,6 +168,22 @@ class PipelineWorkload:
                                    d_boxes=self.boxes.data_ptr(), d_kps=self.kps.data_ptr(),
                                    d_scores=self.scores.data_ptr())
 
+    def latency_p50(self, frames: int, reps: int = 40):
+        """p50 / p99 wall time (ms) of one synchronous call on `frames` frames (submit -> results complete)."""
+        import time
+        frames = min(frames, self.F)
+        ts = []
+        for _ in range(reps + 5):
+            t0 = time.perf_counter()
+            self.eng.run_frames_device(self.frames.data_ptr(), frames, self.H, self.W, 0.5, 0.3, 1600.0, self.K,
+                                       d_planted=self.rows.data_ptr(), rows=self.ROWS, d_counts=self.counts.data_ptr(),
+                                       d_boxes=self.boxes.data_ptr(), d_kps=self.kps.data_ptr(),
+                                       d_scores=self.scores.data_ptr())
+            self.eng.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = sorted(ts[5:])
+        return ts[len(ts) // 2], ts[min(len(ts) - 1, int(len(ts) * 0.99))]
+
     def check(self):
         import torch
         self.eng.sync()
@@ -207,6 +223,11 @@ class MultiLanePipeline:
         for wl in self.lanes:
             wl.eng.sync()
         return self.lanes[0].profile(steps)
+
+    def latency_p50(self, frames: int, reps: int = 40):
+        for wl in self.lanes:
+            wl.eng.sync()
+        return self.lanes[0].latency_p50(frames, reps)
 
     def close(self):
         for wl in self.lanes:
