@@ -10,10 +10,12 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "k_conv_gemm.h"
 #include "k_layers.h"
+#include "k_mbconv.h"
 #include "k_prepost.h"
 #include "pf_program.h"
 
@@ -233,6 +235,46 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "sepup_c%d_n%d_%dx%d", a.inC, a.N, to.H, to.W);
                     ProfScope ps(h, tagbuf);
                     PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 1>), grid, dim3(512), h->stream, a);
+                }
+                break;
+            }
+            case PF_OP_MBCONV: {
+                if constexpr (!std::is_same<T, float>::value) {
+                    PF_FAIL(h, "fused inverted-residual op needs f32 tensors (f32 / f32s program)");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    MbconvArgs a{};
+                    a.in = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.res = f[2] >= 0 ? (const float*)p.tensor_ptr(f[2]) : nullptr;
+                    a.resLd = f[2] >= 0 ? p.tens[f[2]].ld : 0;
+                    a.w_exp = (const float*)p.cptr(f[3]); a.b_exp = (const float*)p.cptr(f[4]);
+                    a.w_dw = (const float*)p.cptr(f[5]); a.b_dw = (const float*)p.cptr(f[6]);
+                    a.w_pwl = (const float*)p.cptr(f[7]); a.b_pwl = (const float*)p.cptr(f[8]);
+                    const int K = f[9], S = f[10], dil = f[12], CP = f[15];
+                    a.pad = f[11]; a.act = f[13]; a.MidPad = f[14]; a.CoutPad = f[16]; a.Cout = f[17];
+                    a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
+                    a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
+                    const bool wave_level = CP <= 32 && a.CoutPad <= 32 && K == 3 && dil == 1;   // ir.py pads Mid to 16 for these
+                    if (a.CoutPad > 80 || (a.MidPad % (wave_level ? 16 : 32)) || a.Cin > CP) PF_FAIL(h, "mbconv: unsupported channel counts");
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbconv_k%ds%d_c%d_m%d_n%d_%dx%d", K, S, a.Cin, a.MidPad, a.Cout, to.H, to.W);
+                    ProfScope ps(h, tagbuf);
+#define PF_MBCONV_CASE(KK, SS, DD, CPP, THH, TWW)                                                                    \
+    if (K == KK && S == SS && dil == DD && CP == CPP) {                                                               \
+        a.tilesX = pf_div_up(to.W, TWW);                                                                              \
+        PF_LAUNCH((mbconv_fused_kernel<KK, SS, DD, CPP, THH, TWW>), dim3(a.tilesX * pf_div_up(to.H, THH), B), dim3(512), h->stream, a); \
+    } else
+                    if (wave_level && S == 2 && CP == 16) {
+                        PF_LAUNCH((mbconv_wave_kernel<2, 16, 4, 4>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 4), 4), B), dim3(256), h->stream, a);
+                    } else if (wave_level && S == 1 && CP == 32) {
+                        PF_LAUNCH((mbconv_wave_kernel<1, 32, 4, 8>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
+                    } else
+                    PF_MBCONV_CASE(3, 2, 1, 48, 4, 16)
+                    PF_MBCONV_CASE(3, 1, 1, 80, 8, 16)
+                    PF_FAIL(h, "mbconv: no kernel for k%d s%d d%d cin_pad %d", K, S, dil, CP);
+#undef PF_MBCONV_CASE
                 }
                 break;
             }

@@ -24,5 +24,13 @@ __device__ __forceinline__ pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32
 __device__ __forceinline__ float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
 
+// Orders LDS traffic between the lanes of ONE wave (producer lanes write, other lanes read) without a
+// workgroup barrier: the wave issues its LDS instructions in order, so only the compiler has to be fenced.
+__device__ __forceinline__ void pf_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 #define PF_BUILD_TAG "gfx950"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

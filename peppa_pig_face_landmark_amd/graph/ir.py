@@ -17,14 +17,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 5
+VERSION = 6
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP = range(1, 14)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV = range(1, 15)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -232,6 +232,37 @@ class ProgramBuilder:
         woff = self.const_act(np.transpose(weight.astype(np.float64).reshape(c, k * k), (1, 0)))
         boff = self.const_f32(bias)
         self._op(OP_DW, [x, out, woff, boff, k, stride, pad, dil, ACT[act]], [self._tb(x)], [self._tb(out)])
+        return out
+
+    MBCONV_KERNELS = {(3, 2, 1, 16), (3, 1, 1, 32), (3, 2, 1, 48), (3, 1, 1, 80)}   # (K, stride, dil, CinPad) built in csrc/k_mbconv.h
+
+    def mbconv_supported(self, cin: int, k: int, stride: int, dil: int, cout: int) -> bool:
+        return self.esize == 4 and (k, stride, dil, _round_up(cin, 16)) in self.MBCONV_KERNELS and cout <= 80
+
+    def mbconv(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray,
+               w_pwl: np.ndarray, b_pwl: np.ndarray, act: str, *, stride: int, pad: int, dil: int = 1,
+               res: int = -1, out_name: str = "") -> int:
+        """Whole inverted-residual block (expand 1x1 -> depthwise kxk -> project 1x1 [+ x]) in one launch;
+        weights BN-folded: w_exp [Mid,Cin,1,1], w_dw [Mid,1,K,K], w_pwl [Cout,Mid,1,1]."""
+        ti = self.tensors[x]
+        mid, cin = w_exp.shape[:2]
+        cout, k = w_pwl.shape[0], w_dw.shape[2]
+        assert cin == ti.real_c == ti.C and w_dw.shape == (mid, 1, k, k) and w_pwl.shape[1] == mid
+        assert self.mbconv_supported(cin, k, stride, dil, cout)
+        oh = (ti.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        ow = (ti.W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        out = self.tensor(oh, ow, cout, name=out_name)
+        cp, coutp = _round_up(cin, 16), _round_up(cout, 16)
+        midp = _round_up(mid, 16 if (cp <= 32 and coutp <= 32) else 32)   # wave-level kernel: 16-channel chunks
+        we = np.zeros((midp, cp)); we[:mid, :cin] = w_exp.reshape(mid, cin)
+        be = np.zeros(midp); be[:mid] = b_exp
+        wd = np.zeros((k * k, midp)); wd[:, :mid] = w_dw.reshape(mid, k * k).T
+        bd = np.zeros(midp); bd[:mid] = b_dw
+        wp = np.zeros((coutp, midp)); wp[:cout, :mid] = w_pwl.reshape(cout, mid)
+        bp = np.zeros(coutp); bp[:cout] = b_pwl
+        self._op(OP_MBCONV, [x, out, res, self.const_f32(we), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
+                             self.const_f32(wp), self.const_f32(bp), k, stride, pad, dil, ACT[act], midp, cp, coutp, cout],
+                 [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
     def upcat(self, lo: int, skip: int, out_name: str = "") -> int:

@@ -120,7 +120,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 
 
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
-                          keep_all: bool = False, debug_full_hm: bool = False):
+                          keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
@@ -151,6 +151,12 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
+            elif fuse_mbconv and not se and pb.mbconv_supported(cin, k, s, cur_dil, cout):
+                we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
+                wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
+                wl, bl = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
+                x = pb.mbconv(x, we, be, wd, bd, wl, bl, act, stride=s, pad=pad, dil=cur_dil,
+                              res=inp if skip else -1, out_name=f"{p}.out")
             else:
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
                 x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")

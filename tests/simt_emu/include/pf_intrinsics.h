@@ -65,5 +65,7 @@ inline pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
 inline float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 inline int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
 
+inline void pf_wave_sync() { pf_emu::wave_barrier(); }
+
 #define PF_BUILD_TAG "simt-emu"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
