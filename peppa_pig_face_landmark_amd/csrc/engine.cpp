@@ -248,32 +248,32 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.in = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
                     a.res = f[2] >= 0 ? (const float*)p.tensor_ptr(f[2]) : nullptr;
                     a.resLd = f[2] >= 0 ? p.tens[f[2]].ld : 0;
-                    a.w_exp = (const float*)p.cptr(f[3]); a.b_exp = (const float*)p.cptr(f[4]);
+                    a.w_exp = (const pf_half*)p.cptr(f[3]); a.b_exp = (const float*)p.cptr(f[4]);
                     a.w_dw = (const float*)p.cptr(f[5]); a.b_dw = (const float*)p.cptr(f[6]);
-                    a.w_pwl = (const float*)p.cptr(f[7]); a.b_pwl = (const float*)p.cptr(f[8]);
-                    const int K = f[9], S = f[10], dil = f[12], CP = f[15];
-                    a.pad = f[11]; a.act = f[13]; a.MidPad = f[14]; a.CoutPad = f[16]; a.Cout = f[17];
+                    a.w_pwl = (const pf_half*)p.cptr(f[7]); a.b_pwl = (const float*)p.cptr(f[8]);
+                    const int K = f[9], S = f[10], dil = f[12], KS = f[15];
+                    a.pad = f[11]; a.act = f[13]; a.MidPad = f[14]; a.CoutPad = f[16]; a.Cout = f[17]; a.Mid16 = f[18];
+                    memcpy(&a.scale_exp, &f[19], 4); memcpy(&a.scale_pwl, &f[20], 4);
                     a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
-                    const bool wave_level = CP <= 32 && a.CoutPad <= 32 && K == 3 && dil == 1;   // ir.py pads Mid to 16 for these
-                    if (a.CoutPad > 80 || (a.MidPad % (wave_level ? 16 : 32)) || a.Cin > CP) PF_FAIL(h, "mbconv: unsupported channel counts");
+                    if ((a.MidPad % 32) || (a.Cin % 8) || a.Cin > 32 * KS || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
+                    if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "mbconv: activation must be relu or hard-swish");
                     char tagbuf[96];
                     tagbuf[0] = 0;
-                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbconv_k%ds%d_c%d_m%d_n%d_%dx%d", K, S, a.Cin, a.MidPad, a.Cout, to.H, to.W);
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbconv_k%ds%d_c%d_m%d_n%d_%dx%d", K, S, a.Cin, a.Mid16, a.Cout, to.H, to.W);
                     ProfScope ps(h, tagbuf);
-#define PF_MBCONV_CASE(KK, SS, DD, CPP, THH, TWW)                                                                    \
-    if (K == KK && S == SS && dil == DD && CP == CPP) {                                                               \
-        a.tilesX = pf_div_up(to.W, TWW);                                                                              \
-        PF_LAUNCH((mbconv_fused_kernel<KK, SS, DD, CPP, THH, TWW>), dim3(a.tilesX * pf_div_up(to.H, THH), B), dim3(512), h->stream, a); \
+                    // (stride, Cin/32, Cout/16) -> patch shape and mid-channel split; low-resolution blocks use MSPLIT = 4
+#define PF_MBCONV_CASE(SS, KSS, PHH, PWW, NTT, MS)                                                                \
+    if (S == SS && KS == KSS && a.CoutPad <= 16 * NTT) {                                                           \
+        const int patches = pf_div_up(to.H, PHH) * pf_div_up(to.W, PWW);                                           \
+        PF_LAUNCH((mbconv_wave_kernel<SS, KSS, PHH, PWW, NTT, MS>),                                                \
+                  dim3(MS > 1 ? patches : pf_div_up(patches, 4), B), dim3(256), h->stream, a);                     \
     } else
-                    if (wave_level && S == 2 && CP == 16) {
-                        PF_LAUNCH((mbconv_wave_kernel<2, 16, 4, 4>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 4), 4), B), dim3(256), h->stream, a);
-                    } else if (wave_level && S == 1 && CP == 32) {
-                        PF_LAUNCH((mbconv_wave_kernel<1, 32, 4, 8>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
-                    } else
-                    PF_MBCONV_CASE(3, 2, 1, 48, 4, 16)
-                    PF_MBCONV_CASE(3, 1, 1, 80, 8, 16)
-                    PF_FAIL(h, "mbconv: no kernel for k%d s%d d%d cin_pad %d", K, S, dil, CP);
+                    PF_MBCONV_CASE(2, 1, 4, 4, 2, 1)
+                    PF_MBCONV_CASE(1, 1, 4, 8, 2, 1)
+                    PF_MBCONV_CASE(2, 2, 4, 4, 5, 4)
+                    PF_MBCONV_CASE(1, 3, 4, 8, 5, 4)
+                    PF_FAIL(h, "mbconv: no kernel for stride %d, %d input channels, %d output channels", S, a.Cin, a.Cout);
 #undef PF_MBCONV_CASE
                 }
                 break;

@@ -110,8 +110,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
                 for (int r = 0; r < 4; ++r)
                     if (n + r < a.N) v[r] += (float)res[(size_t)m * a.resLd + n + r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = pf_act(v[r], a.act);
+            pf_act_n<4>(v, a.act);
             if (want_amax && mok) {
                 const int local = m - b * OHW;
 #pragma unroll

@@ -65,11 +65,12 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
     }
     T* o = static_cast<T*>(a.out) + (size_t)idx * a.outLd + g0;
     constexpr int VE = PfVec<T>::N;
+    pf_act_n<CO>(acc, a.act);
 #pragma unroll
     for (int v = 0; v < CO / VE; ++v) {
         typename PfVec<T>::type pk;
 #pragma unroll
-        for (int e = 0; e < VE; ++e) pk[e] = (T)pf_act(acc[v * VE + e], a.act);
+        for (int e = 0; e < VE; ++e) pk[e] = (T)acc[v * VE + e];
         pf_stv<T>(o + v * VE, pk);
     }
 }
@@ -115,8 +116,9 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(DwArgs a) {
         }
     }
     vec_t o;
+    pf_act_n<VE>(acc, a.act);
 #pragma unroll
-    for (int e = 0; e < VE; ++e) o[e] = (T)pf_act(acc[e], a.act);
+    for (int e = 0; e < VE; ++e) o[e] = (T)acc[e];
     pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
 }
 
@@ -545,11 +547,13 @@ __global__ __launch_bounds__(256) void dw_conv_tiled_kernel(DwArgs a) {
     }
     T* out = static_cast<T*>(a.out) + ((size_t)(b * a.outH + oy) * a.outW) * a.outLd + cv * VE;
 #pragma unroll
+    for (int j = 0; j < TX; ++j) pf_act_n<VE>(acc[j], a.act);
+#pragma unroll
     for (int j = 0; j < TX; ++j) {
         if (ox0 + j < a.outW) {
             vec_t o;
 #pragma unroll
-            for (int e = 0; e < VE; ++e) o[e] = (T)pf_act(acc[j][e], a.act);
+            for (int e = 0; e < VE; ++e) o[e] = (T)acc[j][e];
             pf_stv<T>(out + (size_t)(ox0 + j) * a.outLd, o);
         }
     }
@@ -582,8 +586,12 @@ __global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
     const int lh = a.H >> a.shift, lw = a.W >> a.shift;
     const vec_t va = pf_ldv<T>(static_cast<const T*>(a.a) + (size_t)pix * a.aLd + cv * VE);
     const vec_t vb = pf_ldv<T>(static_cast<const T*>(a.b) + ((size_t)(b * lh + (y >> a.shift)) * lw + (x >> a.shift)) * a.bLd + cv * VE);
+    float sum[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) sum[e] = (float)va[e] + (float)vb[e];
+    pf_act_n<VE>(sum, a.act);
     vec_t o;
 #pragma unroll
-    for (int e = 0; e < VE; ++e) o[e] = (T)pf_act((float)va[e] + (float)vb[e], a.act);
+    for (int e = 0; e < VE; ++e) o[e] = (T)sum[e];
     pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
 }

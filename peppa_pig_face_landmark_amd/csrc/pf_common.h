@@ -20,14 +20,48 @@ template <> struct PfVec<float> {
     typedef pf_f32x4 type;
 };
 
+template <int ACT> __device__ __forceinline__ float pf_act_c(float v) {
+    if constexpr (ACT == PF_ACT_RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (ACT == PF_ACT_HSWISH || ACT == PF_ACT_HSIGMOID) {
+        // x * relu6(x + 3) / 6 with the division as a multiplication (onnxruntime's HardSigmoid alpha = 1/6 form)
+        float r = v + 3.f;
+        r = (r < 0.f ? 0.f : (r > 6.f ? 6.f : r)) * (1.f / 6.f);
+        return ACT == PF_ACT_HSWISH ? v * r : r;
+    } else if constexpr (ACT == PF_ACT_SILU) return v / (1.f + expf(-v));
+    else if constexpr (ACT == PF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    else return v;
+}
+
+// one value, activation known only at run time (cold paths; folds when `act` is a literal)
 __device__ __forceinline__ float pf_act(float v, int act) {
     switch (act) {
-        case PF_ACT_RELU: return v > 0.f ? v : 0.f;
-        case PF_ACT_HSWISH: { float r = v + 3.f; r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r); return v * r / 6.f; }
-        case PF_ACT_SILU: return v / (1.f + expf(-v));
-        case PF_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        case PF_ACT_HSIGMOID: { float r = v + 3.f; r = r < 0.f ? 0.f : (r > 6.f ? 6.f : r); return r / 6.f; }
+        case PF_ACT_RELU: return pf_act_c<PF_ACT_RELU>(v);
+        case PF_ACT_HSWISH: return pf_act_c<PF_ACT_HSWISH>(v);
+        case PF_ACT_SILU: return pf_act_c<PF_ACT_SILU>(v);
+        case PF_ACT_SIGMOID: return pf_act_c<PF_ACT_SIGMOID>(v);
+        case PF_ACT_HSIGMOID: return pf_act_c<PF_ACT_HSIGMOID>(v);
         default: return v;
+    }
+}
+
+// N values behind ONE scalar branch on the (wave-uniform) kernel argument.  The empty asm statements keep
+// the compiler from flattening the switch into "evaluate every activation, then select", which used to put
+// an expf and two IEEE divisions behind every output element of every epilogue.
+template <int N, typename V> __device__ __forceinline__ void pf_act_n(V& v, int act) {
+    switch (act) {
+        case PF_ACT_NONE: break;
+#define PF_ACT_CASE(A)                                            \
+    case A:                                                       \
+        asm volatile("");                                         \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) v[i] = pf_act_c<A>(v[i]); \
+        break;
+        PF_ACT_CASE(PF_ACT_RELU)
+        PF_ACT_CASE(PF_ACT_HSWISH)
+        PF_ACT_CASE(PF_ACT_SILU)
+        PF_ACT_CASE(PF_ACT_SIGMOID)
+        PF_ACT_CASE(PF_ACT_HSIGMOID)
+#undef PF_ACT_CASE
+        default: break;
     }
 }
 

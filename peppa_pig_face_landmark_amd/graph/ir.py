@@ -234,16 +234,30 @@ class ProgramBuilder:
         self._op(OP_DW, [x, out, woff, boff, k, stride, pad, dil, ACT[act]], [self._tb(x)], [self._tb(out)])
         return out
 
-    MBCONV_KERNELS = {(3, 2, 1, 16), (3, 1, 1, 32), (3, 2, 1, 48), (3, 1, 1, 80)}   # (K, stride, dil, CinPad) built in csrc/k_mbconv.h
+    MBCONV_KERNELS = {(2, 1, 2), (1, 1, 2), (2, 2, 5), (1, 3, 5)}   # (stride, Cin/32, Cout/16 max) built in csrc/k_mbconv.h
 
     def mbconv_supported(self, cin: int, k: int, stride: int, dil: int, cout: int) -> bool:
-        return self.esize == 4 and (k, stride, dil, _round_up(cin, 16)) in self.MBCONV_KERNELS and cout <= 80
+        if self.esize != 4 or k != 3 or dil != 1 or cin % 8:
+            return False
+        return any(s == stride and ks == _round_up(cin, 32) // 32 and cout <= 16 * nt for s, ks, nt in self.MBCONV_KERNELS)
+
+    @staticmethod
+    def _split_rows(w: np.ndarray) -> Tuple[np.ndarray, float]:
+        """[rows][K] (K % 32 == 0) float64 -> ([rows][K/32][hi 32 | lo 32] f16 of w * 2^s, 2^-s)."""
+        rows, k = w.shape
+        wmax = float(np.abs(w).max())
+        s = 0 if wmax == 0.0 else int(np.floor(np.log2(16384.0 / wmax)))
+        ws = (w * (2.0 ** s)).astype(np.float32)
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        blocks = np.stack([hi.reshape(rows, k // 32, 32), lo.reshape(rows, k // 32, 32)], axis=2)
+        return np.ascontiguousarray(blocks), float(2.0 ** (-s))
 
     def mbconv(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray,
                w_pwl: np.ndarray, b_pwl: np.ndarray, act: str, *, stride: int, pad: int, dil: int = 1,
                res: int = -1, out_name: str = "") -> int:
-        """Whole inverted-residual block (expand 1x1 -> depthwise kxk -> project 1x1 [+ x]) in one launch;
-        weights BN-folded: w_exp [Mid,Cin,1,1], w_dw [Mid,1,K,K], w_pwl [Cout,Mid,1,1]."""
+        """Whole inverted-residual block (expand 1x1 -> depthwise 3x3 -> project 1x1 [+ x]) in one launch;
+        weights BN-folded: w_exp [Mid,Cin,1,1], w_dw [Mid,1,3,3], w_pwl [Cout,Mid,1,1]."""
         ti = self.tensors[x]
         mid, cin = w_exp.shape[:2]
         cout, k = w_pwl.shape[0], w_dw.shape[2]
@@ -252,16 +266,19 @@ class ProgramBuilder:
         oh = (ti.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         ow = (ti.W + 2 * pad - dil * (k - 1) - 1) // stride + 1
         out = self.tensor(oh, ow, cout, name=out_name)
-        cp, coutp = _round_up(cin, 16), _round_up(cout, 16)
-        midp = _round_up(mid, 16 if (cp <= 32 and coutp <= 32) else 32)   # wave-level kernel: 16-channel chunks
+        mid16, midp, cp, coutp = _round_up(mid, 16), _round_up(mid, 32), _round_up(cin, 32), _round_up(cout, 16)
         we = np.zeros((midp, cp)); we[:mid, :cin] = w_exp.reshape(mid, cin)
         be = np.zeros(midp); be[:mid] = b_exp
         wd = np.zeros((k * k, midp)); wd[:, :mid] = w_dw.reshape(mid, k * k).T
         bd = np.zeros(midp); bd[:mid] = b_dw
         wp = np.zeros((coutp, midp)); wp[:cout, :mid] = w_pwl.reshape(cout, mid)
         bp = np.zeros(coutp); bp[:cout] = b_pwl
-        self._op(OP_MBCONV, [x, out, res, self.const_f32(we), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
-                             self.const_f32(wp), self.const_f32(bp), k, stride, pad, dil, ACT[act], midp, cp, coutp, cout],
+        we_s, se = self._split_rows(we)
+        wp_s, sp = self._split_rows(wp)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        self._op(OP_MBCONV, [x, out, res, self.const(we_s), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
+                             self.const(wp_s), self.const_f32(bp), k, stride, pad, dil, ACT[act], midp, cp // 32, coutp, cout,
+                             mid16, fbits(se), fbits(sp)],
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
