@@ -278,6 +278,37 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 }
                 break;
             }
+            case PF_OP_EXPDW: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused expand+depthwise op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    ConvGemmArgs a{};
+                    a.in = p.tensor_ptr(f[0]); a.out = p.tensor_ptr(f[1]);
+                    a.gap_out = f[2] >= 0 ? (float*)p.buf_ptr(f[2]) : nullptr;
+                    a.wt = p.cptr(f[3]); a.bias = (const float*)p.cptr(f[4]);
+                    a.dw_w2 = (const float*)p.cptr(f[5]); a.dw_b = (const float*)p.cptr(f[6]);
+                    const int K = f[7], pad = f[8], dil = f[9];
+                    a.act = f[10]; a.Cpad = f[11]; a.Npad = f[12]; a.N = f[13]; memcpy(&a.acc_scale, &f[14], 4);
+                    a.B = B; a.inH = ti.H; a.inW = ti.W; a.inC = ti.C; a.inLd = ti.ld;
+                    a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
+                    a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
+                    const int ohw = to.H * to.W;
+                    if (ti.H != to.H || ti.W != to.W || to.W > 16 || (256 % ohw) != 0 || 256 / ohw > 4 || pad != dil * (K - 1) / 2 || to.C != a.N)
+                        PF_FAIL(h, "expdw: unsupported shape (%dx%d, k%d pad %d dil %d)", to.H, to.W, K, pad, dil);
+                    dim3 grid(pf_div_up(B * ohw, 256), pf_div_up(a.N, 64));
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "expdw%dx%dd%d_c%d_n%d_%dx%d", K, K, dil, a.inC, a.N, to.H, to.W);
+                    ProfScope ps(h, tagbuf);
+                    if (K == 3 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 3, 1>), grid, dim3(512), h->stream, a);
+                    else if (K == 5 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 1>), grid, dim3(512), h->stream, a);
+                    else if (K == 5 && dil == 2) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 2>), grid, dim3(512), h->stream, a);
+                    else PF_FAIL(h, "expdw: no kernel for k%d dil %d", K, dil);
+                }
+                break;
+            }
             case PF_OP_DW: {
                 const PfTensorRec& ti = p.tens[f[0]];
                 const PfTensorRec& to = p.tens[f[1]];

@@ -49,6 +49,9 @@ struct ConvGemmArgs {
     const float* dw_w2;   // [9][C2] plain depthwise weights of the skip channels (BN folded)
     const float* dw_b;    // [C1+C2]
     int loH, loW, C1, loLd, skipLd;
+    // fused "pointwise expand -> depthwise kxk" (EPI != 0 kernels): dw_w2 = [K*K][N] depthwise weights, dw_b = [N]
+    // bias, both BN folded; the depthwise output goes to `out`, its per-face channel means (SE squeeze) to gap_out
+    float* gap_out;       // [B][N] or nullptr
 };
 
 template <typename T> struct ConvMma;
@@ -317,6 +320,112 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     conv_gemm_epilogue<T, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, 1.0f);
 }
 
+// ---- fused depthwise epilogue (MobileNetV3 inverted residual, expand -> depthwise, model.py:252-264) -------
+// The workgroup's BM pixels are BM / (H*W) WHOLE images (host guarantees H*W divides BM, W <= 16), so the
+// expanded tile act(acc) can stay in LDS and the k x k depthwise conv (+bias, act) reads it from there:
+// the expanded tensor -- the largest one of the block -- never exists in HBM.  Thread = (channel, image row):
+// per filter row it loads the W-pixel input row once and slides the filter along it in registers.  Also
+// emits the per-face channel means of the depthwise output (the SE squeeze), complete because a workgroup
+// owns whole images.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int K, int DIL>
+__device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (&acc)[BN / WARPS_N / 16][BM / WARPS_M / 16],
+                                               unsigned char* smem, int m0, int n0, int wm, int wn, int t, int M) {
+    constexpr int NTHR = WARPS_M * WARPS_N * 64;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int ES = BN + 4;                 // E row stride (floats)
+    constexpr int NG = NTHR / BN;              // row groups
+    constexpr int MAXF = 4;                    // images per workgroup
+    constexpr int PAD = DIL * (K - 1) / 2;
+    constexpr int MAXW = 16;
+    static_assert(NTHR % BN == 0, "thread = (channel, row group)");
+    float* es = reinterpret_cast<float*>(smem);          // [BM][ES]
+    float* sums = es + BM * ES;                           // [NG][MAXF][BN]
+    const int lane = t & 63;
+    const int pcol = lane & 15, crow = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int nl = wn * WN + j * 16 + crow;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (n0 + nl + r < a.Npad) ? a.bias[n0 + nl + r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            pf_f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[j][i][r], a.acc_scale, bv[r]);
+            pf_act_n<4>(v, a.act);
+            *reinterpret_cast<pf_f32x4*>(es + (wm * WM + i * 16 + pcol) * ES + nl) = v;
+        }
+    }
+    __syncthreads();
+    const int W = a.outW, H = a.outH, OHW = H * W;
+    const int rows = BM / W;
+    const int c = t % BN, g = t / BN;
+    const int n = n0 + c;
+    const bool cok = n < a.N;
+    float wk[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
+    const float bd = cok ? a.dw_b[n] : 0.f;
+    float fsum[MAXF];
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) fsum[f] = 0.f;
+    float* out = static_cast<float*>(a.out);
+    for (int r = g; r < rows; r += NG) {
+        const int f = r / H, y = r - f * H;
+        float o[MAXW];
+#pragma unroll
+        for (int x = 0; x < MAXW; ++x) o[x] = bd;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = y + ky * DIL - PAD;
+            if ((unsigned)yy >= (unsigned)H) continue;
+            const float* erow = es + ((f * H + yy) * W) * ES + c;
+            float in[MAXW];
+#pragma unroll
+            for (int x = 0; x < MAXW; ++x) in[x] = x < W ? erow[x * ES] : 0.f;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const float w = wk[ky * K + kx];
+#pragma unroll
+                for (int x = 0; x < MAXW; ++x) {
+                    const int xx = x + kx * DIL - PAD;       // compile-time register index
+                    if (xx >= 0 && xx < MAXW) o[x] = fmaf(w, in[xx], o[x]);   // in[xx] is 0 beyond the image width
+                }
+            }
+        }
+        pf_act_n<MAXW>(o, a.act);
+        const int m = m0 + r * W;                             // first pixel of the row
+        if (cok && m < M) {
+            float rs = 0.f;
+#pragma unroll
+            for (int x = 0; x < MAXW; ++x)
+                if (x < W) {
+                    out[(size_t)(m + x) * a.outLd + n] = o[x];
+                    rs += o[x];
+                }
+#pragma unroll
+            for (int ff = 0; ff < MAXF; ++ff)
+                if (ff == f) fsum[ff] += rs;
+        }
+    }
+    if (a.gap_out) {
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) sums[(g * MAXF + f) * BN + c] = fsum[f];
+        __syncthreads();
+        const int faces = BM / OHW;
+        if (t < faces * BN) {
+            const int f = t / BN, cc = t - f * BN;
+            float tot = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < NG; ++gg) tot += sums[(gg * MAXF + f) * BN + cc];
+            const int b = m0 / OHW + f;
+            if (b < a.B && n0 + cc < a.N) a.gap_out[(size_t)b * a.N + n0 + cc] = tot / (float)OHW;
+        }
+    }
+}
+
 // =============================================================================================
 // Split-precision variant: f32 tensors in HBM, f16 matrix cores, f32-grade results.
 //
@@ -333,9 +442,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // STAGE = 0: the pixel operand is read from a.in.  STAGE = 1 (pointwise only): it is produced on the
 // fly -- bilinear x2 upsample of up_lo / pass-through of up_skip, depthwise 3x3 (+bias) -- so the
 // concatenated and the depthwise tensors never exist in HBM.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
-    // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves)
+// EPI_K != 0 (pointwise only): the epilogue is the fused depthwise EPI_K x EPI_K conv (dilation EPI_DIL) above.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, EPI_K ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+    // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves);
+    // the fused-depthwise variants keep an 80 KB tile in LDS (one workgroup per CU) and may use 256
     constexpr int NTHR = WARPS_M * WARPS_N * 64;       // 256 or 512 threads (8 waves hide the staging latency)
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -562,7 +673,13 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         if (more) store_tile(cur ^ 1);
         __syncthreads();
     }
-    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
+    if constexpr (EPI_K != 0) {
+        static_assert(KS == 1 && STAGE == 0, "fused depthwise epilogue: pointwise expand only");
+        static_assert(2 * STAGE_BYTES >= (BM * (BN + 4) + (NTHR / BN) * 4 * BN) * 4, "E tile must fit the staging LDS");
+        expdw_epilogue<BM, BN, WARPS_M, WARPS_N, EPI_K, EPI_DIL>(a, acc, smem, m0, n0, wm, wn, t, M);   // loop ended on a barrier
+    } else {
+        conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
+    }
 }
 
 // Tile configurations (BM x BN, waves M x N) picked by the host from the padded channel count.

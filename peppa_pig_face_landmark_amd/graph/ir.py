@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV = range(1, 15)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW = range(1, 16)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -174,12 +174,12 @@ class ProgramBuilder:
     def conv_uses_split(self, cin: int, taps: int = 1) -> bool:
         return self.split and (cin >= self.SPLIT_MIN_CIN or (taps > 1 and cin >= self.SPLIT_MIN_CIN_KXK))
 
-    def pack_conv_weight(self, weight: np.ndarray) -> Tuple[int, int, int, float, bool]:
+    def pack_conv_weight(self, weight: np.ndarray, force_split: bool = False) -> Tuple[int, int, int, float, bool]:
         """[N,Cin,KH,KW] -> (const offset, Npad, Cpad, acc_scale, use_split).
         direct kernels: [Npad][KH*KW][Cpad] in the activation dtype (64-byte K steps), acc_scale 1;
         split kernels : [Npad][KH*KW][Cpad/32][hi 32 x f16 | lo 32 x f16] of w * 2^s, acc_scale 2^-s."""
         n, cin, kh, kw = weight.shape
-        use_split = self.conv_uses_split(cin, kh * kw)
+        use_split = force_split or self.conv_uses_split(cin, kh * kw)
         ke = 32 if use_split else 64 // self.esize
         npad, cpad = _round_up(n, 16), _round_up(cin, ke)
         w = np.zeros((npad, kh * kw, cpad), np.float64)
@@ -281,6 +281,31 @@ class ProgramBuilder:
                              mid16, fbits(se), fbits(sp)],
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
+
+    def expdw_supported(self, H: int, W: int, k: int, stride: int, pad: int, dil: int) -> bool:
+        ohw = H * W
+        return (self.split and stride == 1 and W <= 16 and 256 % ohw == 0 and 256 // ohw <= 4
+                and (k, dil) in ((3, 1), (5, 1), (5, 2)) and pad == dil * (k - 1) // 2)
+
+    def expdw(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray, act: str, *,
+              pad: int, dil: int = 1, want_gap: bool = False, out_name: str = "") -> Tuple[int, int]:
+        """Pointwise expand + depthwise kxk (+BN, act each) in one launch; the expanded tensor stays in LDS.
+        Returns (depthwise output tensor, buffer with its per-face channel means or -1)."""
+        ti = self.tensors[x]
+        mid, cin = w_exp.shape[:2]
+        k = w_dw.shape[2]
+        assert cin == ti.real_c and w_dw.shape == (mid, 1, k, k) and mid % self.ve == 0
+        assert self.expdw_supported(ti.H, ti.W, k, 1, pad, dil)
+        out = self.tensor(ti.H, ti.W, mid, name=out_name)
+        woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(w_exp, force_split=True)
+        be = np.zeros(npad, np.float64)
+        be[:mid] = b_exp
+        gap = self.buffer(mid, ELEM_F32, "gap") if want_gap else -1
+        wd = np.transpose(w_dw.astype(np.float64).reshape(mid, k * k), (1, 0))
+        self._op(OP_EXPDW, [x, out, gap, woff, self.const_f32(be), self.const_f32(wd), self.const_f32(b_dw), k, pad, dil,
+                            ACT[act], cpad, npad, mid, struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
+                 [self._tb(x)], [self._tb(out), gap])
+        return out, gap
 
     def upcat(self, lo: int, skip: int, out_name: str = "") -> int:
         tl, ts = self.tensors[lo], self.tensors[skip]

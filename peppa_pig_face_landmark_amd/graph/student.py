@@ -158,13 +158,21 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 x = pb.mbconv(x, we, be, wd, bd, wl, bl, act, stride=s, pad=pad, dil=cur_dil,
                               res=inp if skip else -1, out_name=f"{p}.out")
             else:
-                wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
-                x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")
-                wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
-                x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
+                ti = pb.tensors[x]
+                pooled = -1
+                if fuse_mbconv and pb.expdw_supported(ti.H, ti.W, k, s, pad, cur_dil):
+                    we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
+                    wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
+                    x, pooled = pb.expdw(x, we, be, wd, bd, act, pad=pad, dil=cur_dil, want_gap=bool(se), out_name=f"{p}.dw")
+                else:
+                    wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
+                    x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")
+                    wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
+                    x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 gate = -1
                 if se:
-                    pooled = pb.gap(x)
+                    if pooled < 0:
+                        pooled = pb.gap(x)
                     rd = w[f"{p}.se.conv_reduce.weight"]
                     ex = w[f"{p}.se.conv_expand.weight"]
                     hid = pb.fc(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu")
