@@ -366,7 +366,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.K = f[4]; a.N = f[5]; a.act = f[6];
                 a.scale2 = (const float*)p.cptr(f[7]); a.shift2 = (const float*)p.cptr(f[8]); a.act2 = f[9];
                 ProfScope ps(h, "fc");
-                PF_LAUNCH(fc_kernel, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
+                if (a.K <= PF_FC_MAXK) PF_LAUNCH(fc_kernel<true>, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
+                else PF_LAUNCH(fc_kernel<false>, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
                 break;
             }
             case PF_OP_SCSE: {

@@ -343,6 +343,13 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
     float* sums = es + BM * ES;                           // [NG][MAXF][BN]
     const int lane = t & 63;
     const int pcol = lane & 15, crow = (lane >> 4) * 4;
+    const int c = t % BN, g = t / BN;
+    const int n = n0 + c;
+    const bool cok = n < a.N;
+    float wk[K * K];                           // requested before the E tile is written: the loads overlap it
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
+    const float bd = cok ? a.dw_b[n] : 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int nl = wn * WN + j * 16 + crow;
@@ -361,13 +368,6 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
     __syncthreads();
     const int W = a.outW, H = a.outH, OHW = H * W;
     const int rows = BM / W;
-    const int c = t % BN, g = t / BN;
-    const int n = n0 + c;
-    const bool cok = n < a.N;
-    float wk[K * K];
-#pragma unroll
-    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
-    const float bd = cok ? a.dw_b[n] : 0.f;
     float fsum[MAXF];
 #pragma unroll
     for (int f = 0; f < MAXF; ++f) fsum[f] = 0.f;
@@ -394,6 +394,7 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
                     if (xx >= 0 && xx < MAXW) o[x] = fmaf(w, in[xx], o[x]);   // in[xx] is 0 beyond the image width
                 }
             }
+            asm volatile("" ::: "memory");       // one filter row's LDS reads in flight at a time (register footprint)
         }
         pf_act_n<MAXW>(o, a.act);
         const int m = m0 + r * W;                             // first pixel of the row
@@ -444,7 +445,7 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
 // concatenated and the depthwise tensors never exist in HBM.
 // EPI_K != 0 (pointwise only): the epilogue is the fused depthwise EPI_K x EPI_K conv (dilation EPI_DIL) above.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, EPI_K ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
     // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves);
     // the fused-depthwise variants keep an 80 KB tile in LDS (one workgroup per CU) and may use 256
     constexpr int NTHR = WARPS_M * WARPS_N * 64;       // 256 or 512 threads (8 waves hide the staging latency)

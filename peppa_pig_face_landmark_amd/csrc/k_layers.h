@@ -228,11 +228,18 @@ struct FcArgs {
 // items (consecutive lanes -> consecutive n, coalesced); x is staged through LDS and read as float4.
 #define PF_FC_BN 64
 #define PF_FC_BB 16
+#define PF_FC_MAXK 1024   // largest K staged whole (64 KB of LDS)
 #define PF_FC_KT 128
+// WHOLE_K: the 16 input vectors are staged in LDS once for all of K (K <= PF_FC_MAXK), so the k loop has
+// no barrier and the weight loads pipeline freely -- the SE bottleneck FCs (K up to 960, 64-240 blocks in
+// flight) were pure load-latency chains with the tile-by-tile version.  Same k -> thread assignment and
+// summation order in both variants.
+template <bool WHOLE_K>
 __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
-    __shared__ __attribute__((aligned(16))) float smem[PF_FC_BB * PF_FC_KT + 4 * PF_FC_BB * PF_FC_BN];
-    float(*xs)[PF_FC_KT] = reinterpret_cast<float(*)[PF_FC_KT]>(smem);
-    float* red = smem + PF_FC_BB * PF_FC_KT;   // [4 k-slices][16 items][64 outputs]
+    constexpr int XK = WHOLE_K ? PF_FC_MAXK : PF_FC_KT;
+    __shared__ __attribute__((aligned(16))) float smem[PF_FC_BB * XK + 4 * PF_FC_BB * PF_FC_BN];
+    float(*xs)[XK] = reinterpret_cast<float(*)[XK]>(smem);
+    float* red = smem + PF_FC_BB * XK;   // [4 k-slices][16 items][64 outputs]
     const int t = threadIdx.x;
     const int nl = t & (PF_FC_BN - 1);
     const int ks = t >> 6;
@@ -242,27 +249,52 @@ __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
     float acc[PF_FC_BB];
 #pragma unroll
     for (int i = 0; i < PF_FC_BB; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
-        for (int i = t; i < PF_FC_BB * PF_FC_KT; i += 256) {
-            const int bb = i / PF_FC_KT, kk = i - bb * PF_FC_KT;
-            xs[bb][kk] = (b0 + bb < a.B && k0 + kk < a.K) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
-        }
-        __syncthreads();
-        if (nok) {
-#pragma unroll 2
-            for (int kk = ks * 32; kk < ks * 32 + 32; kk += 4) {
-                float wv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wv[j] = (k0 + kk + j < a.K) ? a.wt[(size_t)(k0 + kk + j) * a.N + n] : 0.f;
-#pragma unroll
-                for (int i = 0; i < PF_FC_BB; ++i) {
-                    const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[i][kk]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i] = fmaf(wv[j], xv[j], acc[i]);
-                }
+    const int kround = (a.K + PF_FC_KT - 1) / PF_FC_KT * PF_FC_KT;
+    if constexpr (WHOLE_K) {
+        if ((a.K & 3) == 0) {                  // 16-byte loads, 4 per thread in flight
+            const int k4 = kround / 4;
+#pragma unroll 4
+            for (int i = t; i < PF_FC_BB * k4; i += 256) {
+                const int bb = i / k4, kk = (i - bb * k4) * 4;
+                pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (b0 + bb < a.B && kk < a.K) v = *reinterpret_cast<const pf_f32x4*>(a.x + (size_t)(b0 + bb) * a.K + kk);
+                *reinterpret_cast<pf_f32x4*>(&xs[bb][kk]) = v;
+            }
+        } else {
+            for (int i = t; i < PF_FC_BB * kround; i += 256) {
+                const int bb = i / kround, kk = i - bb * kround;
+                xs[bb][kk] = (b0 + bb < a.B && kk < a.K) ? a.x[(size_t)(b0 + bb) * a.K + kk] : 0.f;
             }
         }
         __syncthreads();
+    }
+    for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
+        if constexpr (!WHOLE_K) {
+            for (int i = t; i < PF_FC_BB * PF_FC_KT; i += 256) {
+                const int bb = i / PF_FC_KT, kk = i - bb * PF_FC_KT;
+                xs[bb][kk] = (b0 + bb < a.B && k0 + kk < a.K) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
+            }
+            __syncthreads();
+        }
+        const int xk0 = WHOLE_K ? k0 : 0;
+        if (nok) {
+            // all 32 weights of this thread's k slice are requested before the first FMA: the kernel is a chain of
+            // load latencies otherwise (64-240 workgroups, a few hundred loads each)
+            float wv[32];
+            const float* wp = a.wt + (size_t)(k0 + ks * 32) * a.N + n;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) wv[j] = (k0 + ks * 32 + j < a.K) ? wp[(size_t)j * a.N] : 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int i = 0; i < PF_FC_BB; ++i) {
+                    const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[i][xk0 + ks * 32 + 4 * q]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i] = fmaf(wv[4 * q + j], xv[j], acc[i]);
+                }
+            }
+        }
+        if constexpr (!WHOLE_K) __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < PF_FC_BB; ++i) red[(ks * PF_FC_BB + i) * PF_FC_BN + nl] = acc[i];

@@ -1,0 +1,30 @@
+"""Collects SQ counters for kernels whose name contains a substring (one rocprofv3 pass per counter group).
+usage: python tools/pmc_kernel.py <name-substring> [bench args...]   (run on the GPU box, writes gpurun_out/pmc_*.json)"""
+import csv, glob, json, os, subprocess, sys, collections
+sub = sys.argv[1]
+bench_args = sys.argv[2:] or ["--workload", "landmark", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "1"]
+GROUPS = [["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
+          ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA", "SQ_INSTS_SMEM"],
+          ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
+          ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA"]]
+os.environ["TMPDIR"] = "/tmp"
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+for gi, grp in enumerate(GROUPS):
+    d = f"/tmp/pmc_{gi}"
+    cmd = ["rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath("bench.py"), *bench_args]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=os.getcwd())
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not files:
+        print("group", gi, "no output", r.stderr[-400:])
+        continue
+    for fn in files:
+        for row in csv.DictReader(open(fn)):
+            if sub in row["Kernel_Name"]:
+                res[row["Kernel_Name"][:120]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}
+for k, cs in out.items():
+    print(k)
+    for c, v in cs.items():
+        print(f"   {c:24s} {v:16.0f}")
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(out, open(f"gpurun_out/pmc_{sub.replace('<','_').replace(',','_').replace(' ','')[:40]}.json", "w"), indent=1)
