@@ -256,7 +256,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     memcpy(&a.scale_exp, &f[19], 4); memcpy(&a.scale_pwl, &f[20], 4);
                     a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
-                    if ((a.MidPad % 32) || (a.Cin % 8) || a.Cin > 32 * KS || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
+                    if ((f[21] != 1 && ((a.MidPad % 32) || a.Cin > 32 * KS)) || (a.Cin % 8) || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
                     if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "mbconv: activation must be relu or hard-swish");
                     char tagbuf[96];
                     tagbuf[0] = 0;
@@ -269,8 +269,16 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
         PF_LAUNCH((mbconv_wave_kernel<SS, KSS, PHH, PWW, NTT, MS>),                                                \
                   dim3(MS > 1 ? patches : pf_div_up(patches, 4), B), dim3(256), h->stream, a);                     \
     } else
-                    PF_MBCONV_CASE(2, 1, 4, 4, 2, 1)
-                    PF_MBCONV_CASE(1, 1, 4, 8, 2, 1)
+                    if (f[21] == 1) {   // exact-f32 variant (high-resolution blocks), weights packed as f32
+                        a.w_exp32 = (const float*)p.cptr(f[3]); a.w_pwl32 = (const float*)p.cptr(f[7]);
+                        const int CP = f[15];
+                        if (a.MidPad != a.Mid16 || a.CoutPad > 32) PF_FAIL(h, "mbconv(f32): unsupported block shape");
+                        if (S == 2 && CP == 16)
+                            PF_LAUNCH((mbconv_wave_f32_kernel<2, 16, 4, 4>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 4), 4), B), dim3(256), h->stream, a);
+                        else if (S == 1 && CP == 32)
+                            PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
+                        else PF_FAIL(h, "mbconv(f32): no kernel for stride %d, %d input channels", S, a.Cin);
+                    } else
                     PF_MBCONV_CASE(2, 2, 4, 4, 5, 4)
                     PF_MBCONV_CASE(1, 3, 4, 8, 5, 4)
                     PF_FAIL(h, "mbconv: no kernel for stride %d, %d input channels, %d output channels", S, a.Cin, a.Cout);

@@ -29,6 +29,8 @@ struct MbconvArgs {
     const float* b_dw;    // [MidPad]
     const pf_half* w_pwl; // [CoutPad][MidPad/32][hi 32 | lo 32]
     const float* b_pwl;   // [CoutPad]
+    const float* w_exp32; // exact-f32 variant: [Mid16][CP] / [CoutPad][Mid16] f32 (MidPad == Mid16 there)
+    const float* w_pwl32;
     float scale_exp, scale_pwl;   // 2^-s of the two weight sets
     int B, inH, inW, Cin, inLd, outH, outW, Cout, outLd, resLd;
     int Mid16, MidPad, CoutPad, pad, act;   // Mid16: expanded channels rounded to 16; MidPad: to 32
@@ -260,4 +262,152 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
             store_tile(mt, nt, sum);
         }
     }
+}
+
+// ---- exact-f32 variant for the two high-resolution blocks (16 / 24 input channels, 24 outputs) ---------------
+// Same wave-per-patch structure, v_mfma_f32_16x16x4_f32 on f32 fragments: with so few channels the split
+// path's hi/lo fragments double the register footprint (occupancy 4 -> 5-6 waves per SIMD matters more
+// here than matrix throughput, the block is latency/bandwidth bound).  16 expanded channels per step.
+template <int S, int CP, int PH, int PW>
+__global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
+    constexpr int PP = PH * PW, MPW = PP / 16;
+    constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
+    constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
+    constexpr int KK = CP / 16;
+    constexpr int MAXNT = 2;                   // Cout <= 32
+    static_assert(PP % 16 == 0 && (PW == 4 || PW == 8), "patch shape");
+
+    __shared__ __attribute__((aligned(16))) float smem[4][(HPP + PP) * 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* es = smem[wave];                    // [HPP][16]: fragment stores cover 1 KB contiguously
+    float* ds = es + HPP * 16;                 // [PP][16]
+
+    const int patchesX = (a.outW + PW - 1) / PW, patchesY = (a.outH + PH - 1) / PH;
+    const int pid = blockIdx.x * 4 + wave;
+    if (pid >= patchesX * patchesY) return;
+    const int b = blockIdx.y;
+    const int oy0 = (pid / patchesX) * PH, ox0 = (pid % patchesX) * PW;
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    const float* in = a.in + (size_t)b * a.inH * a.inW * a.inLd;
+    const int frow = lane & 15, fk = (lane >> 4) * 4;
+
+    pf_f32x4 xf[MH][KK];
+    unsigned inside = 0;
+#pragma unroll
+    for (int mt = 0; mt < MH; ++mt) {
+        const int hp = mt * 16 + frow;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW;
+        inside |= ok ? (1u << mt) : 0u;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            xf[mt][kk] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && kk * 16 + fk < a.Cin)
+                xf[mt][kk] = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)iy * a.inW + ix) * a.inLd + kk * 16 + fk);
+        }
+    }
+    pf_f32x4 acc[MPW][MAXNT];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int j = 0; j < MAXNT; ++j) acc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int NTC = a.CoutPad / 16;
+    const int dc = lane & 15, dg = lane >> 4;
+    const unsigned woff = (unsigned)(frow * CP + fk);
+    const unsigned poff = (unsigned)(frow * a.Mid16 + fk);
+
+    // every weight set is requested right after the previous one's last use (latency hides behind the next phase)
+    pf_f32x4 wv[KK], be, pv[MAXNT];
+    float wk[9], bd;
+    auto fetch_expand = [&](int m) {
+        if (m >= a.Mid16) return;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wv[kk] = *reinterpret_cast<const pf_f32x4*>(a.w_exp32 + (size_t)m * CP + woff + kk * 16);
+        be = *reinterpret_cast<const pf_f32x4*>(a.b_exp + m + (unsigned)fk);
+    };
+    auto fetch_dw = [&](int m) {
+        if (m >= a.Mid16) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = (a.w_dw + (k * a.MidPad + m))[(unsigned)dc];
+        bd = (a.b_dw + m)[(unsigned)dc];
+    };
+    auto fetch_project = [&](int m) {
+        if (m >= a.Mid16) return;
+#pragma unroll
+        for (int nt = 0; nt < MAXNT; ++nt)
+            if (nt < NTC) pv[nt] = *reinterpret_cast<const pf_f32x4*>(a.w_pwl32 + (size_t)nt * 16 * a.Mid16 + m + poff);
+    };
+    fetch_expand(0);
+    fetch_dw(0);
+    fetch_project(0);
+
+#pragma unroll 1
+    for (int mc = 0; mc < a.Mid16; mc += 16) {
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt) {
+            pf_f32x4 e = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
+            pf_f32x4 o = e + be;
+            mb_act<4>(o, a.act);
+            *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        fetch_expand(mc + 16);
+        pf_wave_sync();
+        float dv[PP / 4];
+#pragma unroll
+        for (int i = 0; i < PP / 4; ++i) {
+            const int px = PW == 4 ? dg : dg + 4 * (i & 1);
+            const int py = PW == 4 ? i : i >> 1;
+            float s = bd;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
+            dv[i] = s;
+        }
+        mb_act<PP / 4>(dv, a.act);
+#pragma unroll
+        for (int i = 0; i < PP / 4; ++i) {
+            const int px = PW == 4 ? dg : dg + 4 * (i & 1);
+            const int py = PW == 4 ? i : i >> 1;
+            ds[(py * PW + px) * 16 + dc] = dv[i];
+        }
+        fetch_dw(mc + 16);
+        pf_wave_sync();
+#pragma unroll
+        for (int mt = 0; mt < MPW; ++mt) {
+            const pf_f32x4 d4 = *reinterpret_cast<const pf_f32x4*>(ds + (mt * 16 + frow) * 16 + fk);
+#pragma unroll
+            for (int nt = 0; nt < MAXNT; ++nt)
+                if (nt < NTC) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[mt][nt] = pf_mfma_16x16x4_f32(pv[nt][j], d4[j], acc[mt][nt]);
+                }
+        }
+        fetch_project(mc + 16);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MPW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MAXNT; ++nt) {
+            const int p = mt * 16 + frow;
+            const int co = nt * 16 + fk;
+            const int oy = oy0 + p / PW, ox = ox0 + p % PW;
+            if (nt >= NTC || oy >= a.outH || ox >= a.outW || co >= a.Cout) continue;
+            const size_t pix = ((size_t)b * a.outH + oy) * a.outW + ox;
+            pf_f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + a.b_pwl[co + r];
+            if (a.res) {
+                const pf_f32x4 rv = *reinterpret_cast<const pf_f32x4*>(a.res + pix * a.resLd + co);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += rv[r];
+            }
+            *reinterpret_cast<pf_f32x4*>(a.out + pix * a.outLd + co) = v;
+        }
 }

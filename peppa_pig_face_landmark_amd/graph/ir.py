@@ -266,7 +266,23 @@ class ProgramBuilder:
         oh = (ti.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         ow = (ti.W + 2 * pad - dil * (k - 1) - 1) // stride + 1
         out = self.tensor(oh, ow, cout, name=out_name)
-        mid16, midp, cp, coutp = _round_up(mid, 16), _round_up(mid, 32), _round_up(cin, 32), _round_up(cout, 16)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        mid16, coutp = _round_up(mid, 16), _round_up(cout, 16)
+        if (stride, _round_up(cin, 16)) in ((2, 16), (1, 32)) and coutp <= 32:
+            # high-resolution blocks: exact-f32 kernel (f32 fragments halve the register footprint; 16-channel steps)
+            cp = _round_up(cin, 16)
+            we = np.zeros((mid16, cp)); we[:mid, :cin] = w_exp.reshape(mid, cin)
+            be = np.zeros(mid16); be[:mid] = b_exp
+            wd = np.zeros((k * k, mid16)); wd[:, :mid] = w_dw.reshape(mid, k * k).T
+            bd = np.zeros(mid16); bd[:mid] = b_dw
+            wp = np.zeros((coutp, mid16)); wp[:cout, :mid] = w_pwl.reshape(cout, mid)
+            bp = np.zeros(coutp); bp[:cout] = b_pwl
+            self._op(OP_MBCONV, [x, out, res, self.const_f32(we), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
+                                 self.const_f32(wp), self.const_f32(bp), k, stride, pad, dil, ACT[act], mid16, cp, coutp, cout,
+                                 mid16, fbits(1.0), fbits(1.0), 1],
+                     [self._tb(x), self._tb(res)], [self._tb(out)])
+            return out
+        midp, cp = _round_up(mid, 32), _round_up(cin, 32)
         we = np.zeros((midp, cp)); we[:mid, :cin] = w_exp.reshape(mid, cin)
         be = np.zeros(midp); be[:mid] = b_exp
         wd = np.zeros((k * k, midp)); wd[:, :mid] = w_dw.reshape(mid, k * k).T
@@ -275,10 +291,9 @@ class ProgramBuilder:
         bp = np.zeros(coutp); bp[:cout] = b_pwl
         we_s, se = self._split_rows(we)
         wp_s, sp = self._split_rows(wp)
-        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
         self._op(OP_MBCONV, [x, out, res, self.const(we_s), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
                              self.const(wp_s), self.const_f32(bp), k, stride, pad, dil, ACT[act], midp, cp // 32, coutp, cout,
-                             mid16, fbits(se), fbits(sp)],
+                             mid16, fbits(se), fbits(sp), 0],
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
