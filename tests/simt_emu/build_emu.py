@@ -30,7 +30,7 @@ def build_emu(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
         return OUT
     cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
-           "-I", os.path.join(HERE, "include"), "-I", CSRC] + srcs + ["-o", OUT]
+           "-I", os.path.join(HERE, "include"), "-I", CSRC] + os.environ.get("PEPPA_EMU_CFLAGS", "").split() + srcs + ["-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT
 
