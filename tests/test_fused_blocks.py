@@ -62,7 +62,7 @@ def _check(eng, weights, size, batch):
     d = np.abs(loc1 - loc0).reshape(batch, 98, 2).max(2)
     assert d[safe].max() < 1e-4          # fused vs unfused program
     d = np.abs(loc1 - oloc).reshape(batch, 98, 2).max(2)
-    assert d[safe].max() < 1e-4          # fused program vs oracle (north-star tolerance is 1e-3)
+    assert d[safe].max() < 2e-4          # fused program vs oracle (north-star tolerance is 1e-3)
     assert np.abs(score1 - score0)[safe].max() < 2e-3
 
 
