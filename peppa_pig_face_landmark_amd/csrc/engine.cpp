@@ -305,6 +305,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     const int ohw = to.H * to.W;
                     if (ti.H != to.H || ti.W != to.W || to.W > 16 || (256 % ohw) != 0 || 256 / ohw > 4 || pad != dil * (K - 1) / 2 || to.C != a.N)
                         PF_FAIL(h, "expdw: unsupported shape (%dx%d, k%d pad %d dil %d)", to.H, to.W, K, pad, dil);
+                    if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "expdw: activation must be relu or hard-swish");
                     dim3 grid(pf_div_up(B * ohw, 256), pf_div_up(a.N, 64));
                     char tagbuf[96];
                     tagbuf[0] = 0;

@@ -346,10 +346,6 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
     const int c = t % BN, g = t / BN;
     const int n = n0 + c;
     const bool cok = n < a.N;
-    float wk[K * K];                           // requested before the E tile is written: the loads overlap it
-#pragma unroll
-    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
-    const float bd = cok ? a.dw_b[n] : 0.f;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int nl = wn * WN + j * 16 + crow;
@@ -361,10 +357,14 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
             pf_f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[j][i][r], a.acc_scale, bv[r]);
-            pf_act_n<4>(v, a.act);
+            pf_act_rh<4>(v, a.act);
             *reinterpret_cast<pf_f32x4*>(es + (wm * WM + i * 16 + pcol) * ES + nl) = v;
         }
     }
+    float wk[K * K];                           // requested before the barrier (accumulators are dead by now)
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
+    const float bd = cok ? a.dw_b[n] : 0.f;
     __syncthreads();
     const int W = a.outW, H = a.outH, OHW = H * W;
     const int rows = BM / W;
@@ -396,7 +396,7 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
             }
             asm volatile("" ::: "memory");       // one filter row's LDS reads in flight at a time (register footprint)
         }
-        pf_act_n<MAXW>(o, a.act);
+        pf_act_rh<MAXW>(o, a.act);
         const int m = m0 + r * W;                             // first pixel of the row
         if (cok && m < M) {
             float rs = 0.f;

@@ -46,18 +46,6 @@ __device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1
     }
 }
 
-// the Student's inverted-residual blocks use ReLU (stages 1-2) or hard-swish (stages 3-5) only
-template <int N, typename V> __device__ __forceinline__ void mb_act(V& v, int act) {
-    if (act == PF_ACT_HSWISH) {
-        asm volatile("");                      // keep the (wave-uniform) branch a branch
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_HSWISH>(v[i]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_RELU>(v[i]);
-    }
-}
-
 // S: stride, KS: input channels / 32 (rounded up), PH x PW: patch, MAXNT: output channels / 16 (rounded up)
 template <int S, int KS, int PH, int PW, int MAXNT, int MSPLIT>
 __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(MbconvArgs a) {
@@ -169,7 +157,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                 pf_f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaf(e[r], a.scale_exp, be[r]);
-                mb_act<4>(o, a.act);
+                pf_act_rh<4>(o, a.act);
                 *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ok ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
             fetch_expand(mnext);
@@ -188,7 +176,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                         s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
                 dv[i] = s;
             }
-            mb_act<PP / 4>(dv, a.act);
+            pf_act_rh<PP / 4>(dv, a.act);
 #pragma unroll
             for (int i = 0; i < PP / 4; ++i) {
                 const int px = PW == 4 ? dg : dg + 4 * (i & 1);
@@ -352,7 +340,7 @@ __global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
             pf_f32x4 o = e + be;
-            mb_act<4>(o, a.act);
+            pf_act_rh<4>(o, a.act);
             *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
         }
         fetch_expand(mc + 16);
@@ -370,7 +358,7 @@ __global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
                     s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
             dv[i] = s;
         }
-        mb_act<PP / 4>(dv, a.act);
+        pf_act_rh<PP / 4>(dv, a.act);
 #pragma unroll
         for (int i = 0; i < PP / 4; ++i) {
             const int px = PW == 4 ? dg : dg + 4 * (i & 1);
