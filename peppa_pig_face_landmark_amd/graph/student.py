@@ -151,7 +151,8 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
-            elif fuse_mbconv and not se and pb.mbconv_supported(cin, k, s, cur_dil, cout):
+            elif (fuse_mbconv and not se and pb.mbconv_supported(cin, k, s, cur_dil, cout)
+                  and not pb.expdw_supported(pb.tensors[x].H, pb.tensors[x].W, k, s, pad, cur_dil)):
                 we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
                 wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
                 wl, bl = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
