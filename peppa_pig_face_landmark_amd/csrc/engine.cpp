@@ -256,7 +256,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     memcpy(&a.scale_exp, &f[19], 4); memcpy(&a.scale_pwl, &f[20], 4);
                     a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
-                    if ((f[21] != 1 && ((a.MidPad % 32) || a.Cin > 32 * KS)) || (a.Cin % 8) || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
+                    if ((f[21] == 0 && ((a.MidPad % 32) || a.Cin > 32 * KS)) || (a.Cin % 8) || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
                     if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "mbconv: activation must be relu or hard-swish");
                     char tagbuf[96];
                     tagbuf[0] = 0;
@@ -269,7 +269,11 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
         PF_LAUNCH((mbconv_wave_kernel<SS, KSS, PHH, PWW, NTT, MS>),                                                \
                   dim3(MS > 1 ? patches : pf_div_up(patches, 4), B), dim3(256), h->stream, a);                     \
     } else
-                    if (f[21] == 1) {   // exact-f32 variant (high-resolution blocks), weights packed as f32
+                    if (f[21] == 2) {   // depthwise-separable block (no expand conv): dw 3x3 + act -> pointwise [+ x]
+                        a.w_pwl32 = (const float*)p.cptr(f[7]);
+                        if (S != 1 || a.Cin != 16 || a.Mid16 != 16 || a.MidPad != 16 || a.CoutPad > 32) PF_FAIL(h, "dsconv: unsupported block shape");
+                        PF_LAUNCH((mbconv_wave_f32_kernel<1, 16, 4, 8, true>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
+                    } else if (f[21] == 1) {   // exact-f32 variant (high-resolution blocks), weights packed as f32
                         a.w_exp32 = (const float*)p.cptr(f[3]); a.w_pwl32 = (const float*)p.cptr(f[7]);
                         const int CP = f[15];
                         if (a.MidPad != a.Mid16 || a.CoutPad > 32) PF_FAIL(h, "mbconv(f32): unsupported block shape");

@@ -256,7 +256,9 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 // Same wave-per-patch structure, v_mfma_f32_16x16x4_f32 on f32 fragments: with so few channels the split
 // path's hi/lo fragments double the register footprint (occupancy 4 -> 5-6 waves per SIMD matters more
 // here than matrix throughput, the block is latency/bandwidth bound).  16 expanded channels per step.
-template <int S, int CP, int PH, int PW>
+// NOEXP: depthwise-separable block (timm DepthwiseSeparableConv, encoder block 0): no expand conv, the
+// "expanded" map is the input itself (the halo fragments are stored to LDS as they are).
+template <int S, int CP, int PH, int PW, bool NOEXP = false>
 __global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
     constexpr int PP = PH * PW, MPW = PP / 16;
     constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
         for (int nt = 0; nt < MAXNT; ++nt)
             if (nt < NTC) pv[nt] = *reinterpret_cast<const pf_f32x4*>(a.w_pwl32 + (size_t)nt * 16 * a.Mid16 + m + poff);
     };
-    fetch_expand(0);
+    if constexpr (!NOEXP) fetch_expand(0);
     fetch_dw(0);
     fetch_project(0);
 
@@ -334,16 +336,21 @@ __global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
     for (int mc = 0; mc < a.Mid16; mc += 16) {
 #pragma unroll
         for (int mt = 0; mt < MH; ++mt) {
-            pf_f32x4 e = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (NOEXP) {
+                static_assert(!NOEXP || CP == 16, "depthwise-separable variant: 16 channels");
+                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = xf[mt][0];   // zero outside the image already
+            } else {
+                pf_f32x4 e = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+                for (int kk = 0; kk < KK; ++kk)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
-            pf_f32x4 o = e + be;
-            pf_act_rh<4>(o, a.act);
-            *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
+                pf_f32x4 o = e + be;
+                pf_act_rh<4>(o, a.act);
+                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
-        fetch_expand(mc + 16);
+        if constexpr (!NOEXP) fetch_expand(mc + 16);
         pf_wave_sync();
         float dv[PP / 4];
 #pragma unroll

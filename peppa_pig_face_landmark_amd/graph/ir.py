@@ -297,6 +297,27 @@ class ProgramBuilder:
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
+    def dsconv_supported(self, cin: int, k: int, stride: int, dil: int, cout: int) -> bool:
+        return self.esize == 4 and cin == 16 and k == 3 and stride == 1 and dil == 1 and cout <= 32 and cout % 4 == 0
+
+    def dsconv(self, x: int, w_dw: np.ndarray, b_dw: np.ndarray, w_pw: np.ndarray, b_pw: np.ndarray, act: str, *,
+               res: int = -1, out_name: str = "") -> int:
+        """Depthwise-separable block (depthwise 3x3 + act -> pointwise [+ x]) in one launch; BN-folded weights."""
+        ti = self.tensors[x]
+        cout, cin = w_pw.shape[:2]
+        assert cin == ti.real_c == ti.C and w_dw.shape == (cin, 1, 3, 3) and self.dsconv_supported(cin, 3, 1, 1, cout)
+        out = self.tensor(ti.H, ti.W, cout, name=out_name)
+        coutp = _round_up(cout, 16)
+        wd = w_dw.reshape(cin, 9).T
+        wp = np.zeros((coutp, cin)); wp[:cout] = w_pw.reshape(cout, cin)
+        bp = np.zeros(coutp); bp[:cout] = b_pw
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        zero = self.const_f32(np.zeros(16))
+        self._op(OP_MBCONV, [x, out, res, zero, zero, self.const_f32(wd), self.const_f32(b_dw), self.const_f32(wp),
+                             self.const_f32(bp), 3, 1, 1, 1, ACT[act], 16, 16, coutp, cout, 16, fbits(1.0), fbits(1.0), 2],
+                 [self._tb(x), self._tb(res)], [self._tb(out)])
+        return out
+
     def expdw_supported(self, H: int, W: int, k: int, stride: int, pad: int, dil: int) -> bool:
         ohw = H * W
         return (self.split and stride == 1 and W <= 16 and 256 % ohw == 0 and 256 // ohw <= 4

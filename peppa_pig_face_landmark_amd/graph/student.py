@@ -146,7 +146,11 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
             p = f"encoder.blocks.{si}.{bi}"
             inp = x
             skip = (s == 1 and cin == cout)
-            if kind == "ds":
+            if kind == "ds" and fuse_mbconv and pb.dsconv_supported(cin, k, s, cur_dil, cout):
+                wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn1"))
+                wp, bp = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
+                x = pb.dsconv(x, wd, bd, wp, bp, act, res=inp if skip else -1, out_name=f"{p}.out")
+            elif kind == "ds":
                 wt, b = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn1"))
                 x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
