@@ -256,11 +256,20 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     memcpy(&a.scale_exp, &f[19], 4); memcpy(&a.scale_pwl, &f[20], 4);
                     a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
+                    a.act_dw = a.act; a.act_out = PF_ACT_NONE; a.outCs = 1;
+                    if (f[21] == 3) {   // ShuffleNetV2 unit: separate activations, channel-strided store, pass-through copy
+                        a.act_dw = f[22]; a.act_out = f[23]; a.outCs = f[24];
+                        if (f[25] >= 0) {
+                            a.pass_src = (const float*)p.tensor_ptr(f[25]); a.pass_dst = (float*)p.tensor_ptr(f[26]);
+                            a.passLd = p.tens[f[25]].ld; a.passC = p.tens[f[25]].C;
+                            if (a.passC % 16) PF_FAIL(h, "shuffle unit: pass-through channels must be a multiple of 16");
+                        }
+                    }
                     if ((f[21] == 0 && ((a.MidPad % 32) || a.Cin > 32 * KS)) || (a.Cin % 8) || K != 3 || dil != 1) PF_FAIL(h, "mbconv: unsupported block shape");
-                    if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "mbconv: activation must be relu or hard-swish");
+                    if (f[21] != 3 && a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "mbconv: activation must be relu or hard-swish");
                     char tagbuf[96];
                     tagbuf[0] = 0;
-                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbconv_k%ds%d_c%d_m%d_n%d_%dx%d", K, S, a.Cin, a.Mid16, a.Cout, to.H, to.W);
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "%s_k%ds%d_c%d_m%d_n%d_%dx%d", f[21] == 3 ? "shuffle" : "mbconv", K, S, a.Cin, a.Mid16, a.Cout, to.H, to.W);
                     ProfScope ps(h, tagbuf);
                     // (stride, Cin/32, Cout/16) -> patch shape and mid-channel split; low-resolution blocks use MSPLIT = 4
 #define PF_MBCONV_CASE(SS, KSS, PHH, PWW, NTT, MS)                                                                \
@@ -282,6 +291,12 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         else if (S == 1 && CP == 32)
                             PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
                         else PF_FAIL(h, "mbconv(f32): no kernel for stride %d, %d input channels", S, a.Cin);
+                    } else
+                    if (f[21] == 3) {
+                        PF_MBCONV_CASE(1, 1, 4, 8, 2, 1)
+                        PF_MBCONV_CASE(1, 2, 4, 8, 4, 4)
+                        PF_MBCONV_CASE(1, 4, 4, 4, 8, 4)
+                        PF_FAIL(h, "shuffle unit: no kernel for %d channels", a.Cin);
                     } else
                     PF_MBCONV_CASE(2, 2, 4, 4, 5, 4)
                     PF_MBCONV_CASE(1, 3, 4, 8, 5, 4)

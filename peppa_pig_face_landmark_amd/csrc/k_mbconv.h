@@ -34,6 +34,13 @@ struct MbconvArgs {
     float scale_exp, scale_pwl;   // 2^-s of the two weight sets
     int B, inH, inW, Cin, inLd, outH, outW, Cout, outLd, resLd;
     int Mid16, MidPad, CoutPad, pad, act;   // Mid16: expanded channels rounded to 16; MidPad: to 32
+    // ShuffleNetV2 unit (yolov5-face backbone, stride 1): expand act = `act`, depthwise act = act_dw (none),
+    // output act = act_out; the result goes to every outCs-th channel of `out` (channel shuffle folded into the
+    // store) and the pass-through half of the unit's input is copied to the channels in between.
+    int act_dw, act_out, outCs;
+    const float* pass_src;  // [B][outH][outW][passLd], passC channels -> pass_dst channel c*outCs, or nullptr
+    float* pass_dst;
+    int passLd, passC;
 };
 
 __device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1, pf_half8& hi, pf_half8& lo) {
@@ -43,6 +50,22 @@ __device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1
         const pf_half hv = (pf_half)v;
         hi[e] = hv;
         lo[e] = (pf_half)(v - (float)hv);
+    }
+}
+
+// activations of the fused block kernels: none | relu | hard-swish | SiLU behind one wave-uniform branch
+template <int N, typename V> __device__ __forceinline__ void mb_act(V& v, int act) {
+    if (act == PF_ACT_HSWISH) {
+        asm volatile("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_HSWISH>(v[i]);
+    } else if (act == PF_ACT_SILU) {
+        asm volatile("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_SILU>(v[i]);
+    } else if (act == PF_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_RELU>(v[i]);
     }
 }
 
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                 pf_f32x4 o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaf(e[r], a.scale_exp, be[r]);
-                pf_act_rh<4>(o, a.act);
+                mb_act<4>(o, a.act);
                 *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ok ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
             fetch_expand(mnext);
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                         s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
                 dv[i] = s;
             }
-            pf_act_rh<PP / 4>(dv, a.act);
+            mb_act<PP / 4>(dv, a.act_dw);
 #pragma unroll
             for (int i = 0; i < PP / 4; ++i) {
                 const int px = PW == 4 ? dg : dg + 4 * (i & 1);
@@ -187,27 +210,25 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
             pf_wave_sync();
         }
         // ---- project 32 expanded channels --------------------------------------------------------------------
-        pf_half8 ph[MAXNT], pl[MAXNT];
-#pragma unroll
-        for (int nt = 0; nt < MAXNT; ++nt)
-            if (nt < NTC) {
-                const pf_half* base = a.w_pwl + ((size_t)nt * 16 * (a.MidPad / 32) + mc / 32) * 64;
-                ph[nt] = *reinterpret_cast<const pf_half8*>(base + poff);
-                pl[nt] = *reinterpret_cast<const pf_half8*>(base + poff + 32);
-            }
+        pf_half8 dh[MPW], dl[MPW];
 #pragma unroll
         for (int mt = 0; mt < MPW; ++mt) {
             const float* dp = ds + (mt * 16 + frow) * DS + k8;
-            pf_half8 dh, dl;
-            pf_split8(*reinterpret_cast<const pf_f32x4*>(dp), *reinterpret_cast<const pf_f32x4*>(dp + 4), dh, dl);
-#pragma unroll
-            for (int nt = 0; nt < MAXNT; ++nt)
-                if (nt < NTC) {
-                    acc[mt][nt] = pf_mfma_16x16x32_f16(pl[nt], dh, acc[mt][nt]);
-                    acc[mt][nt] = pf_mfma_16x16x32_f16(ph[nt], dl, acc[mt][nt]);
-                    acc[mt][nt] = pf_mfma_16x16x32_f16(ph[nt], dh, acc[mt][nt]);
-                }
+            pf_split8(*reinterpret_cast<const pf_f32x4*>(dp), *reinterpret_cast<const pf_f32x4*>(dp + 4), dh[mt], dl[mt]);
         }
+#pragma unroll
+        for (int nt = 0; nt < MAXNT; ++nt)
+            if (nt < NTC) {             // one output tile's weights at a time (8 tiles x hi/lo would be 64 registers)
+                const pf_half* base = a.w_pwl + ((size_t)nt * 16 * (a.MidPad / 32) + mc / 32) * 64;
+                const pf_half8 ph = *reinterpret_cast<const pf_half8*>(base + poff);
+                const pf_half8 pl = *reinterpret_cast<const pf_half8*>(base + poff + 32);
+#pragma unroll
+                for (int mt = 0; mt < MPW; ++mt) {
+                    acc[mt][nt] = pf_mfma_16x16x32_f16(pl, dh[mt], acc[mt][nt]);
+                    acc[mt][nt] = pf_mfma_16x16x32_f16(ph, dl[mt], acc[mt][nt]);
+                    acc[mt][nt] = pf_mfma_16x16x32_f16(ph, dh[mt], acc[mt][nt]);
+                }
+            }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
@@ -225,7 +246,28 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += rv[r];
         }
-        *reinterpret_cast<pf_f32x4*>(a.out + pix * a.outLd + co) = v;
+        mb_act<4>(v, a.act_out);
+        if (a.outCs == 1) {
+            *reinterpret_cast<pf_f32x4*>(a.out + pix * a.outLd + co) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.out[pix * a.outLd + (size_t)(co + r) * a.outCs] = v[r];
+        }
+    };
+    // pass-through half of a ShuffleV2 unit: this patch's pixels, channel c -> c * outCs of pass_dst
+    auto copy_pass = [&](int part, int parts) {
+        if (!a.pass_src) return;
+        for (int q = part; q < MPW * (a.passC / 16); q += parts) {
+            const int mt = q % MPW, cg = q / MPW;
+            const int p = mt * 16 + frow;
+            const int oy = oy0 + p / PW, ox = ox0 + p % PW;
+            if (oy >= a.outH || ox >= a.outW) continue;
+            const size_t pix = ((size_t)b * a.outH + oy) * a.outW + ox;
+            const int c = cg * 16 + fk;
+            const pf_f32x4 v = *reinterpret_cast<const pf_f32x4*>(a.pass_src + pix * a.passLd + c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.pass_dst[pix * a.outLd + (size_t)(c + r) * a.outCs] = v[r];
+        }
     };
     if constexpr (MSPLIT == 1) {
 #pragma unroll
@@ -233,6 +275,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 #pragma unroll
             for (int nt = 0; nt < MAXNT; ++nt)
                 if (nt < NTC) store_tile(mt, nt, acc[mt][nt]);
+        copy_pass(0, 1);
     } else {
         // the four waves hold partial sums of the same tiles: exchange through LDS, tile q summed by wave q % 4
         pf_wave_sync();
@@ -249,6 +292,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
             for (int w = 0; w < 4; ++w) sum += *reinterpret_cast<const pf_f32x4*>(smem[w] + (mt * MAXNT + nt) * 256 + lane * 4);
             store_tile(mt, nt, sum);
         }
+        copy_pass(wave, 4);
     }
 }
 

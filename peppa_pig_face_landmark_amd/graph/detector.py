@@ -34,7 +34,7 @@ def _bn(w, prefix):
 
 
 def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (384, 640),
-                           dtype: str = "f32", keep_all: bool = False):
+                           dtype: str = "f32", keep_all: bool = False, fuse_units: bool = True):
     w = weights
     H, W = input_hw
     assert H % 32 == 0 and W % 32 == 0
@@ -65,6 +65,14 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
         out_buf = pb.buffer(oh * ow * oup, ir.ELEM_ACT, name or prefix)
         even = pb.strided_view(out_buf, oh, ow, bf, 0, oup)
         odd = pb.strided_view(out_buf, oh, ow, bf, 1, oup)
+        if stride == 1 and fuse_units and pb.shuffle_unit_supported(bf):
+            x1 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff, tx.ld)
+            x2 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff + bf, tx.ld)
+            w1, b1 = ir.fold_bn(w[f"{prefix}.branch2.0.weight"], None, _bn(w, f"{prefix}.branch2.1"), BN_EPS)
+            wd, bd = ir.fold_bn(w[f"{prefix}.branch2.3.weight"], None, _bn(w, f"{prefix}.branch2.4"), BN_EPS)
+            w2, b2 = ir.fold_bn(w[f"{prefix}.branch2.5.weight"], None, _bn(w, f"{prefix}.branch2.6"), BN_EPS)
+            pb.shuffle_unit(x2, w1, b1, wd, bd, w2, b2, "silu", odd, 2, x1, even)
+            return pb.view(out_buf, oh, ow, oup, 0, oup, name=name)
         if stride == 1:
             pb.copy(pb.view(tx.buf, tx.H, tx.W, bf, tx.coff, tx.ld), even, out_cs=2)
             x2 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff + bf, tx.ld)

@@ -297,6 +297,29 @@ class ProgramBuilder:
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
+    def shuffle_unit_supported(self, c: int) -> bool:
+        return self.split and c in (32, 64, 128)
+
+    def shuffle_unit(self, x2: int, w1: np.ndarray, b1: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray, w2: np.ndarray,
+                     b2: np.ndarray, act: str, out: int, out_cs: int, pass_src: int, pass_dst: int) -> int:
+        """Stride-1 ShuffleNetV2 unit in one launch: act(1x1) -> depthwise 3x3 -> act(1x1) written to every out_cs-th
+        channel of `out` (strided view), pass-through half copied to `pass_dst` (strided view); BN-folded weights."""
+        ti = self.tensors[x2]
+        c = w1.shape[0]
+        assert self.shuffle_unit_supported(c) and w1.shape[:2] == (c, c) and w2.shape[:2] == (c, c) and ti.C == c
+        assert w_dw.shape == (c, 1, 3, 3)
+        to = self.tensors[out]
+        assert (to.H, to.W) == (ti.H, ti.W)
+        we_s, se = self._split_rows(w1.reshape(c, c).astype(np.float64))
+        wp_s, sp = self._split_rows(w2.reshape(c, c).astype(np.float64))
+        wd = w_dw.reshape(c, 9).T
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        self._op(OP_MBCONV, [x2, out, -1, self.const(we_s), self.const_f32(b1), self.const_f32(wd), self.const_f32(b_dw),
+                             self.const(wp_s), self.const_f32(b2), 3, 1, 1, 1, ACT[act], c, c // 32, c, c, c, fbits(se), fbits(sp), 3,
+                             ACT["none"], ACT[act], out_cs, pass_src, pass_dst],
+                 [self._tb(x2), self._tb(pass_src)], [self._tb(out), self._tb(pass_dst)])
+        return out
+
     def dsconv_supported(self, cin: int, k: int, stride: int, dil: int, cout: int) -> bool:
         return self.esize == 4 and cin == 16 and k == 3 and stride == 1 and dil == 1 and cout <= 32 and cout % 4 == 0
 

@@ -1,5 +1,6 @@
 """yolov5n-0.5 detector program on the CPU SIMT emulator vs the oracle restatement (small input)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import detector_net as dn
@@ -7,9 +8,11 @@ from oracle import synth_weights as sw
 from peppa_pig_face_landmark_amd.graph.detector import build_detector_program, random_detector_weights
 
 
-def test_detector_f32_layers_and_rows(emu_engine, detector_weights):
+@pytest.mark.parametrize("dtype", ["f32", "f32s"])
+def test_detector_f32_layers_and_rows(emu_engine, detector_weights, dtype):
+    """f32s additionally runs the stride-1 ShuffleNetV2 units as ONE fused launch each (csrc/k_mbconv.h)."""
     H, W = 128, 160
-    blob, info = build_detector_program(detector_weights, (H, W), "f32", keep_all=True)
+    blob, info = build_detector_program(detector_weights, (H, W), dtype, keep_all=True)
     emu_engine.load_program(1, blob, 1)
     img = sw.smooth_blob_images(1, 160, seed=5)[:, :H]
     rows = emu_engine.detector_forward(img, info["rows"])
