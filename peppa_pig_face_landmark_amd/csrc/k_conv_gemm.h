@@ -455,7 +455,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
     constexpr int XROWSTEP = NTHR / 4;                 // rows covered by one pass of the block
     constexpr int WCHUNKS = (BN * 8 + NTHR - 1) / NTHR;  // 16-byte weight chunks staged per thread
     constexpr int PLANE_X = BM * 64, PLANE_W = BN * 64;
-    constexpr int STAGE_BYTES = 2 * PLANE_X + 2 * PLANE_W;
+    constexpr int W_BYTES = WCHUNKS * NTHR * 16;         // weight planes (hi | lo), rounded up to whole LDS-DMA passes
+    constexpr int STAGE_BYTES = 2 * PLANE_X + W_BYTES;
     static_assert((NTHR == 256 || NTHR == 512) && WM % 16 == 0 && WN % 16 == 0 && WM > 0 && WN > 0, "tile shape");
     static_assert((BM * 4) % NTHR == 0, "pixel tile must split evenly over the block");
 
@@ -498,9 +499,12 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
     const size_t wrow_bytes = (size_t)taps * cblocks * 128;
 
     pf_f32x4 xreg[XUNITS][2];
-    pf_f32x4 wreg[WCHUNKS];
 
-    auto load_tile = [&](int tap, int cb) {
+    // Weights are pre-split bytes: they go global -> LDS directly (no VGPRs, no ds_write pass, which costs 13
+    // LDS-path cycles per 16 bytes against 4 for a read).  LDS slot s (16 B, lane-linear as the DMA requires) is
+    // (plane, row, position) with the row's four chunks rotated; the rotation is applied to the SOURCE address.
+    // Rows past Npad re-read the last row (their outputs are never stored); slots past the planes land in padding.
+    auto load_tile = [&](int tap, int cb, int stage) {
         const int ky = KS == 1 ? 0 : tap / a.KW;
         const int kx = KS == 1 ? 0 : tap - ky * a.KW;
         const int kelem = cb * 32 + xc * 8;
@@ -591,22 +595,21 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
             }
         }
         }
+        unsigned char* wdst = smem + stage * STAGE_BYTES + 2 * PLANE_X;
 #pragma unroll
         for (int c = 0; c < WCHUNKS; ++c) {
-            const int q = t + NTHR * c;        // chunk id: row = q >> 3, piece = q & 7 (0..3 hi, 4..7 lo)
-            const int row = q >> 3;
-            const int n = n0 + row;
-            pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (row < BN && n < a.Npad)
-                v = *reinterpret_cast<const pf_f32x4*>(wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + (q & 7) * 16);
-            wreg[c] = v;
+            const int sl = t + NTHR * c;
+            const int plane = sl >= BN * 4 ? 1 : 0;
+            const int r = (sl - plane * BN * 4) >> 2;
+            const int row = r < BN ? r : BN - 1;
+            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
+            const int n = min(n0 + row, a.Npad - 1);
+            pf_glds16(wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
         }
     };
     auto store_tile = [&](int stage) {
         unsigned char* xh = smem + stage * STAGE_BYTES;
         unsigned char* xl = xh + PLANE_X;
-        unsigned char* wh = xl + PLANE_X;
-        unsigned char* wl = wh + PLANE_W;
 #pragma unroll
         for (int u = 0; u < XUNITS; ++u) {
             pf_half8 hi, lo;
@@ -621,12 +624,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
             *reinterpret_cast<pf_half8*>(xh + off) = hi;
             *reinterpret_cast<pf_half8*>(xl + off) = lo;
         }
-#pragma unroll
-        for (int c = 0; c < WCHUNKS; ++c) {
-            const int q = t + NTHR * c;
-            const int row = q >> 3, piece = q & 7;
-            if (row < BN) *reinterpret_cast<pf_f32x4*>((piece < 4 ? wh : wl) + pf_lds_chunk_off(row, piece & 3)) = wreg[c];
-        }
     };
 
     pf_f32x4 acc[NT][MT];
@@ -636,7 +633,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 
     int tap = 0, cb = 0;
-    load_tile(tap, cb);
+    load_tile(tap, cb, 0);
     store_tile(0);
     __syncthreads();
     const int frow = lane & 15, fchunk = lane >> 4;
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         const bool more = kt + 1 < nk;
         if (more) {
             if (++tap == taps) { tap = 0; ++cb; }
-            load_tile(tap, cb);
+            load_tile(tap, cb, cur ^ 1);
         }
         const unsigned char* xh = smem + cur * STAGE_BYTES;
         const unsigned char* xl = xh + PLANE_X;

@@ -32,5 +32,13 @@ __device__ __forceinline__ void pf_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// global -> LDS copy of 16 bytes per lane without a VGPR round trip (global_load_lds_dwordx4).  The LDS
+// destination is wave-uniform base + lane * 16: callers pass lane-linear pointers (lane 0's pointer is the base).
+// Counts on vmcnt; a following __syncthreads() drains it.
+__device__ __forceinline__ void pf_glds16(const void* gsrc, void* lds_lane_ptr) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_lane_ptr, 16, 0, 0);
+}
+
 #define PF_BUILD_TAG "gfx950"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -67,5 +67,7 @@ inline int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
 
 inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
+inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
+
 #define PF_BUILD_TAG "simt-emu"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
