@@ -133,8 +133,8 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     memcpy(&a.acc_scale, &f[22], 4);
     // tile configurations: index -> (BM pixels, BN channels).  The channel tile is chosen so that
     // q tiles of NT*16 channels cover Npad with the least padding (NT <= 8), ties -> fewer tiles.
-    static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256};
-    static const int bn[PF_CONV_NCFG] = {128, 64, 32, 16, 80, 96, 112, 48};
+    static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256, 128};
+    static const int bn[PF_CONV_NCFG] = {128, 64, 32, 16, 80, 96, 112, 48, 160};
     static const int cfg_of_nt[9] = {-1, 3, 2, 7, 1, 4, 5, 6, 0};
     int cfg = f[21];
     if (cfg < 0) {
@@ -147,6 +147,9 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         }
         (void)best_q;
         cfg = cfg_of_nt[best_nt];
+        // 160 output channels (stage-5 projections, K = 672 / 960): one 128 x 160 tile reads the wide input once
+        // instead of twice (two 80-channel tiles); split-precision pointwise only
+        if (SPLIT && f[23] != 0 && a.Npad == 160 && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && !a.amax_val) cfg = 8;
     }
     const int M = B * a.outH * a.outW;
     if (a.amax_val && ((a.outH * a.outW) % bm[cfg]) != 0) PF_FAIL(h, "argmax conv: H*W=%d not a multiple of BM=%d", a.outH * a.outW, bm[cfg]);
@@ -169,6 +172,14 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
             else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
         }                                                                                               \
         break;
+    if (cfg == 8) {
+        if constexpr (SPLIT) {
+            PF_LAUNCH((conv_gemm_split_kernel<128, 160, 4, 2, 1>), grid, dim3(512), h->stream, a);
+            return 0;
+        } else {
+            PF_FAIL(h, "conv tile configuration 8 is split-precision only");
+        }
+    }
     switch (cfg) {
         PF_CONV_CASE(0, 128, 128, 2, 2)
         PF_CONV_CASE(1, 128, 64, 2, 2)

@@ -55,4 +55,4 @@ enum PfOpCode : int32_t {
 };
 
 // tile configurations of conv_gemm_kernel (index = cfg field)
-#define PF_CONV_NCFG 8
+#define PF_CONV_NCFG 9
