@@ -445,8 +445,9 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
 // concatenated and the depthwise tensors never exist in HBM.
 // EPI_K != 0 (pointwise only): the epilogue is the fused depthwise EPI_K x EPI_K conv (dilation EPI_DIL) above.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
     // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves);
+    // 256-channel tiles hold 64 accumulators + 64 weight-fragment registers and run one workgroup per CU;
     // the fused-depthwise variants keep an 80 KB tile in LDS (one workgroup per CU) and may use 256
     constexpr int NTHR = WARPS_M * WARPS_N * 64;       // 256 or 512 threads (8 waves hide the staging latency)
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;

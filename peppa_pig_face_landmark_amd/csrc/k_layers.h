@@ -227,7 +227,7 @@ struct FcArgs {
 // each) so four times as many weight loads are in flight per CU; every weight is read once per 16
 // items (consecutive lanes -> consecutive n, coalesced); x is staged through LDS and read as float4.
 #define PF_FC_BN 64
-#define PF_FC_BB 16
+#define PF_FC_BB 8
 #define PF_FC_MAXK 1024   // largest K staged whole (64 KB of LDS)
 #define PF_FC_KT 128
 // WHOLE_K: the 16 input vectors are staged in LDS once for all of K (K <= PF_FC_MAXK), so the k loop has
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
     constexpr int XK = WHOLE_K ? PF_FC_MAXK : PF_FC_KT;
     __shared__ __attribute__((aligned(16))) float smem[PF_FC_BB * XK + 4 * PF_FC_BB * PF_FC_BN];
     float(*xs)[XK] = reinterpret_cast<float(*)[XK]>(smem);
-    float* red = smem + PF_FC_BB * XK;   // [4 k-slices][16 items][64 outputs]
+    float* red = smem + PF_FC_BB * XK;   // [4 k-slices][PF_FC_BB items][64 outputs]
     const int t = threadIdx.x;
     const int nl = t & (PF_FC_BN - 1);
     const int ks = t >> 6;
