@@ -2,11 +2,17 @@
 usage: python tools/pmc_kernel.py <name-substring> [bench args...]   (run on the GPU box, writes gpurun_out/pmc_*.json)"""
 import csv, glob, json, os, subprocess, sys, collections
 sub = sys.argv[1]
-bench_args = sys.argv[2:] or ["--workload", "landmark", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "1"]
+args = sys.argv[2:]
+counters = None
+if args and args[0].startswith("--counters="):      # one rocprofv3 pass per listed counter (e.g. FETCH_SIZE,WRITE_SIZE)
+    counters = args.pop(0).split("=", 1)[1].split(",")
+bench_args = args or ["--workload", "landmark", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "1"]
 GROUPS = [["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
           ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA", "SQ_INSTS_SMEM"],
           ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
           ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA"]]
+if counters:
+    GROUPS = [[c] for c in counters]
 os.environ["TMPDIR"] = "/tmp"
 res = collections.defaultdict(lambda: collections.defaultdict(list))
 for gi, grp in enumerate(GROUPS):
@@ -21,7 +27,8 @@ for gi, grp in enumerate(GROUPS):
         for row in csv.DictReader(open(fn)):
             if sub in row["Kernel_Name"]:
                 res[row["Kernel_Name"][:120]][row["Counter_Name"]].append(float(row["Counter_Value"]))
-out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}
+out = {k: {c: max(v) for c, v in cs.items()} for k, cs in res.items()} if counters else \
+      {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in res.items()}   # --counters: largest launch (full batch)
 for k, cs in out.items():
     print(k)
     for c, v in cs.items():
