@@ -172,6 +172,14 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
             else PF_LAUNCH((conv_gemm_kernel<T, BM_, BN_, WM_, WN_, 3>), grid, dim3(256), h->stream, a);          \
         }                                                                                               \
         break;
+    // 3x3 / stride 1 / pad 1 with 128 outputs on 16-, 32- or 64-pixel-wide maps: input patch resident in LDS
+    if (SPLIT && use_split && cfg == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && !a.gate && !a.amax_val &&
+        (a.outW == 16 || a.outW == 32 || a.outW == 64) && ((a.outH * a.outW) % 128) == 0 && a.inH == a.outH && a.inW == a.outW) {
+        if constexpr (SPLIT) {
+            PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
+            return 0;
+        }
+    }
     if (cfg == 8) {
         if constexpr (SPLIT) {
             PF_LAUNCH((conv_gemm_split_kernel<128, 160, 4, 2, 1>), grid, dim3(512), h->stream, a);

@@ -681,5 +681,164 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     }
 }
 
+// ---- 3x3 stride-1 convolution with the input tile (plus halo) resident in LDS -------------------------------
+// The generic kernel above is an im2col pipeline: every tap re-fetches, re-splits and re-writes the same 128
+// pixels x 32 channels (9x per channel chunk).  Here a workgroup's 128 output pixels are BM / W whole image rows;
+// for each 32-channel chunk the (rows + 2) x (W + 2) input patch is fetched ONCE (register-prefetched one chunk
+// ahead), split to hi/lo and parked in LDS, zero padding included; the nine taps then read their pixel fragments
+// at shifted row offsets (conflict-free for any shift with the same chunk rotation) and only the weights stream
+// per tap (LDS-DMA, two stages).  Activation fetches, conversions and LDS writes drop ~4x (halo overhead 2.06x
+// at W = 64); the matrix-core work and the epilogue are unchanged.  Host guarantees: pad = dil = stride = 1,
+// W in {16, 32, 64}, (H * W) % 128 == 0, no input gate.
+template <int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv3x3_halo_split_kernel(ConvGemmArgs a) {
+    constexpr int BM = 128;
+    constexpr int NTHR = WARPS_M * WARPS_N * 64;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int MAXHP = 272;                           // (2 + 2) x (64 + 2) = 264 halo pixels at W = 64 (204 / 180 at 32 / 16)
+    constexpr int XU = (MAXHP * 4 + NTHR - 1) / NTHR;    // (pixel, 8-float unit) pairs per thread
+    constexpr int PLANE_X = MAXHP * 64;
+    constexpr int WCHUNKS = (BN * 8 + NTHR - 1) / NTHR;
+    constexpr int W_BYTES = WCHUNKS * NTHR * 16;
+    static_assert(NTHR == 512 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + 2 * W_BYTES];
+    unsigned char* xh = smem;
+    unsigned char* xl = smem + PLANE_X;
+    unsigned char* wbase = smem + 2 * PLANE_X;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
+    int mtile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware tile order
+    const int m0 = mtile * BM;
+    const int n0 = blockIdx.y * BN;
+    const int W = a.outW, H = a.outH, OHW = H * W;
+    const int M = a.B * OHW;
+    const int HW2 = W + 2;
+    const int TR = BM / W;
+    const int HP = (TR + 2) * HW2;
+    const int face = m0 / OHW;
+    const int y0 = (m0 - face * OHW) / W;
+    const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)face * OHW * a.inLd;
+    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
+    const int cblocks = a.Cpad / 32;
+    const size_t wrow_bytes = (size_t)9 * cblocks * 128;
+
+    // this thread's halo units
+    int xoff[XU], xhp[XU];
+    const int xc = t & 3;
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int hp = (t >> 2) + (NTHR / 4) * u;
+        xhp[u] = hp < HP ? hp : -1;
+        const int hy = hp / HW2, hx = hp - hy * HW2;
+        const int iy = y0 - 1 + hy, ix = hx - 1;
+        const bool ok = hp < HP && m0 < M && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        xoff[u] = ok ? (iy * W + ix) * a.inLd + xc * 8 : -1;
+    }
+    pf_f32x4 xreg[XU][2];
+    auto load_x = [&](int cb) {
+#pragma unroll
+        for (int u = 0; u < XU; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                if (xoff[u] >= 0 && cb * 32 + xc * 8 + 4 * h < a.inC) v = *reinterpret_cast<const pf_f32x4*>(in + xoff[u] + cb * 32 + 4 * h);
+                xreg[u][h] = v;
+            }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            if (xhp[u] < 0) continue;
+            pf_half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = xreg[u][e >> 2][e & 3];
+                const pf_half hv = (pf_half)v;
+                hi[e] = hv;
+                lo[e] = (pf_half)(v - (float)hv);
+            }
+            const int off = pf_lds_chunk_off(xhp[u], xc);
+            *reinterpret_cast<pf_half8*>(xh + off) = hi;
+            *reinterpret_cast<pf_half8*>(xl + off) = lo;
+        }
+    };
+    auto load_w = [&](int tap, int cb, int stage) {
+        unsigned char* wdst = wbase + stage * W_BYTES;
+#pragma unroll
+        for (int c = 0; c < WCHUNKS; ++c) {
+            const int sl = t + NTHR * c;
+            const int plane = sl >= BN * 4 ? 1 : 0;
+            const int r = (sl - plane * BN * 4) >> 2;
+            const int row = r < BN ? r : BN - 1;
+            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
+            const int n = min(n0 + row, a.Npad - 1);
+            pf_glds16(wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
+        }
+    };
+
+    pf_f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+    int hp0[MT];                                         // halo row of this lane's pixel at tap (0, 0)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int p = wm * WM + i * 16 + frow;
+        const int ty = p / W, tx = p - ty * W;
+        hp0[i] = ty * HW2 + tx;
+    }
+
+    load_x(0);
+    load_w(0, 0, 0);
+    store_x();
+    __syncthreads();
+    const int nk = 9 * cblocks;
+    int tap = 0, cb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        const bool last_tap = tap == 8;
+        if (more) load_w(last_tap ? 0 : tap + 1, last_tap ? cb + 1 : cb, cur ^ 1);
+        if (tap == 0 && cb + 1 < cblocks) load_x(cb + 1);          // next chunk's patch: nine taps of latency cover
+        const unsigned char* wh = wbase + cur * W_BYTES;
+        const unsigned char* wl = wh + BN * 64;
+        pf_half8 whf[NT], wlf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
+            whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
+            wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
+        }
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int shift = ky * HW2 + kx;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int off = pf_lds_chunk_off(hp0[i] + shift, fchunk);
+            const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xh + off);
+            const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xl + off);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(wlf[j], xhf, acc[j][i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xlf, acc[j][i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
+        }
+        if (last_tap && more) {
+            __syncthreads();                 // every wave is done with this chunk's patch
+            store_x();
+        }
+        __syncthreads();
+        if (last_tap) { tap = 0; ++cb; } else ++tap;
+    }
+    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
+}
+
 // Tile configurations (BM x BN, waves M x N) picked by the host from the padded channel count.
 #define PF_CONV_CFGS(X) X(128, 128, 2, 2) X(128, 64, 2, 2) X(256, 32, 4, 1) X(256, 16, 4, 1)
