@@ -840,5 +840,221 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }
 
+// ---- fused DecoderBlock front end with the low-res patch and its filters resident in LDS ------------------------
+// Same operator as conv_gemm_split_kernel<..., STAGE = 1> (bilinear x2 upsample + concat + depthwise 3x3 + BN as
+// the producer of a pointwise split-precision GEMM).  There every (pixel, 8-channel) unit issues 36 16-byte
+// global loads per K step (9 taps x input + position-class filter) and the launch is bound by the L1 / texture
+// address path.  Here, per 32-channel chunk of the upsampled half, the workgroup parks the low-res rows it needs
+// ((rows/2 + 2) x (W/2 + 2) pixels, border replication materialised) and the 16 x 9 x 32 class filters in LDS
+// (register-prefetched / LDS-DMA one chunk ahead) and the producer reads them there; the skip-connection chunks
+// (the last one or two) keep the global-load path.  One x stage, one weight stage, two barriers per K step:
+//   phase 1: weights of this step by LDS-DMA || produce + split the pixel operand -> LDS
+//   phase 2: next chunk's patch / filters -> LDS || MFMAs
+// Host guarantees: W in {16, 32, 64} (= 2 x low-res width), (H * W) % 128 == 0, C1 % 32 == 0.
+template <int BN, int WARPS_M, int WARPS_N>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void sepup_patch_kernel(ConvGemmArgs a) {
+    constexpr int BM = 128;
+    constexpr int NTHR = WARPS_M * WARPS_N * 64;
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int MAXPP = 102;                           // 3 x 34 low-res pixels at W = 64 (4 x 18 at 32, 6 x 10 at 16)
+    constexpr int PU = (MAXPP * 8 + NTHR - 1) / NTHR;    // 16-byte patch units per thread
+    constexpr int P_BYTES = MAXPP * 128;
+    constexpr int PW_SLOTS = 16 * 9 * 8;                 // 16-byte slots of one chunk's class filters
+    constexpr int PW_BYTES = PW_SLOTS * 16;
+    constexpr int PLANE_X = BM * 64;
+    constexpr int WCHUNKS = BN * 8 / NTHR;
+    constexpr int W_BYTES = BN * 128;
+    static_assert(NTHR == 512 && (BN * 8) % NTHR == 0 && PW_SLOTS == 2 * NTHR + 128, "tile shape");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_BYTES + PW_BYTES + 2 * PLANE_X + W_BYTES];
+    float* pl = reinterpret_cast<float*>(smem);                      // [patch pixel][32 ch]
+    float* pw = reinterpret_cast<float*>(smem + P_BYTES);            // [class * 9 + tap][32 ch]
+    unsigned char* xh = smem + P_BYTES + PW_BYTES;
+    unsigned char* xl = xh + PLANE_X;
+    unsigned char* wh = xl + PLANE_X;
+    unsigned char* wl = wh + BN * 64;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int W = a.outW, H = a.outH, OHW = H * W;
+    const int M = a.B * OHW;
+    const int TR = BM / W;
+    const int PC = a.loW + 2;
+    const int PP = (TR / 2 + 2) * PC;
+    const int face = m0 / OHW;
+    const int y0 = (m0 - face * OHW) / W;
+    const int rmin = (y0 >> 1) - 1;                      // low-res row held in patch row 0 (before clamping)
+    const float* __restrict__ lo = a.up_lo + (size_t)face * a.loH * a.loW * a.loLd;
+    const float* __restrict__ sk = a.up_skip + (size_t)face * OHW * a.skipLd;
+    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
+    const int cblocks = a.Cpad / 32;
+    const size_t wrow_bytes = (size_t)cblocks * 128;
+    const int lo_chunks = a.C1 / 32;
+
+    // ---- patch units of this thread (border replication applied to the SOURCE coordinates) ---------------
+    int poff[PU], pdst[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+        const int q = t + NTHR * u;
+        const int pp = q >> 3, c4 = q & 7;
+        const bool ok = pp < PP && m0 < M;
+        const int pr = pp / PC, pc = pp - pr * PC;
+        const int ry = min(max(rmin + pr, 0), a.loH - 1), rx = min(max(pc - 1, 0), a.loW - 1);
+        poff[u] = ok ? (ry * a.loW + rx) * a.loLd + c4 * 4 : -1;
+        pdst[u] = pp * 32 + c4 * 4;
+    }
+    pf_f32x4 preg[PU];
+    auto load_patch = [&](int cb) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) preg[u] = poff[u] >= 0 ? *reinterpret_cast<const pf_f32x4*>(lo + poff[u] + cb * 32) : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int u = 0; u < PU; ++u)
+            if (poff[u] >= 0) *reinterpret_cast<pf_f32x4*>(pl + pdst[u]) = preg[u];
+    };
+    auto dma_filters = [&](int cb) {                     // [class*9+tap][C1] rows -> [class*9+tap][32] in LDS
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int sl = t + NTHR * c;
+            pf_glds16(a.dw_w + (size_t)(sl >> 3) * a.C1 + cb * 32 + (sl & 7) * 4, reinterpret_cast<unsigned char*>(pw) + sl * 16);
+        }
+        if (t < 128) {                                   // waves 0 and 1: the last 128 slots
+            const int sl = 2 * NTHR + t;
+            pf_glds16(a.dw_w + (size_t)(sl >> 3) * a.C1 + cb * 32 + (sl & 7) * 4, reinterpret_cast<unsigned char*>(pw) + sl * 16);
+        }
+    };
+    auto dma_weights = [&](int cb) {
+#pragma unroll
+        for (int c = 0; c < WCHUNKS; ++c) {
+            const int sl = t + NTHR * c;
+            const int plane = sl >= BN * 4 ? 1 : 0;
+            const int row = (sl - plane * BN * 4) >> 2;
+            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
+            const int n = min(n0 + row, a.Npad - 1);
+            pf_glds16(wt + (size_t)n * wrow_bytes + (size_t)cb * 128 + plane * 64 + chunk * 16, wh + sl * 16);
+        }
+    };
+
+    // ---- this thread's producer unit: pixel (y, x), channels [cb*32 + xc*8, +8) --------------------------------
+    const int xc = t & 3;
+    const int prow = t >> 2;
+    const bool pvalid = m0 + prow < M;
+    const int py = y0 + prow / W, px = prow % W;
+    const int ycls = py == 0 ? 0 : (py == H - 1 ? 1 : 2 + (py & 1));
+    const int xcls = px == 0 ? 0 : (px == W - 1 ? 1 : 2 + (px & 1));
+    const float* fcls = pw + (ycls * 4 + xcls) * 9 * 32 + xc * 8;
+    const float* ppix = pl + (((py >> 1) - (y0 >> 1)) * PC + (px >> 1)) * 32 + xc * 8;   // patch pixel of tap (0, 0)
+    const int xrow_off = pf_lds_chunk_off(prow, xc);
+
+    pf_f32x4 acc[NT][MT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fchunk = lane >> 4;
+
+    if (lo_chunks > 0) {
+        load_patch(0);
+        dma_filters(0);
+        store_patch();
+    }
+    __syncthreads();
+    if (lo_chunks > 1) load_patch(1);
+    for (int cb = 0; cb < cblocks; ++cb) {
+        // ---- phase 1: weights of this step || produce the pixel operand ----------------------------------------
+        dma_weights(cb);
+        float o[8];
+        const int kelem = cb * 32 + xc * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        if (pvalid && kelem < a.inC) {
+            const pf_f32x4 b0 = *reinterpret_cast<const pf_f32x4*>(a.dw_b + kelem), b1 = *reinterpret_cast<const pf_f32x4*>(a.dw_b + kelem + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = b0[e]; o[4 + e] = b1[e]; }
+            if (cb < lo_chunks) {
+#pragma unroll 1
+                for (int j = 0; j < 3; ++j)   // one patch row at a time keeps the live LDS reads (and VGPRs) bounded
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float* pp = ppix + (j * PC + i) * 32;
+                        const float* ww = fcls + (j * 3 + i) * 32;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const pf_f32x4 v4 = *reinterpret_cast<const pf_f32x4*>(pp + 4 * h);
+                            const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(ww + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[4 * h + e] = fmaf(w4[e], v4[e], o[4 * h + e]);
+                        }
+                    }
+            } else {
+                const int C2 = a.inC - a.C1;
+                const float* wd = a.dw_w2 + (kelem - a.C1);
+                const float* sp = sk + (kelem - a.C1);
+#pragma unroll 1
+                for (int k1 = 0; k1 < 3; ++k1) {
+                    const int yy = py - 1 + k1;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; ++k2) {
+                        const int xx = px - 1 + k2;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const pf_f32x4 v4 = *reinterpret_cast<const pf_f32x4*>(sp + ((size_t)yy * W + xx) * a.skipLd + 4 * h);
+                            const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(wd + (size_t)(k1 * 3 + k2) * C2 + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[4 * h + e] = fmaf(w4[e], v4[e], o[4 * h + e]);
+                        }
+                    }
+                }
+            }
+        }
+        {
+            pf_half8 hi, lo8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const pf_half hv = (pf_half)o[e];
+                hi[e] = hv;
+                lo8[e] = (pf_half)(o[e] - (float)hv);
+            }
+            *reinterpret_cast<pf_half8*>(xh + xrow_off) = hi;
+            *reinterpret_cast<pf_half8*>(xl + xrow_off) = lo8;
+        }
+        __syncthreads();
+        // ---- phase 2: next chunk's patch and filters || MFMAs -------------------------------------------------------
+        if (cb + 1 < lo_chunks) {
+            store_patch();
+            dma_filters(cb + 1);
+            if (cb + 2 < lo_chunks) load_patch(cb + 2);
+        }
+        pf_half8 whf[NT], wlf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
+            whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
+            wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
+            const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xh + off);
+            const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xl + off);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(wlf[j], xhf, acc[j][i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xlf, acc[j][i]);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
+        }
+        __syncthreads();
+    }
+    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
+}
+
 // Tile configurations (BM x BN, waves M x N) picked by the host from the padded channel count.
 #define PF_CONV_CFGS(X) X(128, 128, 2, 2) X(128, 64, 2, 2) X(256, 32, 4, 1) X(256, 16, 4, 1)
