@@ -222,6 +222,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.B = B; a.inH = p.hdr.in_h; a.inW = p.hdr.in_w;
                 a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.act = f[4]; a.CO = to.C;
                 if (to.C % 16) PF_FAIL(h, "stem conv needs a multiple of 16 output channels, got %d", to.C);
+                if (a.act != PF_ACT_NONE && a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH && a.act != PF_ACT_SILU) PF_FAIL(h, "stem conv: unsupported activation %d", a.act);
                 ProfScope ps(h, "stem_conv");
                 PF_LAUNCH((stem_conv_kernel<T>), dim3(pf_div_up(B * to.H * to.W, 256), to.C / 16), dim3(256), h->stream, a);
                 break;

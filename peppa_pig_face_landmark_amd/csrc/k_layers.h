@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemArgs a) {
     }
     T* o = static_cast<T*>(a.out) + (size_t)idx * a.outLd + g0;
     constexpr int VE = PfVec<T>::N;
-    pf_act_n<CO>(acc, a.act);
+    mb_act<CO>(acc, a.act);     // stems use hard-swish (Student), SiLU (detector) or ReLU (Teacher)
 #pragma unroll
     for (int v = 0; v < CO / VE; ++v) {
         typename PfVec<T>::type pk;

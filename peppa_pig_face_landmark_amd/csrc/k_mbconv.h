@@ -53,22 +53,6 @@ __device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1
     }
 }
 
-// activations of the fused block kernels: none | relu | hard-swish | SiLU behind one wave-uniform branch
-template <int N, typename V> __device__ __forceinline__ void mb_act(V& v, int act) {
-    if (act == PF_ACT_HSWISH) {
-        asm volatile("");
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_HSWISH>(v[i]);
-    } else if (act == PF_ACT_SILU) {
-        asm volatile("");
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_SILU>(v[i]);
-    } else if (act == PF_ACT_RELU) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_RELU>(v[i]);
-    }
-}
-
 // S: stride, KS: input channels / 32 (rounded up), PH x PW: patch, MAXNT: output channels / 16 (rounded up)
 template <int S, int KS, int PH, int PW, int MAXNT, int MSPLIT>
 __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(MbconvArgs a) {

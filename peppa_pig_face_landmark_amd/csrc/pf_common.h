@@ -79,6 +79,23 @@ template <int N, typename V> __device__ __forceinline__ void pf_act_rh(V& v, int
     }
 }
 
+// none | relu | hard-swish | SiLU (everything the conv-like layers of the two networks use) behind one
+// wave-uniform branch; lighter on registers than pf_act_n when applied to 16+ values at once
+template <int N, typename V> __device__ __forceinline__ void mb_act(V& v, int act) {
+    if (act == PF_ACT_HSWISH) {
+        asm volatile("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_HSWISH>(v[i]);
+    } else if (act == PF_ACT_SILU) {
+        asm volatile("");
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_SILU>(v[i]);
+    } else if (act == PF_ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = pf_act_c<PF_ACT_RELU>(v[i]);
+    }
+}
+
 // 16-byte global load/store of an activation vector
 template <typename T> __device__ __forceinline__ typename PfVec<T>::type pf_ldv(const T* p) {
     return *reinterpret_cast<const typename PfVec<T>::type*>(p);
