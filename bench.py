@@ -183,7 +183,7 @@ def main():
     if hero_n:
         avg_ms = hero_ms / hero_n
         achieved = HERO_FLOP_PER_FACE * faces_per_launch / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "%s<128,128> %s" % ("conv_gemm_split_kernel" if args.dtype == "f32s" else "conv_gemm_kernel<%s>" % args.dtype, HERO_TAG),
+        roofline = {"bound": "mfma", "kernel": "%s %s" % ("conv3x3_halo_split_kernel<128,4,2>" if args.dtype == "f32s" else "conv_gemm_kernel<%s,128,128>" % args.dtype, HERO_TAG),
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
                     "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_launch) if args.dtype != "f16" else int(2 * 64 * 64 * 128 * 2 * faces_per_launch),
