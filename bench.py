@@ -205,6 +205,23 @@ def main():
                    "lane_batch_call_ms_p50": round(lN[0], 4), "lane_batch_frames": args.frames // lanes,
                    "ms_per_frame_p50_at_lane_batch": round(lN[0] / (args.frames // lanes), 4),
                    "note": "synchronous pf_run_frames call on one stream, device-resident frames"}
+    # ---- PCIe-inclusive rate (never the headline): same step with the frames in page-locked HOST memory ----------
+    pcie = None
+    if workload == "pipeline" and rank == 0 and world == 1 and hasattr(state, "enable_host_frames"):
+        state.enable_host_frames()
+        hs = max(2, min(args.steps, 8))
+        state.step_host()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(hs):
+            state.step_host()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        state.check()
+        pcie = {"faces_per_s": round(faces_per_step * hs / dt, 1), "frames_per_s": round(args.frames * hs / dt, 1),
+                "h2d_GBps": round(args.frames * hs * 1080 * 1920 * 3 / dt / 1e9, 2), "steps": hs,
+                "note": "frames handed over in pf_host_alloc (page-locked) host memory, copied inside the call on each lane's "
+                        "stream; results stay on the device (9.5 KB/frame)"}
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
@@ -224,6 +241,7 @@ def main():
                   "algorithmic_tflops": round(value * GFLOP_PER_FACE[args.model] / 1e3, 2),
                   "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE[args.model] / 1e3 / PEAK_TFLOPS[args.dtype], 4),
                   "latency": latency,
+                  "pcie_inclusive": pcie,
                   "setup_s": round(setup_s, 2),
                   "kernel_ms_per_lane_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
     }

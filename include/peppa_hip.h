@@ -32,6 +32,9 @@ extern "C" {
 typedef struct pf_handle pf_handle;
 
 enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1, PF_MEM_RESIDENT = 2 };  /* 2: the frame stored by pf_set_frame (bgr may be NULL) */
+/* pf_run_frames_planted only: OR into `mem` when the frames are in host memory but the planted detector rows
+ * (a test / benchmark instrument, 968 KB per frame) already live on the device */
+enum { PF_MEM_ROWS_DEVICE = 0x100 };
 enum { PF_NET_LANDMARK = 0, PF_NET_DETECTOR = 1, PF_NET_SLOTS = 4 };
 enum { PF_INPUT_U8_NHWC = 0, PF_INPUT_F32_NCHW = 1 };
 enum { PF_DTYPE_F16 = 0, PF_DTYPE_F32 = 1, PF_DTYPE_F32_SPLIT = 2 };  /* 2: f32 tensors, 3 x f16-MFMA split-precision convs */
@@ -127,6 +130,14 @@ int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int wid
 int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                  unsigned long long* abs_diff_sum, int* has_prev);
 int pf_forget_frames(pf_handle* h);
+
+/* Frame ingest (replaces the pageable numpy arrays cv2.imread / VideoCapture.read hand to
+ * FaceAna.run, demo.py:13-17,76): page-locked host memory for frame batches (decode straight into it) and for
+ * results.  Frames passed with mem = PF_MEM_HOST from such a buffer are copied host->device asynchronously on the
+ * handle's stream, so with two handles (two streams) one batch's PCIe transfer overlaps the other batch's kernels;
+ * from pageable memory the same call still works but the copy serialises.  Not tied to a handle. */
+int pf_host_alloc(size_t bytes, void** out);
+int pf_host_free(void* p);
 
 /* Engine options.  PF_OPT_HIP_GRAPH = 1: pf_run_frames* calls whose buffers all live on the device are captured
  * into a hipGraph per distinct (pointers, shapes, thresholds) and replayed (launch-latency bound small batches). */

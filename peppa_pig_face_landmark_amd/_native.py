@@ -12,6 +12,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 PF_MEM_HOST, PF_MEM_DEVICE, PF_MEM_RESIDENT = 0, 1, 2
+PF_MEM_ROWS_DEVICE = 0x100
 PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 PF_OPT_HIP_GRAPH = 1
@@ -53,6 +54,10 @@ def _declare(lib):
     lib.pf_set_option.argtypes = [vp, i, i]
     lib.pf_profile_enable.argtypes = [vp, i]
     lib.pf_profile_fetch.argtypes = [vp, C.c_char_p, sz, fp, ip, i, ip]
+    lib.pf_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    lib.pf_host_free.argtypes = [vp]
+    lib.pf_host_alloc.restype = i
+    lib.pf_host_free.restype = i
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
                  "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
                  "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces", "pf_set_frame", "pf_forget_frames", "pf_set_option"):
@@ -95,7 +100,36 @@ class Engine:
         self.device = device
         self._programs = {}
 
+    def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        """Page-locked host array (pf_host_alloc): decode frames straight into it and pass it to run_frames* so the
+        host->device copy is asynchronous.  Freed by close(); do not use the array afterwards."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        if self.lib.pf_host_alloc(nbytes, C.byref(p)) != 0 or not p.value:
+            raise PeppaHipError("pf_host_alloc(%d bytes) failed" % nbytes)
+        if not hasattr(self, "_pinned"):
+            self._pinned = []
+        self._pinned.append(p)
+        buf = (C.c_ubyte * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def run_frames_host_async(self, frames: np.ndarray, d_planted: int, rows: int, score_thres: float, iou_thres: float,
+                              min_face: float, top_k: int, d_counts: int, d_boxes: int, d_kps: int, d_scores: int):
+        """Host-resident frames (ideally from pinned_empty) in, device-resident results out, no synchronisation:
+        the call returns after enqueueing the copy and the kernels on this engine's stream.  Planted detector rows
+        (benchmark instrument) are passed as a device pointer."""
+        F, H, W, _ = frames.shape
+        assert frames.dtype == np.uint8 and frames.flags["C_CONTIGUOUS"]
+        rc = self.lib.pf_run_frames_planted(self.h, _ptr(frames), PF_MEM_HOST | PF_MEM_ROWS_DEVICE, F, H, W,
+                                            _ptr(d_planted) if d_planted else None, rows, score_thres, iou_thres,
+                                            min_face, top_k, _ptr(d_counts), _ptr(d_boxes), _ptr(d_kps), _ptr(d_scores),
+                                            PF_MEM_DEVICE)
+        self._check(rc, "pf_run_frames_planted")
+
     def close(self):
+        for p in getattr(self, "_pinned", []):
+            self.lib.pf_host_free(p)
+        self._pinned = []
         if getattr(self, "h", None) is not None and self.h:
             self.lib.pf_destroy(self.h)
             self.h = None

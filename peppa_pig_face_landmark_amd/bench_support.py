@@ -168,6 +168,17 @@ class PipelineWorkload:
                                    d_boxes=self.boxes.data_ptr(), d_kps=self.kps.data_ptr(),
                                    d_scores=self.scores.data_ptr())
 
+    def enable_host_frames(self):
+        """Frame ingest seam (next-row N2): the same frames in page-locked HOST memory (pf_host_alloc)."""
+        self.host_frames = self.eng.pinned_empty((self.F, self.H, self.W, 3), np.uint8)
+        self.host_frames[...] = self.frames.cpu().numpy()
+
+    def step_host(self):
+        """One step with the frames crossing PCIe inside the call (host -> device copy on this lane's stream)."""
+        self.eng.run_frames_host_async(self.host_frames, self.rows.data_ptr(), self.ROWS, 0.5, 0.3, 1600.0, self.K,
+                                       self.counts.data_ptr(), self.boxes.data_ptr(), self.kps.data_ptr(),
+                                       self.scores.data_ptr())
+
     def latency_p50(self, frames: int, reps: int = 40):
         """p50 / p99 wall time (ms) of one synchronous call on `frames` frames (submit -> results complete)."""
         import time
@@ -216,6 +227,14 @@ class MultiLanePipeline:
     def check(self):
         for wl in self.lanes:
             wl.check()
+
+    def enable_host_frames(self):
+        for wl in self.lanes:
+            wl.enable_host_frames()
+
+    def step_host(self):
+        for wl in self.lanes:
+            wl.step_host()
 
     def profile(self, steps: int):
         """Per-kernel HIP-event times of lane 0 running ALONE (profiling serialises its launches);

@@ -234,6 +234,8 @@ static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int 
     if (ensure_pipeline(h, F, faces, top_k, det_nrows)) return 1;
     const int row_stride = width * 3;
     const unsigned char* d_frames = nullptr;
+    const bool rows_on_device = (mem & 0xff) == PF_MEM_DEVICE || (mem & PF_MEM_ROWS_DEVICE) != 0;
+    mem &= 0xff;
     if (stage_frames(h, frames, mem, (size_t)F * height * row_stride, &d_frames)) return 1;
     const int in_h = det.loaded ? det.hdr.in_h : 384, in_w = det.loaded ? det.hdr.in_w : 640;
     const LetterboxGeom g = letterbox_geom(height, width, in_h, in_w);
@@ -243,7 +245,7 @@ static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int 
     }
     const float* d_rows = det.loaded ? (const float*)det.buf_ptr(det.hdr.out_buf0) : nullptr;
     if (det_rows) {
-        if (mem == PF_MEM_DEVICE) {
+        if (rows_on_device) {
             d_rows = det_rows;
         } else {
             const size_t bytes = (size_t)F * rows * 16 * sizeof(float);
@@ -312,6 +314,14 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     PF_HIP(h, hipGraphLaunch(e->exec, h->stream));
     return 0;
 }
+
+int pf_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return 1;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes, hipHostMallocPortable) == hipSuccess ? 0 : 1;
+}
+
+int pf_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? 0 : 1; }
 
 int pf_set_option(pf_handle* h, int option, int value) {
     if (!h) return 1;

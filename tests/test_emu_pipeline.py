@@ -180,3 +180,13 @@ def test_resident_frame_and_diff_gate(emu_engine, student_weights):
     emu_engine.set_frame(frame)
     b = emu_engine.landmarks(None, boxes)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_pinned_host_buffer_roundtrip(emu_engine):
+    """pf_host_alloc / pf_host_free (frame ingest seam): the buffer is writable, readable and owned by the engine."""
+    a = emu_engine.pinned_empty((3, 5, 7, 3), np.uint8)
+    a[...] = np.arange(a.size, dtype=np.uint32).reshape(a.shape) % 251
+    assert a.shape == (3, 5, 7, 3) and int(a[2, 4, 6, 2]) == (a.size - 1) % 251
+    b = emu_engine.pinned_empty((16,), np.float32)
+    b[:] = 1.5
+    assert float(b.sum()) == 24.0

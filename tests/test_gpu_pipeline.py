@@ -224,3 +224,35 @@ def test_hip_graph_replay_equals_eager(gpu_engine, student_weights, frame1080):
     again = run()
     assert all(torch.equal(a, b) for a, b in zip(again, replay))
     assert int(replay[0].sum()) == F * K
+
+
+def test_pinned_host_frames_equal_device_frames(gpu_engine, student_weights, frame1080):
+    """SURVEY 8f N2 (frame ingest): a batch handed over in pf_host_alloc (page-locked) host memory and copied inside
+    the call gives bit-identical results to the same batch already resident in HBM."""
+    F, K = 2, 8
+    blob, _ = build_student_program(student_weights, 256, "f32s")
+    gpu_engine.load_program(0, blob, F * K)
+    dev = torch.device("cuda", 0)
+    frames_np, rows_np = [], []
+    for f in range(F):
+        fr, boxes = make_frame(1080, 1920, K, seed=70 + f)
+        frames_np.append(fr)
+        rows_np.append(plant_rows(boxes, (1080, 1920), 15120, (384, 640), 24, seed=70 + f))
+    frames = torch.from_numpy(np.stack(frames_np)).to(dev)
+    rows = torch.from_numpy(np.stack(rows_np)).to(dev)
+    outs = [torch.zeros(F, dtype=torch.int32, device=dev), torch.zeros(F * K, 4, device=dev),
+            torch.zeros(F * K, 98, 2, device=dev), torch.zeros(F * K, 98, device=dev)]
+    gpu_engine.run_frames_device(frames.data_ptr(), F, 1080, 1920, 0.5, 0.3, 1600.0, K, d_planted=rows.data_ptr(),
+                                 rows=15120, d_counts=outs[0].data_ptr(), d_boxes=outs[1].data_ptr(),
+                                 d_kps=outs[2].data_ptr(), d_scores=outs[3].data_ptr())
+    gpu_engine.sync()
+    ref = [o.clone() for o in outs]
+    assert ref[0].tolist() == [K] * F
+    pinned = gpu_engine.pinned_empty((F, 1080, 1920, 3), np.uint8)
+    pinned[...] = np.stack(frames_np)
+    for o in outs:
+        o.zero_()
+    gpu_engine.run_frames_host_async(pinned, rows.data_ptr(), 15120, 0.5, 0.3, 1600.0, K, outs[0].data_ptr(),
+                                     outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr())
+    gpu_engine.sync()
+    assert all(torch.equal(a, b) for a, b in zip(ref, outs))
