@@ -16,8 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpeppa_hip.so")
 SOURCES = ["engine.cpp"]
-DEPS = ["engine.cpp", "pipeline.inl", "k_conv_gemm.h", "k_layers.h", "k_prepost.h", "pf_common.h",
-        "pf_intrinsics.h", "pf_program.h", os.path.join("..", "..", "include", "peppa_hip.h")]
+STAMP = os.path.join(HERE, "libpeppa_hip.srchash")
 
 
 def _hipcc() -> str:
@@ -27,11 +26,24 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (expected /opt/rocm/bin/hipcc)")
 
 
+def source_hash() -> str:
+    """Content hash of every file the library is built from (csrc/* and the public header): the staleness test
+    must not depend on mtimes, which a repository snapshot copied to another machine does not preserve."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "peppa_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+    with open(STAMP) as f:
+        return f.read().strip() != source_hash()
 
 
 def build_hip(force: bool = False, verbose: bool = True) -> str:
@@ -42,6 +54,8 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print("[peppa-hip] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return OUT
 
 
