@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--model", default="student", choices=["student", "teacher"],
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
+    ap.add_argument("--no-probes", action="store_true", help="skip the call-latency and PCIe-inclusive probes (keeps a rocprofv3 "
+                    "--stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=48)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
@@ -198,7 +200,7 @@ def main():
                        "kernels": {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}, f, indent=1)
     latency = None
-    if workload == "pipeline":
+    if workload == "pipeline" and not args.no_probes:
         l1 = state.latency_p50(1)
         lN = state.latency_p50(args.frames // lanes)
         latency = {"single_frame_call_ms_p50": round(l1[0], 4), "single_frame_call_ms_p99": round(l1[1], 4),
@@ -207,7 +209,7 @@ def main():
                    "note": "synchronous pf_run_frames call on one stream, device-resident frames"}
     # ---- PCIe-inclusive rate (never the headline): same step with the frames in page-locked HOST memory ----------
     pcie = None
-    if workload == "pipeline" and rank == 0 and world == 1 and hasattr(state, "enable_host_frames"):
+    if workload == "pipeline" and rank == 0 and world == 1 and hasattr(state, "enable_host_frames") and not args.no_probes:
         state.enable_host_frames()
         hs = max(2, min(args.steps, 8))
         state.step_host()
