@@ -44,8 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto", "landmark", "pipeline"])
     ap.add_argument("--batch", type=int, default=256, help="faces per step per GPU (landmark workload)")
-    ap.add_argument("--frames", type=int, default=64, help="1080p frames per step per GPU (pipeline workload)")
-    ap.add_argument("--lanes", type=int, default=2, help="concurrent HIP streams (engines) per GPU sharing a step's frames")
+    ap.add_argument("--frames", type=int, default=96, help="1080p frames per step per GPU (pipeline workload)")
+    ap.add_argument("--lanes", type=int, default=3, help="concurrent HIP streams (engines) per GPU sharing a step's frames")
     ap.add_argument("--faces-per-frame", type=int, default=8)
     ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
                     help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
