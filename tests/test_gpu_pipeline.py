@@ -256,3 +256,51 @@ def test_pinned_host_frames_equal_device_frames(gpu_engine, student_weights, fra
                                      outs[1].data_ptr(), outs[2].data_ptr(), outs[3].data_ptr())
     gpu_engine.sync()
     assert all(torch.equal(a, b) for a, b in zip(ref, outs))
+
+
+def test_c5_teacher_4k_32_faces(gpu_engine):
+    """BASELINE configs[4] / SURVEY 8d C5 shape: one 2160x3840 frame, 32 faces on an 8 x 4 grid (w = 200, h = 260),
+    Teacher@256 (HRNet-W18): planted detections -> NMS -> top-32 -> crops -> Teacher -> landmarks, against the oracle
+    chain on the same frame (boxes bit-exact, landmarks within the north-star tolerance)."""
+    from oracle import landmark_net as ln
+    from oracle import teacher_net as tn
+    from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program
+    H, W, K = 2160, 3840, 32
+    rng = np.random.default_rng(5)
+    frame = np.clip(np.rint(114 + rng.normal(0, 6, (H, W, 3))), 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    boxes = []
+    for k in range(K):
+        i, j = k % 8, k // 8
+        cx, cy, fw, fh = 240 + 480 * i, 270 + 540 * j, 200 + 3 * k, 260.0      # distinct areas: top-k order is unambiguous
+        m = ((xx - cx) / (fw / 2)) ** 2 + ((yy - cy) / (fh / 2)) ** 2 <= 1.0
+        frame[m] = (140, 170, 210)
+        for dx, dy, r in ((-0.2, -0.15, 0.09), (0.2, -0.15, 0.09), (0.0, 0.25, 0.14)):
+            frame[(xx - (cx + dx * fw)) ** 2 + (yy - (cy + dy * fh)) ** 2 <= (r * fw) ** 2] = (40, 40, 60)
+        boxes.append([cx - fw / 2, cy - fh / 2, cx + fw / 2, cy + fh / 2])
+    boxes = np.asarray(boxes, np.float32)
+    rows = plant_rows(boxes, (H, W), 15120, (384, 640), 24, seed=5)
+    weights = sw.teacher_weights()
+    blob, _ = build_teacher_program(weights, 256, "f32s")
+    gpu_engine.load_program(0, blob, K)
+    counts, bout, kps, scores = gpu_engine.run_frames(frame[None], 0.5, 0.3, 1600.0, K, planted_rows=rows[None])
+    assert counts.tolist() == [K]
+    _, info = pp.detector_preprocess_u8(frame, (384, 640))
+    kept = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+    ref_boxes = pp.sort_and_filter(kept, 1600.0, K)
+    assert ref_boxes.shape[0] == K and np.array_equal(bout[0], ref_boxes[:, :4])
+    assert np.isfinite(kps).all() and np.isfinite(scores).all()
+    Wt = ln.to_torch(weights)
+    worst = 0.0
+    for k in (0, 13, 31):
+        ci = pp.landmark_crop_box(ref_boxes[k], H, W)
+        crop = pp.landmark_crop(frame, ci, (256, 256))
+        x = torch.from_numpy(crop[None].astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+        taps = {}
+        with torch.no_grad():
+            oloc, _ = tn.teacher_forward(Wt, x, taps)
+        ref = pp.landmark_backproject(oloc.numpy()[0], ci)
+        safe = helpers.heat_margins(taps)[0] > 2e-3
+        worst = max(worst, float(np.abs(kps[0, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)))
+    print("C5 Teacher 4K x 32: worst normalised landmark error %.2e" % worst)
+    assert worst < 1e-3
