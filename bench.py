@@ -236,7 +236,9 @@ def main():
         "config": {"workload": ("configs[2] full pipeline: %d x 1080p frames x %d planted faces per GPU per step" % (args.frames, args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
                    "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
-                   "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast %.2f ms" % bcast_ms},
+                   "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast of %.1f MB in %.2f ms%s" % (
+                       sum(len(b) for b in blobs.values()) / 1e6, bcast_ms,
+                       (" = %.1f GB/s" % (sum(len(b) for b in blobs.values()) / 1e9 / (bcast_ms * 1e-3))) if bcast_ms > 0 else "")},
         "roofline": roofline,
         "cpu_baseline": None,
         "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
