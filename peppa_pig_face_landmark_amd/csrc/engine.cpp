@@ -359,6 +359,19 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
                     const int ohw = to.H * to.W;
+                    if (to.H == 32 && to.W == 32 && ti.H == 32 && ti.W == 32) {   // whole 32 x 32 image per workgroup, GEMM straight from global
+                        if (a.Cpad > 64 || (a.inC % 8) || pad != dil * (K - 1) / 2 || to.C != a.N || (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH))
+                            PF_FAIL(h, "expdw(32x32): unsupported shape");
+                        char tagbuf2[96];
+                        tagbuf2[0] = 0;
+                        if (h->profiling) snprintf(tagbuf2, sizeof(tagbuf2), "expdw%dx%dd%d_c%d_n%d_%dx%d", K, K, dil, a.inC, a.N, to.H, to.W);
+                        ProfScope ps2(h, tagbuf2);
+                        dim3 g2(B, pf_div_up(a.N, 16));
+                        if (K == 5 && dil == 1) PF_LAUNCH((expdw_image_kernel<5, 1>), g2, dim3(512), h->stream, a);
+                        else if (K == 3 && dil == 1) PF_LAUNCH((expdw_image_kernel<3, 1>), g2, dim3(512), h->stream, a);
+                        else PF_FAIL(h, "expdw(32x32): no kernel for k%d dil %d", K, dil);
+                        break;
+                    }
                     if (ti.H != to.H || ti.W != to.W || to.W > 16 || (256 % ohw) != 0 || 256 / ohw > 4 || pad != dil * (K - 1) / 2 || to.C != a.N)
                         PF_FAIL(h, "expdw: unsupported shape (%dx%d, k%d pad %d dil %d)", to.H, to.W, K, pad, dil);
                     if (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) PF_FAIL(h, "expdw: activation must be relu or hard-swish");

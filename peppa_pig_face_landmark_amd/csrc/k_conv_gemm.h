@@ -681,6 +681,136 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     }
 }
 
+// ---- expand 1x1 -> depthwise k x k (+ SE squeeze) on 32 x 32 maps: one workgroup = one image x 16 expanded channels ----
+// The 16 x 16 variant above (expdw_epilogue) owns whole images inside a 256-pixel GEMM tile; a 32 x 32 image is 1024
+// pixels, too many rows for the GEMM's LDS staging.  With <= 64 input channels (stage 2 of the Student: 40 -> 120) the
+// expand GEMM is tiny, so it skips LDS altogether: every wave loads the pixel fragments of its 128 pixels straight from
+// global memory (the image's 160 KB of input is re-read by the 8 channel tiles out of L2), splits them and runs
+// 3 MFMAs per 16 x 16 tile; the activated 32 x 32 x 16 tile (67 KB, rows padded so four rows land in different banks)
+// lives in LDS and the depthwise conv reads it there, thread = (channel, image row), as in the 16 x 16 kernel.
+template <int K, int DIL>
+__global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
+    constexpr int HW = 32, CB = 16;
+    constexpr int RS = HW * CB + 16;            // floats per image row in LDS
+    constexpr int PAD = DIL * (K - 1) / 2;
+    constexpr int MAXKS = 2;                    // input channels <= 64
+    __shared__ __attribute__((aligned(16))) float es[HW * RS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x, n0 = blockIdx.y * CB;
+    const int frow = lane & 15, kg = lane >> 4;
+    const int ksteps = a.Cpad / 32;
+    const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)b * HW * HW * a.inLd;
+    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
+    // weight fragments of this channel tile (rows n0 + frow), all K steps
+    pf_half8 whf[MAXKS], wlf[MAXKS];
+    {
+        const int row = min(n0 + frow, a.Npad - 1);
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            whf[ks] = pf_half8{0, 0, 0, 0, 0, 0, 0, 0};
+            wlf[ks] = whf[ks];
+            if (ks < ksteps) {
+                const unsigned char* p = wt + ((size_t)row * ksteps + ks) * 128 + kg * 16;
+                whf[ks] = *reinterpret_cast<const pf_half8*>(p);
+                wlf[ks] = *reinterpret_cast<const pf_half8*>(p + 64);
+            }
+        }
+    }
+    const int cch = 4 * kg;                     // accumulator layout: channels cch..cch+3 of pixel frow
+    pf_f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (n0 + cch + r < a.Npad) ? a.bias[n0 + cch + r] : 0.f;
+    // ---- expand: 8 waves x 8 tiles of 16 pixels ----------------------------------------------------------------
+#pragma unroll 2
+    for (int mt = 0; mt < 8; ++mt) {
+        const int p = wave * 128 + mt * 16 + frow;
+        const float* px = in + (size_t)p * a.inLd;
+        pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            if (ks < ksteps) {
+                const int c = ks * 32 + kg * 8;
+                pf_f32x4 v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                if (c < a.inC) {                // inC % 8 == 0
+                    v0 = *reinterpret_cast<const pf_f32x4*>(px + c);
+                    v1 = *reinterpret_cast<const pf_f32x4*>(px + c + 4);
+                }
+                pf_half8 xh, xl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+                    const pf_half hv = (pf_half)v;
+                    xh[e] = hv;
+                    xl[e] = (pf_half)(v - (float)hv);
+                }
+                acc = pf_mfma_16x16x32_f16(wlf[ks], xh, acc);
+                acc = pf_mfma_16x16x32_f16(whf[ks], xl, acc);
+                acc = pf_mfma_16x16x32_f16(whf[ks], xh, acc);
+            }
+        }
+        pf_f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[r], a.acc_scale, bv[r]);
+        pf_act_rh<4>(v, a.act);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + cch + r >= a.N) v[r] = 0.f;
+        *reinterpret_cast<pf_f32x4*>(es + (p >> 5) * RS + (p & 31) * CB + cch) = v;
+    }
+    // depthwise filters of this thread's channel (requested before the barrier)
+    const int c = t & 15, y = t >> 4;
+    const int n = n0 + c;
+    const bool cok = n < a.N;
+    float wk[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
+    const float bd = cok ? a.dw_b[n] : 0.f;
+    __syncthreads();
+    // ---- depthwise: thread = (channel c, image row y) -------------------------------------------------------------
+    float o[HW];
+#pragma unroll
+    for (int x = 0; x < HW; ++x) o[x] = bd;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int yy = y + ky * DIL - PAD;
+        if ((unsigned)yy >= (unsigned)HW) continue;
+        const float* erow = es + yy * RS + c;
+        float iv[HW];
+#pragma unroll
+        for (int x = 0; x < HW; ++x) iv[x] = erow[x * CB];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const float w = wk[ky * K + kx];
+#pragma unroll
+            for (int x = 0; x < HW; ++x) {
+                const int xx = x + kx * DIL - PAD;           // compile-time register index
+                if (xx >= 0 && xx < HW) o[x] = fmaf(w, iv[xx], o[x]);
+            }
+        }
+    }
+    pf_act_rh<HW>(o, a.act);
+    float rs = 0.f;
+    if (cok) {
+        float* out = static_cast<float*>(a.out) + ((size_t)b * HW * HW + (size_t)y * HW) * a.outLd + n;
+#pragma unroll
+        for (int x = 0; x < HW; ++x) {
+            out[(size_t)x * a.outLd] = o[x];
+            rs += o[x];
+        }
+    }
+    if (a.gap_out) {
+        __syncthreads();                        // E is dead: its LDS becomes the row-sum scratch
+        es[y * CB + c] = rs;
+        __syncthreads();
+        if (t < CB && n0 + t < a.N) {
+            float tot = 0.f;
+#pragma unroll
+            for (int r = 0; r < HW; ++r) tot += es[r * CB + t];
+            a.gap_out[(size_t)b * a.N + n0 + t] = tot / (float)(HW * HW);
+        }
+    }
+}
+
 // ---- 3x3 stride-1 convolution with the input tile (plus halo) resident in LDS -------------------------------
 // The generic kernel above is an im2col pipeline: every tap re-fetches, re-splits and re-writes the same 128
 // pixels x 32 channels (9x per channel chunk).  Here a workgroup's 128 output pixels are BM / W whole image rows;

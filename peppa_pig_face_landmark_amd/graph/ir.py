@@ -341,7 +341,10 @@ class ProgramBuilder:
                  [self._tb(x), self._tb(res)], [self._tb(out)])
         return out
 
-    def expdw_supported(self, H: int, W: int, k: int, stride: int, pad: int, dil: int) -> bool:
+    def expdw_supported(self, H: int, W: int, k: int, stride: int, pad: int, dil: int, cin: int = 0) -> bool:
+        if (H, W) == (32, 32):      # whole-image kernel (expdw_image_kernel): <= 64 input channels
+            return (self.split and stride == 1 and 0 < cin <= 64 and cin % 8 == 0 and (k, dil) in ((3, 1), (5, 1))
+                    and pad == dil * (k - 1) // 2)
         ohw = H * W
         return (self.split and stride == 1 and W <= 16 and 256 % ohw == 0 and 256 // ohw <= 4
                 and (k, dil) in ((3, 1), (5, 1), (5, 2)) and pad == dil * (k - 1) // 2)
@@ -354,7 +357,7 @@ class ProgramBuilder:
         mid, cin = w_exp.shape[:2]
         k = w_dw.shape[2]
         assert cin == ti.real_c and w_dw.shape == (mid, 1, k, k) and mid % self.ve == 0
-        assert self.expdw_supported(ti.H, ti.W, k, 1, pad, dil)
+        assert self.expdw_supported(ti.H, ti.W, k, 1, pad, dil, cin)
         out = self.tensor(ti.H, ti.W, mid, name=out_name)
         woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(w_exp, force_split=True)
         be = np.zeros(npad, np.float64)

@@ -66,7 +66,7 @@ def _check(eng, weights, size, batch):
     assert np.abs(score1 - score0)[safe].max() < 2e-3
 
 
-@pytest.mark.parametrize("size,batch", [(64, 3), (128, 2)])
+@pytest.mark.parametrize("size,batch", [(64, 3), (128, 2), (256, 1)])
 def test_fused_blocks_match_unfused_emu(emu_engine, student_weights, size, batch):
     _check(emu_engine, student_weights, size, batch)
 
