@@ -359,6 +359,18 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
                     const int ohw = to.H * to.W;
+                    const int dstride = f[15] > 0 ? f[15] : 1;
+                    if (dstride == 2) {   // 64 x 64 -> 32 x 32, depthwise stride 2: whole image per workgroup, quadrant by quadrant
+                        if (ti.H != 64 || ti.W != 64 || to.H != 32 || to.W != 32 || a.Cpad != 32 || (a.inC % 8) || K != 5 || dil != 1 || pad != 2 ||
+                            to.C != a.N || (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH))
+                            PF_FAIL(h, "expdw(stride 2): unsupported shape");
+                        char tagbuf2[96];
+                        tagbuf2[0] = 0;
+                        if (h->profiling) snprintf(tagbuf2, sizeof(tagbuf2), "expdw%dx%ds2_c%d_n%d_%dx%d", K, K, a.inC, a.N, to.H, to.W);
+                        ProfScope ps2(h, tagbuf2);
+                        PF_LAUNCH((expdw_image_s2_kernel<5>), dim3(B, pf_div_up(a.N, 16)), dim3(512), h->stream, a);
+                        break;
+                    }
                     if (to.H == 32 && to.W == 32 && ti.H == 32 && ti.W == 32) {   // whole 32 x 32 image per workgroup, GEMM straight from global
                         if (a.Cpad > 64 || (a.inC % 8) || pad != dil * (K - 1) / 2 || to.C != a.N || (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH))
                             PF_FAIL(h, "expdw(32x32): unsupported shape");

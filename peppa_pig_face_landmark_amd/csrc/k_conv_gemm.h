@@ -811,6 +811,117 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
     }
 }
 
+// ---- same for the stride-2 block that enters stage 2 (64 x 64 x 24 -> expand 72 -> depthwise 5x5 / 2 -> 32 x 32) -------------
+// One workgroup = one image x 16 expanded channels, looping over the four 16 x 16 output quadrants: per quadrant the
+// expand conv is evaluated on the 35 x 35 input pixels the quadrant's windows cover (1.2x recompute, input from L2,
+// pixels outside the image forced to 0 = the depthwise conv's zero padding), parked in LDS (78 KB) and consumed by the
+// strided depthwise conv, thread = (channel, output row, half row).  The SE squeeze is complete per workgroup because it
+// visits all four quadrants.  Input channels <= 32 (one K step).
+template <int K>
+__global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) {
+    constexpr int IN = 64, OUT = 32, Q = 16, CB = 16;    // input / output size, quadrant size, channels per workgroup
+    constexpr int PAD = (K - 1) / 2;
+    constexpr int R = (Q - 1) * 2 + K;                   // 35: input rows / columns a quadrant needs
+    constexpr int RS = R * CB + 8;                       // floats per region row: 2 * RS = 48 (mod 64) -> 4 output rows, 4 bank groups
+    constexpr int NPX = R * R, MTILES = (NPX + 15) / 16;
+    constexpr int OX = Q / 2, SPAN = (OX - 1) * 2 + K;   // outputs per thread along x, input span they need
+    __shared__ __attribute__((aligned(16))) float es[R * RS];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int b = blockIdx.x, n0 = blockIdx.y * CB;
+    const int frow = lane & 15, kg = lane >> 4;
+    const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)b * IN * IN * a.inLd;
+    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
+    const int wrow = min(n0 + frow, a.Npad - 1);
+    const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wt + (size_t)wrow * 128 + kg * 16);
+    const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wt + (size_t)wrow * 128 + 64 + kg * 16);
+    const int cch = 4 * kg;
+    pf_f32x4 bv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = (n0 + cch + r < a.Npad) ? a.bias[n0 + cch + r] : 0.f;
+    const int c = t & 15, y = (t >> 4) & 15, xh = t >> 8;
+    const int n = n0 + c;
+    const bool cok = n < a.N;
+    float wk[K * K];
+#pragma unroll
+    for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
+    const float bd = cok ? a.dw_b[n] : 0.f;
+    float rs = 0.f;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int oy0 = (q >> 1) * Q, ox0 = (q & 1) * Q;
+        const int iy0 = oy0 * 2 - PAD, ix0 = ox0 * 2 - PAD;
+        // ---- expand on the quadrant's input region ---------------------------------------------------------------
+        for (int mt = wave; mt < MTILES; mt += 8) {
+            const int p = mt * 16 + frow;
+            const int ry = p / R, rx = p - ry * R;
+            const int iy = iy0 + ry, ix = ix0 + rx;
+            const bool ok = p < NPX && (unsigned)iy < (unsigned)IN && (unsigned)ix < (unsigned)IN;
+            pf_f32x4 v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+            if (ok && kg * 8 < a.inC) {
+                const float* px = in + ((size_t)iy * IN + ix) * a.inLd + kg * 8;
+                v0 = *reinterpret_cast<const pf_f32x4*>(px);
+                v1 = *reinterpret_cast<const pf_f32x4*>(px + 4);
+            }
+            pf_half8 xhf, xlf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+                const pf_half hv = (pf_half)v;
+                xhf[e] = hv;
+                xlf[e] = (pf_half)(v - (float)hv);
+            }
+            pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            acc = pf_mfma_16x16x32_f16(wlf, xhf, acc);
+            acc = pf_mfma_16x16x32_f16(whf, xlf, acc);
+            acc = pf_mfma_16x16x32_f16(whf, xhf, acc);
+            pf_f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[r], a.acc_scale, bv[r]);
+            pf_act_rh<4>(v, a.act);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (!ok || n0 + cch + r >= a.N) v[r] = 0.f;        // zero padding of the EXPANDED map / padding channels
+            if (p < NPX) *reinterpret_cast<pf_f32x4*>(es + ry * RS + rx * CB + cch) = v;
+        }
+        __syncthreads();
+        // ---- depthwise K x K / 2: thread = (channel, output row y, half row xh) ----------------------------------------
+        float o[OX];
+#pragma unroll
+        for (int x = 0; x < OX; ++x) o[x] = bd;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const float* erow = es + (2 * y + ky) * RS + (2 * xh * OX) * CB + c;
+            float iv[SPAN];
+#pragma unroll
+            for (int i = 0; i < SPAN; ++i) iv[i] = erow[i * CB];
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                for (int x = 0; x < OX; ++x) o[x] = fmaf(wk[ky * K + kx], iv[2 * x + kx], o[x]);
+        }
+        pf_act_rh<OX>(o, a.act);
+        if (cok) {
+            float* out = static_cast<float*>(a.out) + ((size_t)b * OUT * OUT + (size_t)(oy0 + y) * OUT + ox0 + xh * OX) * a.outLd + n;
+#pragma unroll
+            for (int x = 0; x < OX; ++x) {
+                out[(size_t)x * a.outLd] = o[x];
+                rs += o[x];
+            }
+        }
+        __syncthreads();                        // the next quadrant overwrites the region
+    }
+    if (a.gap_out) {
+        es[(t >> 4) * CB + c] = rs;             // 32 partial sums per channel
+        __syncthreads();
+        if (t < CB && n0 + t < a.N) {
+            float tot = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) tot += es[r * CB + t];
+            a.gap_out[(size_t)b * a.N + n0 + t] = tot / (float)(OUT * OUT);
+        }
+    }
+}
+
 // ---- 3x3 stride-1 convolution with the input tile (plus halo) resident in LDS -------------------------------
 // The generic kernel above is an im2col pipeline: every tap re-fetches, re-splits and re-writes the same 128
 // pixels x 32 channels (9x per channel chunk).  Here a workgroup's 128 output pixels are BM / W whole image rows;

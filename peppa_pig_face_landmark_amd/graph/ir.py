@@ -342,6 +342,8 @@ class ProgramBuilder:
         return out
 
     def expdw_supported(self, H: int, W: int, k: int, stride: int, pad: int, dil: int, cin: int = 0) -> bool:
+        if (H, W) == (64, 64) and stride == 2:   # expdw_image_s2_kernel: 64x64 -> 32x32, 5x5, <= 32 input channels
+            return self.split and 0 < cin <= 32 and cin % 8 == 0 and (k, dil, pad) == (5, 1, 2)
         if (H, W) == (32, 32):      # whole-image kernel (expdw_image_kernel): <= 64 input channels
             return (self.split and stride == 1 and 0 < cin <= 64 and cin % 8 == 0 and (k, dil) in ((3, 1), (5, 1))
                     and pad == dil * (k - 1) // 2)
@@ -350,22 +352,22 @@ class ProgramBuilder:
                 and (k, dil) in ((3, 1), (5, 1), (5, 2)) and pad == dil * (k - 1) // 2)
 
     def expdw(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray, act: str, *,
-              pad: int, dil: int = 1, want_gap: bool = False, out_name: str = "") -> Tuple[int, int]:
+              pad: int, dil: int = 1, stride: int = 1, want_gap: bool = False, out_name: str = "") -> Tuple[int, int]:
         """Pointwise expand + depthwise kxk (+BN, act each) in one launch; the expanded tensor stays in LDS.
         Returns (depthwise output tensor, buffer with its per-face channel means or -1)."""
         ti = self.tensors[x]
         mid, cin = w_exp.shape[:2]
         k = w_dw.shape[2]
         assert cin == ti.real_c and w_dw.shape == (mid, 1, k, k) and mid % self.ve == 0
-        assert self.expdw_supported(ti.H, ti.W, k, 1, pad, dil, cin)
-        out = self.tensor(ti.H, ti.W, mid, name=out_name)
+        assert self.expdw_supported(ti.H, ti.W, k, stride, pad, dil, cin)
+        out = self.tensor(ti.H // stride, ti.W // stride, mid, name=out_name)
         woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(w_exp, force_split=True)
         be = np.zeros(npad, np.float64)
         be[:mid] = b_exp
         gap = self.buffer(mid, ELEM_F32, "gap") if want_gap else -1
         wd = np.transpose(w_dw.astype(np.float64).reshape(mid, k * k), (1, 0))
         self._op(OP_EXPDW, [x, out, gap, woff, self.const_f32(be), self.const_f32(wd), self.const_f32(b_dw), k, pad, dil,
-                            ACT[act], cpad, npad, mid, struct.unpack("<i", struct.pack("<f", acc_scale))[0]],
+                            ACT[act], cpad, npad, mid, struct.unpack("<i", struct.pack("<f", acc_scale))[0], stride],
                  [self._tb(x)], [self._tb(out), gap])
         return out, gap
 

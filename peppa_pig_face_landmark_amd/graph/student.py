@@ -168,7 +168,7 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 if fuse_mbconv and pb.expdw_supported(ti.H, ti.W, k, s, pad, cur_dil, cin):
                     we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
                     wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
-                    x, pooled = pb.expdw(x, we, be, wd, bd, act, pad=pad, dil=cur_dil, want_gap=bool(se), out_name=f"{p}.dw")
+                    x, pooled = pb.expdw(x, we, be, wd, bd, act, pad=pad, dil=cur_dil, stride=s, want_gap=bool(se), out_name=f"{p}.dw")
                 else:
                     wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
                     x = pb.conv(x, wt, b, act, out_name=f"{p}.pw")
