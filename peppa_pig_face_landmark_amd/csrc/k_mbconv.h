@@ -282,12 +282,13 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 
 // ---- exact-f32 variant for the two high-resolution blocks (16 / 24 input channels, 24 outputs) ---------------
 // Same wave-per-patch structure, v_mfma_f32_16x16x4_f32 on f32 fragments: with so few channels the split
-// path's hi/lo fragments double the register footprint (occupancy 4 -> 5-6 waves per SIMD matters more
-// here than matrix throughput, the block is latency/bandwidth bound).  16 expanded channels per step.
+// path's hi/lo fragments double the register footprint and spill (0.42 vs 0.26 ms on block 1.0); the block is
+// latency/bandwidth bound, not matrix bound.  16 expanded channels per step.  Launch bound = 3 waves per SIMD:
+// capped at 128 VGPRs (4 waves) the 24-channel variant spills 14 registers and runs 20 % slower.
 // NOEXP: depthwise-separable block (timm DepthwiseSeparableConv, encoder block 0): no expand conv, the
 // "expanded" map is the input itself (the halo fragments are stored to LDS as they are).
 template <int S, int CP, int PH, int PW, bool NOEXP = false>
-__global__ __launch_bounds__(256, 4) void mbconv_wave_f32_kernel(MbconvArgs a) {
+__global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     constexpr int PP = PH * PW, MPW = PP / 16;
     constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
     constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
