@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=96, help="1080p frames per step per GPU (pipeline workload)")
     ap.add_argument("--lanes", type=int, default=3, help="concurrent HIP streams (engines) per GPU sharing a step's frames")
     ap.add_argument("--faces-per-frame", type=int, default=8)
+    ap.add_argument("--frame-hw", type=int, nargs=2, default=[1080, 1920], metavar=("H", "W"),
+                    help="frame size; --frame-hw 2160 3840 --faces-per-frame 32 --model teacher = BASELINE config 5")
     ap.add_argument("--dtype", default="f32s", choices=["f32", "f32s", "f16"],
                     help="f32: exact v_mfma_f32 convs; f32s (default): f32 tensors + split-precision 3xf16 MFMA convs "
                          "(same accuracy); f16: f16 storage fast mode (parity not claimed)")
@@ -142,11 +144,12 @@ def main():
     if workload == "landmark":
         state = bs.LandmarkWorkload(eng, dev, args.batch, seed=1234 + rank)
     elif lanes == 1:
-        state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank, graph=not args.no_graph)
+        state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank, graph=not args.no_graph,
+                                    frame_hw=tuple(args.frame_hw))
     else:
         eng.close()
         state = bs.MultiLanePipeline(lambda: Engine(local_rank), blobs, dev, args.frames, args.faces_per_frame,
-                                     seed=7 + rank, lanes=lanes, graph=not args.no_graph)
+                                     seed=7 + rank, lanes=lanes, graph=not args.no_graph, frame_hw=tuple(args.frame_hw))
         eng = state.lanes[0].eng
 
     def barrier():
@@ -221,19 +224,20 @@ def main():
         dt = time.perf_counter() - t1
         state.check()
         pcie = {"faces_per_s": round(faces_per_step * hs / dt, 1), "frames_per_s": round(args.frames * hs / dt, 1),
-                "h2d_GBps": round(args.frames * hs * 1080 * 1920 * 3 / dt / 1e9, 2), "steps": hs,
+                "h2d_GBps": round(args.frames * hs * args.frame_hw[0] * args.frame_hw[1] * 3 / dt / 1e9, 2), "steps": hs,
                 "note": "frames handed over in pf_host_alloc (page-locked) host memory, copied inside the call on each lane's "
                         "stream; results stay on the device (9.5 KB/frame)"}
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
     out = {
-        "metric": "faces/sec (whole node), %s@256" % args.model.capitalize() + (" 1080px8-face full pipeline" if workload == "pipeline" else " landmark-only"),
+        "metric": "faces/sec (whole node), %s@256" % args.model.capitalize() + ((" %dpx%d-face full pipeline" % (args.frame_hw[0], args.faces_per_frame)) if workload == "pipeline" else " landmark-only"),
         "value": round(value, 1), "unit": "faces/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"f32": "f32", "f16": "f16", "f32s": "f32 (tensors f32; convs = 3x f16-MFMA split precision, f32 accumulate)"}[args.dtype],
         "data": "synthetic",
-        "config": {"workload": ("configs[2] full pipeline: %d x 1080p frames x %d planted faces per GPU per step" % (args.frames, args.faces_per_frame))
+        "config": {"workload": ("%s full pipeline: %d x %dx%d frames x %d planted faces per GPU per step" % (
+                       "configs[2]" if tuple(args.frame_hw) == (1080, 1920) else "configs[4]-shaped", args.frames, args.frame_hw[1], args.frame_hw[0], args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
                    "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
                    "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast of %.1f MB in %.2f ms%s" % (

@@ -142,14 +142,19 @@ class PipelineWorkload:
 
     H, W, ROWS = 1080, 1920, 15120
 
-    def __init__(self, eng, dev, frames: int, faces_per_frame: int, seed: int, graph: bool = True):
+    def __init__(self, eng, dev, frames: int, faces_per_frame: int, seed: int, graph: bool = True,
+                 frame_hw: Tuple[int, int] = (1080, 1920)):
         import torch
-        from .synth import make_frame, plant_rows
+        from .synth import make_frame, make_frame_grid, plant_rows
         self.eng, self.F, self.K = eng, frames, faces_per_frame
+        self.H, self.W = frame_hw                            # (2160, 3840) x 32 faces = BASELINE config 5 / SURVEY C5
         eng.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)   # replay the step from a captured hipGraph
         base_frames, base_rows = [], []
         for i in range(min(frames, 2)):
-            fr, boxes = make_frame(self.H, self.W, faces_per_frame, seed=seed + i)
+            if faces_per_frame == 32:
+                fr, boxes = make_frame_grid(self.H, self.W, 8, 4, seed=seed + i)
+            else:
+                fr, boxes = make_frame(self.H, self.W, faces_per_frame, seed=seed + i)
             base_frames.append(fr)
             base_rows.append(plant_rows(boxes, (self.H, self.W), self.ROWS, (384, 640), 24, seed=seed + i))
         reps = (frames + len(base_frames) - 1) // len(base_frames)
@@ -211,14 +216,14 @@ class MultiLanePipeline:
     large ones of the others: 34.9 k / 39.2 k / 40.4 k / 39.1 k faces/s at 1 / 2 / 3 / 4 lanes (32 frames per lane) on MI355X."""
 
     def __init__(self, make_engine, blobs, dev, frames: int, faces_per_frame: int, seed: int, lanes: int = 2,
-                 graph: bool = True):
+                 graph: bool = True, frame_hw: Tuple[int, int] = (1080, 1920)):
         assert frames % lanes == 0
         self.lanes = []
         per = frames // lanes
         for i in range(lanes):
             eng = make_engine()
             load_programs(eng, blobs, "pipeline", per * faces_per_frame, per)
-            self.lanes.append(PipelineWorkload(eng, dev, per, faces_per_frame, seed + 101 * i, graph=graph))
+            self.lanes.append(PipelineWorkload(eng, dev, per, faces_per_frame, seed + 101 * i, graph=graph, frame_hw=frame_hw))
 
     def step(self):
         for wl in self.lanes:

@@ -25,6 +25,24 @@ def make_frame(h=1080, w=1920, n_faces=8, seed=7, face_w=200, face_h=260):
     return frame, np.asarray(boxes, np.float32)
 
 
+def make_frame_grid(h, w, cols, rows, face_w=200.0, face_h=260.0, seed=5):
+    """BGR uint8 frame with cols x rows faces of fixed size (2160x3840, 8 x 4 grid, 200 x 260); the k-th
+    face is 3k pixels wider so that top-k-by-area is unambiguous.  Returns (frame, boxes_xyxy float32 [cols*rows, 4])."""
+    rng = np.random.default_rng(seed)
+    frame = np.clip(np.rint(114 + rng.normal(0, 6, (h, w, 3))), 0, 255).astype(np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    boxes = []
+    for k in range(cols * rows):
+        i, j = k % cols, k // cols
+        cx, cy = (i + 0.5) * w / cols, (j + 0.5) * h / rows
+        fw, fh = face_w + 3 * k, face_h
+        frame[((xx - cx) / (fw / 2)) ** 2 + ((yy - cy) / (fh / 2)) ** 2 <= 1.0] = (140, 170, 210)
+        for dx, dy, r in ((-0.2, -0.15, 0.09), (0.2, -0.15, 0.09), (0.0, 0.25, 0.14)):
+            frame[(xx - (cx + dx * fw)) ** 2 + (yy - (cy + dy * fh)) ** 2 <= (r * fw) ** 2] = (40, 40, 60)
+        boxes.append([cx - fw / 2, cy - fh / 2, cx + fw / 2, cy + fh / 2])
+    return frame, np.asarray(boxes, np.float32)
+
+
 def plant_rows(boxes_xyxy, frame_hw, n_rows=15120, input_hw=(384, 640), per_box=24, seed=7):
     """Decoded-detector-output rows [n_rows,16] in letterboxed coordinates: for every box 24 jittered
     candidates with distinct scores in (0.55, 0.99) -- the best one is the un-jittered box -- and

@@ -265,20 +265,9 @@ def test_c5_teacher_4k_32_faces(gpu_engine):
     from oracle import landmark_net as ln
     from oracle import teacher_net as tn
     from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program
+    from peppa_pig_face_landmark_amd.synth import make_frame_grid
     H, W, K = 2160, 3840, 32
-    rng = np.random.default_rng(5)
-    frame = np.clip(np.rint(114 + rng.normal(0, 6, (H, W, 3))), 0, 255).astype(np.uint8)
-    yy, xx = np.mgrid[0:H, 0:W]
-    boxes = []
-    for k in range(K):
-        i, j = k % 8, k // 8
-        cx, cy, fw, fh = 240 + 480 * i, 270 + 540 * j, 200 + 3 * k, 260.0      # distinct areas: top-k order is unambiguous
-        m = ((xx - cx) / (fw / 2)) ** 2 + ((yy - cy) / (fh / 2)) ** 2 <= 1.0
-        frame[m] = (140, 170, 210)
-        for dx, dy, r in ((-0.2, -0.15, 0.09), (0.2, -0.15, 0.09), (0.0, 0.25, 0.14)):
-            frame[(xx - (cx + dx * fw)) ** 2 + (yy - (cy + dy * fh)) ** 2 <= (r * fw) ** 2] = (40, 40, 60)
-        boxes.append([cx - fw / 2, cy - fh / 2, cx + fw / 2, cy + fh / 2])
-    boxes = np.asarray(boxes, np.float32)
+    frame, boxes = make_frame_grid(H, W, 8, 4, seed=5)     # distinct areas: top-k order is unambiguous
     rows = plant_rows(boxes, (H, W), 15120, (384, 640), 24, seed=5)
     weights = sw.teacher_weights()
     blob, _ = build_teacher_program(weights, 256, "f32s")
