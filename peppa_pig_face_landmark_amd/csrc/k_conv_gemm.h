@@ -1296,6 +1296,3 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     }
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }
-
-// Tile configurations (BM x BN, waves M x N) picked by the host from the padded channel count.
-#define PF_CONV_CFGS(X) X(128, 128, 2, 2) X(128, 64, 2, 2) X(256, 32, 4, 1) X(256, 16, 4, 1)
