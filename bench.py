@@ -1,17 +1,21 @@
 #!/usr/bin/env python
 """Benchmark of the FaceAna hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic input that is already
-resident in HBM when the timed region starts:
+N > 1 without a launcher self-spawns N ranks (one per GPU) under torch.distributed.run; launched by
+torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE and insists that WORLD_SIZE == N.
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in
+HBM when the timed region starts, results delivered to page-locked HOST buffers inside the step
+(FaceAna.run() returns numpy, facer.py:84-96):
   --workload pipeline : BASELINE.json configs[2] -- F 1080p frames x 8 planted faces each through
                         letterbox -> detector net -> decode -> NMS -> top-k -> crop/resize ->
-                        Student@256 -> heat-map decode -> back-projection   (default when built)
+                        Student@256 -> heat-map decode -> back-projection   (default)
   --workload landmark : BASELINE.json configs[1] -- 256 pre-cropped 256x256 faces through Student@256
 Frames / faces shard across ranks with no data-path collective (weak scaling: per-rank work is
-fixed); the only collective is the one-time RCCL broadcast of the packed weights from rank 0.
-Prints ONE JSON line (rank 0).
+fixed); the only collective is the one-time RCCL broadcast of the packed weights from rank 0, issued
+by the engine itself (pf_broadcast_weights -> ncclBroadcast).  Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
@@ -32,9 +36,22 @@ GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstre
 # dense MFMA peaks (MI355X_MICROARCH.md).  "f32s" = f32 tensors, split-precision convs: every product
 # is 3 v_mfma_f32_16x16x32_f16 instructions (hi*hi + hi*lo + lo*hi), so it is priced against the f16 pipe.
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
+PEAK_HBM_GBPS = 8000.0
 MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
 HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
+# algorithmic FLOPs per face of the other dense kernels of the Student (MACs x 2, model.py line ranges in DESIGN.md 5)
+DENSE_FLOP_PER_FACE = {
+    "conv3x3_c128_n128_64x64": 2.0 * 4096 * 128 * 128 * 9,
+    "sepup_c280_n128_64x64": 2.0 * 4096 * 280 * (128 + 9),
+    "sepup_c296_n256_32x32": 2.0 * 1024 * 296 * (256 + 9),
+    "conv1x1_argmax_c128_n98_64x64": 2.0 * 4096 * 128 * 294,       # the whole hm head (98 scores executed; offsets at the arg-max only)
+    "conv1x1_c960_n160_16x16": 2.0 * 256 * 960 * 160,
+    "expdw5x5d2_c160_n960_16x16": 2.0 * 256 * 960 * (160 + 25),
+    "expdw5x5d1_c112_n672_16x16": 2.0 * 256 * 672 * (112 + 25),
+    "expdw3x3d1_c112_n672_16x16": 2.0 * 256 * 672 * (112 + 9),
+    "conv3x3_c160_n64_16x16": 2.0 * 256 * 160 * 64 * 9,
+}
 
 
 def parse_args():
@@ -55,67 +72,224 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a hipGraph")
     ap.add_argument("--model", default="student", choices=["student", "teacher"],
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
-    ap.add_argument("--no-probes", action="store_true", help="skip the call-latency and PCIe-inclusive probes (keeps a rocprofv3 "
-                    "--stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
+    ap.add_argument("--no-probes", action="store_true", help="skip the call-latency, sustained-loop and PCIe-inclusive probes (keeps a "
+                    "rocprofv3 --stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
+    ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
+                    "(a sustained rate an external GPU-busy sampler can see)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-faces", type=int, default=48)
+    ap.add_argument("--cpu-faces", type=int, default=24)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="plumbing check without a GPU: launch / rendezvous (gloo) / weight-blob broadcast / frame sharding "
+                         "only, no compute, value = null (used by the CPU test tier; never a measurement)")
     return ap.parse_args()
 
 
-def cpu_baseline(workload: str, n_faces: int):
-    """Reference-shaped CPU path timed on this box's host cores: the torch-CPU oracle (stand-in for
-    onnxruntime-CPU, which is not installed) run exactly like face_landmark.py:40-48 -- one face at
-    a time, batch 1, float32 -- on a bounded sample.  Baseline, not target."""
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(n_faces: int, frame_hw, faces_per_frame: int):
+    """Reference-shaped CPU path timed on this box's host cores (baseline, NOT the target).  onnxruntime is not
+    installed, so the torch-CPU oracle stands in for ORT-CPU; pre/post-processing is the numpy restatement of the
+    reference's own (oracle/prepost.py).  Three figures on bounded samples:
+      landmark_b1  the reference's execution shape -- one face per call, python loop (face_landmark.py:40-48)
+      landmark_b8  the same network fed 8 faces per call (a batch path the reference never wrote, :119)
+      pipeline     FaceAna.run()+reset() on whole frames: letterbox, detector net, NMS, per-face crop + forward
+    The torch thread count is tuned on a 2-face probe (more threads than physical cores made round 1's figure
+    worse) and stated."""
     import torch
+    from oracle import detector_net as dn
     from oracle import landmark_net as ln
+    from oracle import prepost as pp
     from oracle import synth_weights as sw
+    from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
 
+    t_all = time.perf_counter()
     W = ln.to_torch(sw.student_weights())
     crops = sw.smooth_blob_images(8, 256, seed=99)
     x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
+    best_thr, best_t = cands[0], 1e30
     with torch.no_grad():
+        for thr in cands:
+            torch.set_num_threads(thr)
+            ln.student_forward(W, x[:1])
+            t0 = time.perf_counter()
+            ln.student_forward(W, x[:1]); ln.student_forward(W, x[1:2])
+            dt = time.perf_counter() - t0
+            if dt < best_t:
+                best_thr, best_t = thr, dt
+        torch.set_num_threads(best_thr)
         ln.student_forward(W, x[:1])
         t0 = time.perf_counter()
         for i in range(n_faces):
             ln.student_forward(W, x[i % 8:i % 8 + 1])
-        dt = time.perf_counter() - t0
-    return {"value": round(n_faces / dt, 2), "unit": "faces/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d faces, Student@256 landmark forward only, batch=1 python loop (face_landmark.py:40-48 shape), "
-                      "torch-CPU f32 oracle as stand-in for onnxruntime-CPU; %.1f s" % (n_faces, dt)}
+        dt_b1 = time.perf_counter() - t0
+        ln.student_forward(W, x)
+        nb8 = max(1, n_faces // 8)
+        t0 = time.perf_counter()
+        for _ in range(nb8):
+            ln.student_forward(W, x)
+        dt_b8 = time.perf_counter() - t0
+        # full pipeline on one frame (x faces_per_frame faces), the reference's order of operations
+        H, Wd = frame_hw
+        frame, boxes = make_frame(H, Wd, faces_per_frame, seed=7)
+        rows = plant_rows(boxes, (H, Wd), 15120, (384, 640), 24, seed=7)
+        DW = ln.to_torch(sw.detector_weights())
+        t0 = time.perf_counter()
+        xin, info = pp.detector_preprocess(frame, (384, 640))
+        dn.detector_forward(DW, torch.from_numpy(xin))               # its output is replaced by the planted rows below
+        kept = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+        sel = pp.sort_and_filter(kept, 1600.0, faces_per_frame)
+        for k in range(sel.shape[0]):
+            ci = pp.landmark_crop_box(sel[k], H, Wd)
+            crop = pp.landmark_crop(frame, ci, (256, 256))
+            loc, _ = ln.student_forward(W, torch.from_numpy(pp.landmark_input(crop)))[:2]
+            pp.landmark_backproject(loc[0].numpy(), ci)
+        dt_pipe = time.perf_counter() - t0
+        n_pipe = int(sel.shape[0])
+    return {"value": round(n_faces / dt_b1, 2), "unit": "faces/s", "cores": best_thr, "kind": "port",
+            "sample": "%d faces, Student@256 landmark forward, batch=1 python loop (face_landmark.py:40-48 shape), torch-CPU f32 "
+                      "oracle as stand-in for onnxruntime-CPU, %d torch threads (best of %s on a 2-face probe; host has %d "
+                      "logical cores); %.1f s" % (n_faces, best_thr, cands, ncpu, dt_b1),
+            "landmark_b8_faces_per_s": round(nb8 * 8 / dt_b8, 2),
+            "pipeline_faces_per_s": round(n_pipe / dt_pipe, 2), "pipeline_ms_per_frame": round(dt_pipe * 1e3, 1),
+            "pipeline_sample": "1 frame %dx%d x %d faces: numpy letterbox + torch detector + numpy NMS/top-k + per-face numpy crop/"
+                               "resize + B=1 forward + back-projection" % (Wd, H, n_pipe),
+            "total_cpu_s": round(time.perf_counter() - t_all, 1),
+            "note": "baseline, not target: a large GPU/CPU ratio says nothing about kernel quality, the roofline fractions do"}
+
+
+def hbm_ops_table(prof, steps, frames_per_launch, faces_per_launch, frame_hw, faces_per_frame):
+    """Achieved HBM GB/s of the byte-shuffling pre/post kernels (SURVEY 8d algorithmic bytes per unit x units per
+    launch / HIP-event launch time), against the 8 TB/s HBM3E peak."""
+    H, W = frame_hw
+    s_crop = 280 * H // 1080        # synthetic boxes are 200 px wide at 1080p: crop side 2 * floor(0.7 w)
+    per = {
+        "letterbox": ("K1 cv2 resize+pad -> u8 384x640x3", frames_per_launch * (H * W * 3 + 384 * 640 * 3)),
+        "detect_decode": ("K3 in-graph Detect decode, f32 rows read + written", frames_per_launch * 2 * 15120 * 16 * 4),
+        "nms": ("K4 xywh2xyxy + NMS + scale_coords + top-k, f32 rows read once", frames_per_launch * (15120 * 16 * 4 + faces_per_frame * 64)),
+        "crop_resize": ("K5 crop + cv2.resize -> u8 256x256x3", faces_per_launch * (3 * s_crop * s_crop + 3 * 256 * 256)),
+        "hm_decode": ("K10/K11 arg-max partials + offsets at the arg-max + back-projection", faces_per_launch * 98 * (32 * 8 + 128 * 4 + 20)),
+    }
+    out = {}
+    for tag, (what, nbytes) in per.items():
+        if tag not in prof or prof[tag][1] == 0:
+            continue
+        ms, cnt = prof[tag]
+        launches_per_step = cnt / steps
+        avg_ms = ms / steps            # all launches of the tag in one step together move `nbytes`
+        gbps = nbytes / (avg_ms * 1e-3) / 1e9
+        out[tag] = {"what": what, "algorithmic_bytes_per_step": int(nbytes), "ms_per_step": round(avg_ms, 4),
+                    "launches_per_step": launches_per_step, "achieved_GBps": round(gbps, 1),
+                    "frac_of_hbm_peak": round(gbps / PEAK_HBM_GBPS, 4)}
+    return out
+
+
+def dense_kernel_table(prof, steps, faces_per_launch, dtype):
+    out = {}
+    for tag, flop in DENSE_FLOP_PER_FACE.items():
+        if tag not in prof or prof[tag][1] == 0:
+            continue
+        ms = prof[tag][0] / steps
+        tf = flop * faces_per_launch / (ms * 1e-3) / 1e12
+        out[tag] = {"ms_per_lane_step": round(ms, 4), "algorithmic_tflops": round(tf, 1),
+                    "frac_of_mfma_peak": round(tf / PEAK_TFLOPS[dtype], 4),
+                    "executed_mfma_frac": round(tf * MFMA_INSTR_PER_PRODUCT[dtype] / PEAK_TFLOPS[dtype], 4)}
+    return out
+
+
+def dry_run_cpu(args):
+    """Launch / rendezvous / broadcast / sharding plumbing on CPU (gloo); no engine, no compute, no measurement."""
+    import torch
+    import torch.distributed as dist
+    from peppa_pig_face_landmark_amd import bench_support as bs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    use_dist = world > 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    rng = np.random.default_rng(0)
+    blobs = {0: rng.integers(0, 256, 70001, dtype=np.uint8).tobytes(), 1: rng.integers(0, 256, 4099, dtype=np.uint8).tobytes()} if rank == 0 else None
+    if use_dist:
+        blobs, _ = bs.broadcast_blobs(blobs, torch.device("cpu"), rank)
+    mine = bs.shard_frames(args.frames * world, rank, world)
+    sums = torch.tensor([float(sum(blobs[0][:64]) + sum(blobs[1][:64])), float(len(mine))], dtype=torch.float64)
+    gathered = [torch.zeros_like(sums) for _ in range(world)]
+    if use_dist:
+        dist.all_gather(gathered, sums)
+    else:
+        gathered = [sums]
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        assert all(float(g[0]) == float(gathered[0][0]) for g in gathered), "ranks hold different blobs"
+        print(json.dumps({"metric": "dry run (plumbing only, no measurement)", "value": None, "unit": "faces/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": "weak",
+                          "frames_per_rank": [int(g[1]) for g in gathered], "max_over_ranks_check": float(t.item())}), flush=True)
 
 
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        # python bench.py --gpus N: become the launcher (one rank per GPU, torch.distributed.run, 127.0.0.1)
+        if not args.dry_run_cpu:
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) visible on this node (no CPU fallback, "
+                                 "no oversubscription)" % (args.gpus, have))
+        from peppa_pig_face_landmark_amd import bench_support as bs
+        sys.exit(bs.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args)
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: local rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    use_dist = world > 1
     dev = torch.device("cuda", local_rank)
+
+    class _StdoutToStderr:
+        """RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on stdout,
+        so stdout points at stderr while communicators come up (the banner, with its rank count, lands in stderr)."""
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1)
+            os.dup2(2, 1)
+        def __exit__(self, *exc):
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line on
-        # stdout, so stdout is pointed at stderr while the communicator comes up
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with _StdoutToStderr():
             dist.init_process_group("nccl", device_id=dev)
             dist.all_reduce(torch.zeros(1, device=dev))
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
 
     from peppa_pig_face_landmark_amd import build as pbuild
-    from peppa_pig_face_landmark_amd._native import Engine, PF_INPUT_U8_NHWC
+    from peppa_pig_face_landmark_amd._native import Engine, PF_NET_DETECTOR, PF_NET_LANDMARK
     from peppa_pig_face_landmark_amd import bench_support as bs
 
     if rank == 0:
@@ -128,12 +302,32 @@ def main():
     if workload == "auto":
         workload = "pipeline" if bs.pipeline_available() else "landmark"
 
-    # ---- weights: packed on rank 0, broadcast once over RCCL / xGMI -----------------------------
+    # ---- weights: packed on rank 0, broadcast once by the ENGINE over RCCL / xGMI (pf_broadcast_weights) -----------
     t0 = time.time()
     blobs = bs.build_programs(workload, args.dtype, args.model) if rank == 0 else None
-    bcast_ms = 0.0
-    if use_dist:
-        blobs, bcast_ms = bs.broadcast_blobs(blobs, dev, rank)
+    slots = [PF_NET_LANDMARK] + ([PF_NET_DETECTOR] if workload == "pipeline" else [])
+
+    def exchange_id(uid):
+        if not use_dist:
+            return uid
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            t.copy_(torch.frombuffer(bytearray(uid), dtype=torch.uint8))
+        dist.broadcast(t, 0)
+        return bytes(t.cpu().numpy().tobytes())
+
+    bcast = {"ms": 0.0, "bytes": 0, "via": "pf_broadcast_weights (ncclBroadcast on the engine's stream)", "rccl_version": None}
+    try:
+        with _StdoutToStderr():
+            blobs_out, bcast["ms"], bcast["bytes"] = bs.broadcast_programs_rccl(eng, blobs, slots, rank, world, exchange_id)
+            bcast["rccl_version"] = eng.rccl_version()
+        blobs = blobs_out
+        print("[bench] rank %d/%d: RCCL %s communicator of %d rank(s); %d weight bytes in %.3f ms" % (
+            rank, world, bcast["rccl_version"], world, bcast["bytes"], bcast["ms"]), file=sys.stderr, flush=True)
+    except Exception as e:   # noqa: BLE001
+        if use_dist:
+            raise                                  # N > 1 cannot run without the broadcast
+        bcast["via"] = "single GPU: local pf_load_program (RCCL self-test failed: %s)" % e
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
     lanes = args.lanes if workload == "pipeline" else 1
     if lanes == 1:
@@ -156,6 +350,7 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+        state.sync()
 
     for _ in range(args.warmup):
         state.step()
@@ -163,6 +358,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state.step()
+    state.sync()                      # the engines run on their own (non-blocking) streams
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -172,10 +368,25 @@ def main():
     barrier()
     state.check()
 
+    # ---- sustained loop (not the headline): long enough for an external GPU-busy sampler to see -------------------
+    sustained = None
+    if not args.no_probes and args.sustain_s > 0:
+        n_sus = 0
+        t1 = time.perf_counter()
+        while time.perf_counter() - t1 < args.sustain_s:
+            for _ in range(4):
+                state.step()
+            state.sync()
+            n_sus += 4
+        dt = time.perf_counter() - t1
+        sustained = {"seconds": round(dt, 2), "steps": n_sus, "faces_per_s_per_gpu": round(n_sus * faces_per_step / dt, 1)}
+
     # ---- per-kernel device time (HIP events on the engine's own stream), dominant kernel roofline ---
-    prof = state.profile(3)
+    PROF_STEPS = 3
+    prof = state.profile(PROF_STEPS)
     hero_ms, hero_n = prof.get(HERO_TAG, (0.0, 0))
     faces_per_launch = faces_per_step // lanes      # the profiled lane processes 1/lanes of the step
+    frames_per_launch = args.frames // lanes
     roofline = None
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
@@ -184,7 +395,7 @@ def main():
         # separate runs, gfx950 FETCH correction applied), scaled to this run's faces per launch
         with open(pmc_path) as f:
             pmc = json.load(f)
-        traffic = int(pmc["traffic_bytes_per_launch"] * (faces_per_step // (args.lanes if workload == "pipeline" else 1)) / pmc["faces_per_launch"])
+        traffic = int(pmc["traffic_bytes_per_launch"] * faces_per_launch / pmc["faces_per_launch"])
     if hero_n:
         avg_ms = hero_ms / hero_n
         achieved = HERO_FLOP_PER_FACE * faces_per_launch / (avg_ms * 1e-3) / 1e12
@@ -199,8 +410,8 @@ def main():
 
     if args.dump_profile and rank == 0:
         with open(args.dump_profile, "w") as f:
-            json.dump({"steps": 3, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
-                       "kernels": {k: {"ms_per_step": v[0] / 3, "launches_per_step": v[1] / 3}
+            json.dump({"steps": PROF_STEPS, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
+                       "kernels": {k: {"ms_per_step": v[0] / PROF_STEPS, "launches_per_step": v[1] / PROF_STEPS}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}, f, indent=1)
     latency = None
     if workload == "pipeline" and not args.no_probes:
@@ -216,11 +427,11 @@ def main():
         state.enable_host_frames()
         hs = max(2, min(args.steps, 8))
         state.step_host()
-        torch.cuda.synchronize()
+        state.sync()
         t1 = time.perf_counter()
         for _ in range(hs):
             state.step_host()
-        torch.cuda.synchronize()
+        state.sync()
         dt = time.perf_counter() - t1
         state.check()
         pcie = {"faces_per_s": round(faces_per_step * hs / dt, 1), "frames_per_s": round(args.frames * hs / dt, 1),
@@ -240,21 +451,28 @@ def main():
                        "configs[2]" if tuple(args.frame_hw) == (1080, 1920) else "configs[4]-shaped", args.frames, args.frame_hw[1], args.frame_hw[0], args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
                    "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
-                   "weights": "synthetic (reference .onnx blobs absent), RCCL broadcast of %.1f MB in %.2f ms%s" % (
-                       sum(len(b) for b in blobs.values()) / 1e6, bcast_ms,
-                       (" = %.1f GB/s" % (sum(len(b) for b in blobs.values()) / 1e9 / (bcast_ms * 1e-3))) if bcast_ms > 0 else "")},
+                   "unique_frames_per_gpu": getattr(state, "unique_frames", None),
+                   "results": "counts/boxes/landmarks/scores copied to page-locked host memory inside every step" if workload == "pipeline" else "device resident",
+                   "weights": "synthetic (reference .onnx blobs absent), %s: %.1f MB in %.3f ms%s" % (
+                       bcast["via"], bcast["bytes"] / 1e6, bcast["ms"],
+                       (" = %.1f GB/s vs 153 GB/s per xGMI link" % (bcast["bytes"] / 1e9 / (bcast["ms"] * 1e-3))) if bcast["ms"] > 0 else "")},
         "roofline": roofline,
         "cpu_baseline": None,
         "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
                   "algorithmic_tflops": round(value * GFLOP_PER_FACE[args.model] / 1e3, 2),
                   "frac_of_conv_roofline": round(value / world * GFLOP_PER_FACE[args.model] / 1e3 / PEAK_TFLOPS[args.dtype], 4),
+                  "hbm_ops": hbm_ops_table(prof, PROF_STEPS, frames_per_launch, faces_per_launch, tuple(args.frame_hw), args.faces_per_frame) if workload == "pipeline" else None,
+                  "dense_kernels": dense_kernel_table(prof, PROF_STEPS, faces_per_launch, args.dtype) if args.model == "student" else None,
+                  "sustained": sustained,
                   "latency": latency,
                   "pcie_inclusive": pcie,
+                  "weight_broadcast": bcast,
                   "setup_s": round(setup_s, 2),
-                  "kernel_ms_per_lane_step": {k: round(v[0] / 3, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]}},
+                  "kernel_ms_per_lane_step": {k: round(v[0] / PROF_STEPS, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
+                  "lane_step_ms_serial": round(sum(v[0] for v in prof.values()) / PROF_STEPS, 4)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(workload, args.cpu_faces)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_faces, tuple(args.frame_hw), args.faces_per_frame)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,7 +31,9 @@ extern "C" {
 
 typedef struct pf_handle pf_handle;
 
-enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1, PF_MEM_RESIDENT = 2 };  /* 2: the frame stored by pf_set_frame (bgr may be NULL) */
+enum { PF_MEM_HOST = 0, PF_MEM_DEVICE = 1, PF_MEM_RESIDENT = 2,     /* 2: the frame stored by pf_set_frame (bgr may be NULL) */
+       PF_MEM_HOST_PINNED = 3 };  /* out_mem of pf_run_frames* only: page-locked host result buffers (pf_host_alloc); the call
+                                   * returns after enqueueing the device->host copies, results are complete after pf_sync() */
 /* pf_run_frames_planted only: OR into `mem` when the frames are in host memory but the planted detector rows
  * (a test / benchmark instrument, 968 KB per frame) already live on the device */
 enum { PF_MEM_ROWS_DEVICE = 0x100 };
@@ -138,6 +140,26 @@ int pf_forget_frames(pf_handle* h);
  * from pageable memory the same call still works but the copy serialises.  Not tied to a handle. */
 int pf_host_alloc(size_t bytes, void** out);
 int pf_host_free(void* p);
+
+/* Multi-GPU: frames shard across ranks -- frame f is processed by rank f mod R, each rank owning one GPU
+ * and one handle -- and nothing on the data path crosses GPUs.  The one exchange is the start-up broadcast of the packed
+ * network programs from rank 0 over RCCL / xGMI (the reference has no inference-side parallelism at all,
+ * face_landmark.py:40-48; its only collectives are the DDP training all-reduces, net_work.py:30,131-137).
+ *  pf_comm_unique_id     rank 0: a fresh 128-byte RCCL unique id (ncclGetUniqueId); the caller hands it to the
+ *                        other ranks by whatever side channel launched them (env, file, torch.distributed store)
+ *  pf_broadcast_weights  collective over all `world` ranks: creates the communicator on first use
+ *                        (ncclCommInitRank on the handle's device), broadcasts rank 0's `blob` (*bytes long; other
+ *                        ranks pass a buffer of `capacity` bytes and get the size back in *bytes) HBM-to-HBM with
+ *                        ncclBroadcast on the handle's stream, then loads it into `slot` exactly like
+ *                        pf_load_program on every rank.  *bcast_ms = device time of the payload broadcast.
+ *                        world == 1 is valid (degenerates to pf_load_program through the same code path).
+ * librccl is bound at the first call (dlopen); a missing library fails that call, not the engine. */
+#define PF_COMM_ID_BYTES 128
+int pf_comm_unique_id(void* id_out, size_t id_bytes);
+int pf_rccl_version(int* version);
+int pf_broadcast_weights(pf_handle* h, const void* rccl_unique_id, int rank, int world, int slot,
+                         void* blob, size_t capacity, size_t* bytes, int max_batch, float* bcast_ms);
+int pf_comm_destroy(pf_handle* h);
 
 /* Engine options.  PF_OPT_HIP_GRAPH = 1: pf_run_frames* calls whose buffers all live on the device are captured
  * into a hipGraph per distinct (pointers, shapes, thresholds) and replayed (launch-latency bound small batches). */

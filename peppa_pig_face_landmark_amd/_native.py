@@ -11,11 +11,12 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-PF_MEM_HOST, PF_MEM_DEVICE, PF_MEM_RESIDENT = 0, 1, 2
+PF_MEM_HOST, PF_MEM_DEVICE, PF_MEM_RESIDENT, PF_MEM_HOST_PINNED = 0, 1, 2, 3
 PF_MEM_ROWS_DEVICE = 0x100
 PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 PF_OPT_HIP_GRAPH = 1
+PF_COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, "libpeppa_hip.so")
@@ -58,6 +59,12 @@ def _declare(lib):
     lib.pf_host_free.argtypes = [vp]
     lib.pf_host_alloc.restype = i
     lib.pf_host_free.restype = i
+    lib.pf_comm_unique_id.argtypes = [vp, sz]
+    lib.pf_rccl_version.argtypes = [ip]
+    lib.pf_broadcast_weights.argtypes = [vp, vp, i, i, i, vp, sz, C.POINTER(sz), i, fp]
+    lib.pf_comm_destroy.argtypes = [vp]
+    for name in ("pf_comm_unique_id", "pf_rccl_version", "pf_broadcast_weights", "pf_comm_destroy"):
+        getattr(lib, name).restype = i
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
                  "pf_read_tensor", "pf_detect", "pf_landmarks", "pf_run_frames", "pf_run_frames_planted",
                  "pf_profile_enable", "pf_profile_fetch", "pf_letterbox", "pf_nms_rows", "pf_crop_faces", "pf_set_frame", "pf_forget_frames", "pf_set_option"):
@@ -156,6 +163,44 @@ class Engine:
         self._check(self.lib.pf_load_program(self.h, slot, C.cast(buf, C.c_void_p), len(blob), int(max_batch)),
                     "pf_load_program")
         self._programs[slot] = max_batch
+
+    # ---- multi-GPU: one-time RCCL broadcast of the packed programs (include/peppa_hip.h) ----------------
+    @staticmethod
+    def comm_unique_id(library: Optional[str] = None) -> bytes:
+        """Rank 0: a fresh RCCL unique id (128 bytes) to hand to the other ranks out of band."""
+        lib = load_library(library)
+        buf = C.create_string_buffer(PF_COMM_ID_BYTES)
+        if lib.pf_comm_unique_id(C.cast(buf, C.c_void_p), PF_COMM_ID_BYTES) != 0:
+            msg = lib.pf_last_error(None)
+            raise PeppaHipError("pf_comm_unique_id failed: " + (msg.decode() if msg else "unknown"))
+        return buf.raw
+
+    def rccl_version(self) -> int:
+        v = C.c_int(0)
+        if self.lib.pf_rccl_version(C.byref(v)) != 0:
+            msg = self.lib.pf_last_error(None)
+            raise PeppaHipError("pf_rccl_version failed: " + (msg.decode() if msg else "unknown"))
+        return v.value
+
+    def broadcast_weights(self, unique_id: bytes, rank: int, world: int, slot: int, blob: Optional[bytes],
+                          max_batch: int, capacity: int = 64 << 20) -> Tuple[bytes, float]:
+        """Collective: rank 0 passes its packed program, the other ranks pass None; every rank ends up with the
+        program loaded into `slot`.  Returns (blob bytes, device milliseconds of the ncclBroadcast)."""
+        assert len(unique_id) == PF_COMM_ID_BYTES
+        if rank == 0:
+            assert blob is not None
+            capacity = len(blob)
+            buf = C.create_string_buffer(blob, len(blob))
+        else:
+            buf = C.create_string_buffer(capacity)
+        n = C.c_size_t(len(blob) if rank == 0 else 0)
+        ms = C.c_float(0.0)
+        idb = C.create_string_buffer(unique_id, PF_COMM_ID_BYTES)
+        self._check(self.lib.pf_broadcast_weights(self.h, C.cast(idb, C.c_void_p), int(rank), int(world), int(slot),
+                                                  C.cast(buf, C.c_void_p), capacity, C.byref(n), int(max_batch), C.byref(ms)),
+                    "pf_broadcast_weights")
+        self._programs[slot] = max_batch
+        return buf.raw[:n.value], float(ms.value)
 
     # ---- network seams ------------------------------------------------------------------------
     def landmark_forward(self, x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -280,12 +325,14 @@ class Engine:
 
     def run_frames_device(self, d_frames: int, F: int, H: int, W: int, score_thres: float, iou_thres: float,
                           min_face: float, top_k: int, d_planted: int = 0, rows: int = 0, d_counts: int = 0,
-                          d_boxes: int = 0, d_kps: int = 0, d_scores: int = 0):
+                          d_boxes: int = 0, d_kps: int = 0, d_scores: int = 0, out_mem: int = PF_MEM_DEVICE):
+        """Device-resident frames; results to device buffers, or (out_mem = PF_MEM_HOST_PINNED) to page-locked host
+        buffers from pinned_empty() -- asynchronous either way, complete after sync()."""
         rc = self.lib.pf_run_frames_planted(self.h, _ptr(d_frames), PF_MEM_DEVICE, F, H, W,
                                             _ptr(d_planted) if d_planted else None, rows, score_thres, iou_thres,
                                             min_face, top_k, _ptr(d_counts) if d_counts else None,
                                             _ptr(d_boxes) if d_boxes else None, _ptr(d_kps) if d_kps else None,
-                                            _ptr(d_scores) if d_scores else None, PF_MEM_DEVICE)
+                                            _ptr(d_scores) if d_scores else None, out_mem)
         self._check(rc, "pf_run_frames_planted")
 
     # ---- stage-level seams -----------------------------------------------------------------------

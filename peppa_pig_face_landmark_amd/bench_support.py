@@ -71,6 +71,48 @@ def broadcast_blobs(blobs: Optional[Dict[int, bytes]], dev, rank: int) -> Tuple[
     return out, ms
 
 
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(script: str, argv, n: int, extra_env=None) -> int:
+    """`python script --gpus N ...` without a launcher: re-exec the same command line under
+    torch.distributed.run with one rank per GPU on this node (the form the driver uses for N > 1) and pass
+    its exit code through.  Rank 0's single JSON line reaches stdout unchanged."""
+    import os
+    import subprocess
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if extra_env:
+        env.update(extra_env)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def broadcast_programs_rccl(eng: "_native.Engine", blobs: Optional[Dict[int, bytes]], slots, rank: int, world: int,
+                            exchange_id) -> Tuple[Dict[int, bytes], float, int]:
+    """One-time weight distribution through the engine's own C ABI (pf_broadcast_weights -> ncclBroadcast on the
+    engine's stream, HBM to HBM over xGMI).  `exchange_id(id_or_None) -> id` moves rank 0's 128-byte RCCL unique
+    id to every rank out of band.  Returns (blobs, total device ms of the payload broadcasts, total bytes)."""
+    uid = exchange_id(_native.Engine.comm_unique_id() if rank == 0 else None)
+    out: Dict[int, bytes] = {}
+    ms_total, nbytes = 0.0, 0
+    for slot in slots:
+        blob, ms = eng.broadcast_weights(uid, rank, world, slot, blobs[slot] if rank == 0 else None, max_batch=1)
+        out[slot] = blob
+        ms_total += ms
+        nbytes += len(blob)
+    return out, ms_total, nbytes
+
+
 def shard_frames(n_frames: int, rank: int, world: int):
     """Frame f is processed by rank f mod world: independent units, no data-path collective."""
     return list(range(rank, n_frames, world))
@@ -114,6 +156,9 @@ class LandmarkWorkload:
     def step(self):
         self.eng.landmark_forward_device(self.crops.data_ptr(), _native.PF_INPUT_U8_NHWC, self.batch,
                                          self.loc.data_ptr(), self.score.data_ptr())
+
+    def sync(self):
+        self.eng.sync()
 
     def check(self):
         import torch
@@ -159,19 +204,35 @@ class PipelineWorkload:
             base_rows.append(plant_rows(boxes, (self.H, self.W), self.ROWS, (384, 640), 24, seed=seed + i))
         reps = (frames + len(base_frames) - 1) // len(base_frames)
         self.frames = torch.from_numpy(np.stack((base_frames * reps)[:frames])).to(dev)
+        # every frame slot gets its own pixels (+-3 of per-frame noise on top of the two base scenes), so the step
+        # reads F distinct frames from HBM instead of two cache-resident ones (96 x 6.2 MB = 597 MB > the 256 MB L3)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + seed)
+        for i in range(frames):
+            nz = torch.randint(-3, 4, self.frames[i].shape, dtype=torch.int16, device=dev, generator=gen)
+            self.frames[i] = (self.frames[i].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
+        self.unique_frames = frames
         self.rows = torch.from_numpy(np.stack((base_rows * reps)[:frames])).to(dev)
         n = frames * faces_per_frame
         self.counts = torch.zeros((frames,), dtype=torch.int32, device=dev)
         self.boxes = torch.zeros((n, 4), dtype=torch.float32, device=dev)
         self.kps = torch.zeros((n, 98, 2), dtype=torch.float32, device=dev)
         self.scores = torch.zeros((n, 98), dtype=torch.float32, device=dev)
+        # results leave the device inside the step, like FaceAna.run() returning numpy (facer.py:84-96): page-locked
+        # host buffers, device->host copies enqueued on the engine's stream (part of the captured graph)
+        self.h_counts = eng.pinned_empty((frames,), np.int32)
+        self.h_boxes = eng.pinned_empty((n, 4), np.float32)
+        self.h_kps = eng.pinned_empty((n, 98, 2), np.float32)
+        self.h_scores = eng.pinned_empty((n, 98), np.float32)
+        for a in (self.h_counts, self.h_boxes, self.h_kps, self.h_scores):
+            a[...] = 0
         torch.cuda.synchronize()
 
     def step(self):
         self.eng.run_frames_device(self.frames.data_ptr(), self.F, self.H, self.W, 0.5, 0.3, 1600.0, self.K,
-                                   d_planted=self.rows.data_ptr(), rows=self.ROWS, d_counts=self.counts.data_ptr(),
-                                   d_boxes=self.boxes.data_ptr(), d_kps=self.kps.data_ptr(),
-                                   d_scores=self.scores.data_ptr())
+                                   d_planted=self.rows.data_ptr(), rows=self.ROWS, d_counts=self.h_counts.ctypes.data,
+                                   d_boxes=self.h_boxes.ctypes.data, d_kps=self.h_kps.ctypes.data,
+                                   d_scores=self.h_scores.ctypes.data, out_mem=_native.PF_MEM_HOST_PINNED)
 
     def enable_host_frames(self):
         """Frame ingest seam (next-row N2): the same frames in page-locked HOST memory (pf_host_alloc)."""
@@ -201,12 +262,14 @@ class PipelineWorkload:
         return ts[len(ts) // 2], ts[min(len(ts) - 1, int(len(ts) * 0.99))]
 
     def check(self):
-        import torch
+        """The timed steps deliver to the page-locked host buffers (the latency / PCIe probes to the device ones)."""
         self.eng.sync()
-        assert bool((self.counts == self.K).all()), "NMS did not return the planted faces: %s" % self.counts.tolist()
-        assert bool(torch.isfinite(self.kps).all()), "non-finite landmarks"
+        assert bool((self.h_counts == self.K).all()), "NMS did not return the planted faces: %s" % self.h_counts.tolist()
+        assert bool(np.isfinite(self.h_kps).all()) and bool(np.isfinite(self.h_scores).all()), "non-finite landmarks"
+        assert float(np.abs(self.h_kps).max()) > 0.0, "results never reached the host buffers"
 
     profile = LandmarkWorkload.profile
+    sync = LandmarkWorkload.sync
 
 
 class MultiLanePipeline:
@@ -228,6 +291,14 @@ class MultiLanePipeline:
     def step(self):
         for wl in self.lanes:
             wl.step()
+
+    def sync(self):
+        for wl in self.lanes:
+            wl.eng.sync()
+
+    @property
+    def unique_frames(self):
+        return sum(wl.unique_frames for wl in self.lanes)
 
     def check(self):
         for wl in self.lanes:

@@ -46,7 +46,7 @@ struct Program {
 
 struct ProfEntry { double ms = 0; int count = 0; };
 
-struct GraphKey { const void* p[6]; int i[5]; float f[3]; };
+struct GraphKey { const void* p[6]; int i[5]; float f[3]; unsigned long long epoch; };
 struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
 
 }  // namespace
@@ -64,6 +64,13 @@ struct pf_handle {
     // hipGraph replay of pf_run_frames* (PF_OPT_HIP_GRAPH)
     bool use_graphs = false, capturing = false;
     std::vector<GraphEntry> graphs;
+    // bumped whenever a device allocation a captured graph may reference is (re)made -- scratch growth, program
+    // (re)load -- so that stale graphs are destroyed instead of replayed over freed memory
+    unsigned long long alloc_epoch = 0;
+    // RCCL communicator for pf_broadcast_weights (comm.inl); created lazily, one per handle
+    void* comm = nullptr;
+    unsigned char comm_id[128] = {0};
+    int comm_rank = -1, comm_world = 0;
     // profiling
     bool profiling = false;
     std::map<std::string, ProfEntry> prof;
@@ -73,12 +80,24 @@ struct pf_handle {
 
 static std::string g_create_error;
 
+namespace { void comm_release(pf_handle* h); }   // comm.inl
+
 #define PF_FAIL(h, ...)                                   \
     do {                                                  \
         char _b[512];                                     \
         snprintf(_b, sizeof(_b), __VA_ARGS__);            \
         (h)->err = _b;                                    \
         return 1;                                         \
+    } while (0)
+
+// every kernel launch is checked where it is made: a bad launch configuration (too much LDS, too many
+// registers for the block size) must not surface one call later.  `h` is in scope at every launch site.
+#undef PF_LAUNCH
+#define PF_LAUNCH(kernel, grid, block, stream, ...)                                                          \
+    do {                                                                                                     \
+        hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                                     \
+        const hipError_t _le = hipGetLastError();                                                            \
+        if (_le != hipSuccess) PF_FAIL(h, "launch of %s failed: %s (%s:%d)", #kernel, hipGetErrorString(_le), __FILE__, __LINE__); \
     } while (0)
 
 #define PF_HIP(h, call)                                                                        \
@@ -597,6 +616,7 @@ void pf_destroy(pf_handle* h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    comm_release(h);
     for (auto& p : h->prog) {
         if (p.d_const) (void)hipFree(p.d_const);
         if (p.d_arena) (void)hipFree(p.d_arena);
@@ -636,6 +656,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipStreamSynchronize(h->stream));
     if (p.d_const) { (void)hipFree(p.d_const); p.d_const = nullptr; }
     if (p.d_arena) { (void)hipFree(p.d_arena); p.d_arena = nullptr; }
+    h->alloc_epoch++;            // graphs captured over the old arena / constants must not be replayed
     p.loaded = false;
     p.hdr = hd;
     p.esize = hd.dtype == PF_DTYPE_F16 ? 2 : 4;
@@ -766,3 +787,4 @@ int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int
 }  // extern "C"
 
 #include "pipeline.inl"
+#include "comm.inl"

@@ -382,6 +382,11 @@ __global__ __launch_bounds__(256) void hm_decode_kernel(HmDecodeArgs a) {
         const int oi = pf_shfl_xor_i32(bi, mask);
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
+    // A heat-map with no finite maximum (all NaN, or everything below the -3e38 sentinel: f16 overflow, bad weights)
+    // never wins a comparison and leaves the sentinel index: report NaN like torch.max (model.py:522) instead of
+    // reading the feature row of pixel 0x7fffffff.
+    const bool no_max = (unsigned)bi >= (unsigned)(a.H * a.W);
+    if (no_max) { bi = 0; bv = __builtin_nanf(""); }
     const T* f = static_cast<const T*>(a.feat) + ((size_t)b * a.H * a.W + bi) * a.featLd;
     float sx = 0.f, sy = 0.f;
     for (int k = lane; k < a.C; k += 64) {
@@ -395,8 +400,8 @@ __global__ __launch_bounds__(256) void hm_decode_kernel(HmDecodeArgs a) {
     }
     if (ok && lane == 0) {
         const float ox = sx + a.off_bias[p], oy = sy + a.off_bias[a.P + p];
-        const float lx = ((float)(bi % a.W) + ox) / (float)a.W;
-        const float ly = ((float)(bi / a.W) + oy) / (float)a.H;
+        const float lx = no_max ? bv : ((float)(bi % a.W) + ox) / (float)a.W;
+        const float ly = no_max ? bv : ((float)(bi / a.W) + oy) / (float)a.H;
         a.loc[(size_t)b * 2 * a.P + 2 * p] = lx;
         a.loc[(size_t)b * 2 * a.P + 2 * p + 1] = ly;
         a.score[(size_t)b * a.P + p] = bv;

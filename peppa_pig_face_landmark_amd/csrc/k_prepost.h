@@ -31,8 +31,6 @@ struct PipelineScratch {
     bool have_cur = false, have_prev = false;
     unsigned char* d_crops = nullptr; size_t crops_bytes = 0;
     float* d_rows_planted = nullptr; size_t rows_planted_bytes = 0;
-    float* d_lbinfo = nullptr;       // [4] scale,left,top,pad
-    float h_lbinfo[4] = {0.f, 0.f, 0.f, 0.f};  // host copy kept alive for the async upload
     float* d_keep_rows = nullptr;    // [F][max_keep][16]
     int* d_keep_count = nullptr;     // [F]
     float* d_sel_boxes = nullptr;    // [F][top_k][4]
@@ -44,7 +42,7 @@ struct PipelineScratch {
     unsigned char* d_nms_flags = nullptr;      // [F][cap]
     int cap_frames = 0, cap_faces = 0, cap_keep = 0, cap_topk = 0, cap_rows = 0;
     void release() {
-        void* ptrs[] = {d_cur, d_prev, d_diff_sum, d_frames, d_letterbox, d_crops, d_rows_planted, d_lbinfo, d_keep_rows, d_keep_count,
+        void* ptrs[] = {d_cur, d_prev, d_diff_sum, d_frames, d_letterbox, d_crops, d_rows_planted, d_keep_rows, d_keep_count,
                         d_sel_boxes, d_sel_count, d_crop_params, d_cropf, d_kps, d_nms_keys, d_nms_flags};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = PipelineScratch();
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LetterboxArgs a) {
 // --------------------------------------------------------------------------------------------
 struct NmsArgs {
     const float* rows;     // [F][R][16] decoded detector rows (cx,cy,w,h,score,...) letterboxed pixels
-    const float* lbinfo;   // [4] = scale, left, top, unused (same geometry for every frame)
+    float lb_scale, lb_left, lb_top;   // letterbox geometry (same for every frame of the call), face_detector.py:71
     float* keep_rows;      // [F][max_keep][16]  kept rows, xyxy un-letterboxed in cols 0:4
     int* keep_count;       // [F]
     float* sel_boxes;      // [F][top_k][4]  after sort_and_filter (may be nullptr)
@@ -229,7 +227,7 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
     __syncthreads();
     // 4. emit kept rows with scale_coords applied (face_detector.py:37,82-93)
     const int nk = s_nkeep < a.max_keep ? (s_nkeep < 1024 ? s_nkeep : 1024) : a.max_keep;
-    const float scale = a.lbinfo[0], left = a.lbinfo[1], top = a.lbinfo[2];
+    const float scale = a.lb_scale, left = a.lb_left, top = a.lb_top;
     float* out = a.keep_rows + (size_t)f * a.max_keep * 16;
     for (int k = tid; k < nk; k += 1024) {
         const float* b = rows + (size_t)s_keep[k] * 16;

@@ -13,9 +13,11 @@ const int kNumPoints = 98;
 template <typename T>
 int ensure_dev(pf_handle* h, T*& ptr, size_t& have_bytes, size_t need_bytes) {
     if (need_bytes <= have_bytes && ptr) return 0;
-    if (ptr) (void)hipFree(ptr);
+    if (h->capturing) PF_FAIL(h, "internal: device scratch would be reallocated inside a graph capture");
+    if (ptr) { (void)hipStreamSynchronize(h->stream); (void)hipFree(ptr); }
     ptr = nullptr;
     have_bytes = 0;
+    h->alloc_epoch++;            // captured graphs may hold the old pointer
     PF_HIP(h, hipMalloc((void**)&ptr, need_bytes));
     have_bytes = need_bytes;
     return 0;
@@ -23,8 +25,10 @@ int ensure_dev(pf_handle* h, T*& ptr, size_t& have_bytes, size_t need_bytes) {
 
 template <typename T>
 int realloc_dev(pf_handle* h, T*& ptr, size_t bytes) {
-    if (ptr) (void)hipFree(ptr);
+    if (h->capturing) PF_FAIL(h, "internal: device scratch would be reallocated inside a graph capture");
+    if (ptr) { (void)hipStreamSynchronize(h->stream); (void)hipFree(ptr); }
     ptr = nullptr;
+    h->alloc_epoch++;
     PF_HIP(h, hipMalloc((void**)&ptr, bytes));
     return 0;
 }
@@ -36,7 +40,6 @@ int ensure_pipeline(pf_handle* h, int frames, int faces, int top_k, int rows) {
     if (frames > s.cap_frames || top_k > s.cap_topk || rows > s.cap_rows) {
         const int F = std::max(frames, s.cap_frames), K = std::max(top_k, s.cap_topk), R = std::max(rows, s.cap_rows);
         const int cap = next_pow2(std::max(R, 2));
-        if (realloc_dev(h, s.d_lbinfo, 4 * sizeof(float))) return 1;
         if (realloc_dev(h, s.d_keep_rows, (size_t)F * kMaxKeep * 16 * sizeof(float))) return 1;
         if (realloc_dev(h, s.d_keep_count, (size_t)F * sizeof(int))) return 1;
         if (realloc_dev(h, s.d_sel_boxes, (size_t)F * K * 4 * sizeof(float))) return 1;
@@ -109,11 +112,10 @@ int run_detector_stage(pf_handle* h, const unsigned char* d_frames, int F, int H
 int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const LetterboxGeom& g,
                   float score_thres, float iou_thres, float min_face, int top_k, bool select) {
     PipelineScratch& s = h->pipe;
-    s.h_lbinfo[0] = (float)g.scale; s.h_lbinfo[1] = (float)g.left; s.h_lbinfo[2] = (float)g.top; s.h_lbinfo[3] = 0.f;
-    if (!h->capturing)   // same constants were uploaded by the eager run that precedes every capture
-        PF_HIP(h, hipMemcpyAsync(s.d_lbinfo, s.h_lbinfo, sizeof(s.h_lbinfo), hipMemcpyHostToDevice, h->stream));
     NmsArgs na{};
-    na.rows = d_rows; na.lbinfo = s.d_lbinfo; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
+    // letterbox geometry travels by value in the kernel arguments, so a captured graph carries its own copy
+    na.lb_scale = (float)g.scale; na.lb_left = (float)g.left; na.lb_top = (float)g.top;
+    na.rows = d_rows; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
     na.sel_boxes = select ? s.d_sel_boxes : nullptr; na.sel_count = s.d_sel_count;
     na.keys = s.d_nms_keys; na.flags = s.d_nms_flags;
     na.R = rows; na.cap = next_pow2(std::max(s.cap_rows, 2)); na.max_keep = kMaxKeep; na.top_k = top_k;
@@ -256,7 +258,7 @@ static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int 
     }
     if (run_nms_stage(h, d_rows, det_nrows, F, g, score_thres, iou_thres, min_face, top_k, true)) return 1;
     if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, h->pipe.d_sel_count, faces, top_k)) return 1;
-    const hipMemcpyKind kind = out_mem == PF_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kind = out_mem == PF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (counts) PF_HIP(h, hipMemcpyAsync(counts, h->pipe.d_sel_count, (size_t)F * sizeof(int), kind, h->stream));
     if (boxes) PF_HIP(h, hipMemcpyAsync(boxes, h->pipe.d_sel_boxes, (size_t)faces * 4 * sizeof(float), kind, h->stream));
     if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
@@ -272,7 +274,9 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
                           float min_face, int top_k,
                           int* counts, float* boxes, float* kps, float* scores, int out_mem) {
     if (!h) return 1;
-    const bool graphable = h->use_graphs && !h->profiling && mem == PF_MEM_DEVICE && out_mem == PF_MEM_DEVICE;
+    if (out_mem != PF_MEM_HOST && out_mem != PF_MEM_DEVICE && out_mem != PF_MEM_HOST_PINNED) PF_FAIL(h, "pf_run_frames: bad out_mem %d", out_mem);
+    // results into page-locked host memory are plain asynchronous copies on the stream: they capture into the graph too
+    const bool graphable = h->use_graphs && !h->profiling && mem == PF_MEM_DEVICE && (out_mem == PF_MEM_DEVICE || out_mem == PF_MEM_HOST_PINNED);
     if (!graphable) {
         if (enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
                                top_k, counts, boxes, kps, scores, out_mem)) return 1;
@@ -283,6 +287,13 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     key.p[0] = frames; key.p[1] = det_rows; key.p[2] = counts; key.p[3] = boxes; key.p[4] = kps; key.p[5] = scores;
     key.i[0] = n_frames; key.i[1] = height; key.i[2] = width; key.i[3] = rows; key.i[4] = top_k;
     key.f[0] = score_thres; key.f[1] = iou_thres; key.f[2] = min_face;
+    key.epoch = h->alloc_epoch;
+    // any (re)allocation since a graph was captured -- scratch growth for a larger call, a program reload -- may have
+    // freed memory the graph's kernel arguments point at: drop every graph captured under an older epoch
+    if (!h->graphs.empty() && h->graphs.front().key.epoch != h->alloc_epoch) {
+        for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
     GraphEntry* e = nullptr;
     for (auto& g : h->graphs)
         if (memcmp(&g.key, &key, sizeof(key)) == 0) { e = &g; break; }
@@ -294,8 +305,17 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
         GraphEntry ne{};
         ne.key = key;
         h->graphs.push_back(ne);
-        return enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
-                                  top_k, counts, boxes, kps, scores, out_mem);
+        const int rc = enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
+                                          top_k, counts, boxes, kps, scores, out_mem);
+        if (h->alloc_epoch != key.epoch) {   // this eager run (re)allocated scratch: older graphs are stale, this entry is not
+            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+            ne.key.epoch = h->alloc_epoch;
+            if (!rc) h->graphs.push_back(ne);
+        } else if (rc) {
+            h->graphs.pop_back();
+        }
+        return rc;
     }
     if (!e->exec) {
         PF_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));

@@ -54,3 +54,42 @@ def test_broadcast_and_sharding_world2():
     shards = res[0][2]
     assert sorted(shards[0] + shards[1]) == list(range(13)) and not set(shards[0]) & set(shards[1])
     assert res[0][3] == res[1][3] == 2.0
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env,
+                       timeout=timeout, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None), lines
+
+
+def test_bench_self_spawns_n_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher must itself start 2 ranks (torch.distributed.run) and report
+    n_gpus = 2 on ONE stdout JSON line; the CPU tier drives exactly that launch path with --dry-run-cpu (gloo)."""
+    r, out, lines = _run_bench(["--gpus", "2", "--dry-run-cpu", "--frames", "7", "--steps", "2", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    assert out["n_gpus"] == 2 and out["dry_run"] is True and out["value"] is None
+    assert out["frames_per_rank"] == [7, 7] and out["max_over_ranks_check"] == 2.0
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """--gpus N on a node with fewer GPUs fails loudly (non-zero exit, no JSON line) instead of printing a 1-GPU line."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("2+ GPUs visible")
+    r, out, lines = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and not lines
+    assert "--gpus 2" in (r.stderr + r.stdout)
+
+
+def test_bench_refuses_world_size_mismatch():
+    r, out, lines = _run_bench(["--gpus", "2", "--dry-run-cpu"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
+    assert r.returncode != 0 and not lines

@@ -47,7 +47,12 @@ def test_student_f32_matches_oracle(gpu_engine, student_weights, size, batch, dt
     assert np.abs(score - oscore)[safe].max() < 5e-3
     # unsafe (near-tie) landmarks may pick the other of two equal-height cells; report, don't hide
     flips = int((d[~safe] > LANDMARK_TOL).sum())
-    print(f"near-tie landmarks: {int((~safe).sum())}, of which flipped: {flips}")
+    n_unsafe = int((~safe).sum())
+    print(f"near-tie landmarks: {n_unsafe}, of which flipped: {flips}")
+    # bounded flip rate: even among the near-ties (oracle top-1/top-2 margin <= 2e-3) a flip needs the
+    # engine's heat-map error to exceed half the margin, so at most a small share may move
+    assert flips <= max(1, n_unsafe // 4), (flips, n_unsafe)
+    assert flips <= 0.005 * safe.size + 1, (flips, safe.size)
 
 
 def test_student_f32_production_program_equals_debug_program(gpu_engine, student_weights):

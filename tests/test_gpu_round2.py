@@ -1,0 +1,135 @@
+"""Round-2 GPU checks: the RCCL weight broadcast behind the C ABI, the hipGraph cache across reallocations, the NaN-safe
+heat-map decode, and pf_detect on the detector's OWN rows against the numpy restatement of py_nms."""
+import numpy as np
+import pytest
+
+from oracle import prepost as pp
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd import _native
+from peppa_pig_face_landmark_amd.graph.detector import build_detector_program
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def test_broadcast_weights_world1_equals_load_program(gpu_engine, student_weights):
+    """pf_broadcast_weights with a 1-rank communicator goes through ncclCommInitRank + ncclBroadcast on the engine's
+    stream and must leave exactly the program pf_load_program would have loaded."""
+    blob, _ = build_student_program(student_weights, 128, "f32s")
+    crops = sw.smooth_blob_images(2, 128, seed=5)
+    gpu_engine.load_program(0, blob, 2)
+    ref = gpu_engine.landmark_forward(crops)
+    uid = _native.Engine.comm_unique_id(gpu_engine.lib._name)
+    assert len(uid) == 128 and any(uid)
+    got_blob, ms = gpu_engine.broadcast_weights(uid, 0, 1, 0, blob, max_batch=2)
+    assert got_blob == blob and ms >= 0.0
+    out = gpu_engine.landmark_forward(crops)
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[1], ref[1])
+    assert gpu_engine.rccl_version() > 20000
+    with pytest.raises(_native.PeppaHipError):
+        gpu_engine.broadcast_weights(uid, 1, 1, 0, blob, max_batch=2)      # rank outside the world
+
+
+def _device_run(eng, torch, frames_np, rows_np, K, graph):
+    eng.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)
+    dev = torch.device("cuda", 0)
+    F, H, W, _ = frames_np.shape
+    fr = torch.from_numpy(frames_np).to(dev)
+    rw = torch.from_numpy(rows_np).to(dev)
+    counts = torch.zeros((F,), dtype=torch.int32, device=dev)
+    boxes = torch.zeros((F * K, 4), dtype=torch.float32, device=dev)
+    kps = torch.zeros((F * K, 98, 2), dtype=torch.float32, device=dev)
+    scores = torch.zeros((F * K, 98), dtype=torch.float32, device=dev)
+    outs = []
+    for _ in range(3):          # 1st eager, 2nd capture + replay, 3rd replay
+        kps.zero_()
+        eng.run_frames_device(fr.data_ptr(), F, H, W, 0.5, 0.3, 1600.0, K, d_planted=rw.data_ptr(), rows=15120,
+                              d_counts=counts.data_ptr(), d_boxes=boxes.data_ptr(), d_kps=kps.data_ptr(), d_scores=scores.data_ptr())
+        eng.sync()
+        outs.append((counts.cpu().numpy().copy(), boxes.cpu().numpy().copy(), kps.cpu().numpy().copy()))
+    return outs, (fr, rw, counts, boxes, kps, scores)
+
+
+def test_graph_cache_survives_growth_and_frame_size_changes(gpu_engine, student_weights):
+    """a captured graph must never be replayed over scratch that was reallocated for a larger call, and two
+    frame sizes alternating on one handle must each get their own letterbox geometry."""
+    import torch
+    K = 2
+    blob, _ = build_student_program(student_weights, 128, "f32s")
+    gpu_engine.load_program(0, blob, 8 * K)
+    small, sb = make_frame(540, 960, K, seed=3)
+    big, bb = make_frame(720, 1280, K, seed=4)
+    rs = plant_rows(sb, (540, 960), 15120, (384, 640), 8, seed=3)
+    rb = plant_rows(bb, (720, 1280), 15120, (384, 640), 8, seed=4)
+    keep = []
+
+    def run(frames, rows, graph):
+        outs, bufs = _device_run(gpu_engine, torch, frames, rows, K, graph)
+        keep.append(bufs)                      # keep device buffers alive: their pointers are graph keys
+        for o in outs[1:]:
+            assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+        return outs[0]
+
+    ref_small = run(small[None], rs[None], False)
+    ref_big = run(big[None], rb[None], False)
+    ref_small4 = run(np.stack([small] * 4), np.stack([rs] * 4), False)
+    assert ref_small[0].tolist() == [K] and ref_big[0].tolist() == [K]
+    # graphs on: small (captured) -> big (different geometry) -> small x4 (scratch grows: reallocation) -> small again
+    for frames, rows, ref in ((small[None], rs[None], ref_small), (big[None], rb[None], ref_big),
+                              (np.stack([small] * 4), np.stack([rs] * 4), ref_small4),
+                              (small[None], rs[None], ref_small), (big[None], rb[None], ref_big)):
+        got = run(frames, rows, True)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
+        assert np.array_equal(got[2], ref[2])
+    # reloading a program frees the arena the graphs point at: replay must re-capture, not fault
+    gpu_engine.load_program(0, blob, 8 * K)
+    got = run(small[None], rs[None], True)
+    assert np.array_equal(got[2], ref_small[2])
+    gpu_engine.set_option(_native.PF_OPT_HIP_GRAPH, 0)
+
+
+def test_nan_heatmap_reports_nan_instead_of_faulting(gpu_engine, student_weights):
+    """an all-NaN score map leaves the arg-max sentinel; hm_decode must answer NaN like torch.max
+    (model.py:520-522) instead of reading pixel 0x7fffffff."""
+    w = dict(student_weights)
+    key = [k for k in w if k.endswith("hm.bias")]
+    assert len(key) == 1, key
+    b = np.array(w[key[0]], np.float32).copy()
+    b[7] = np.nan
+    w[key[0]] = b
+    blob, _ = build_student_program(w, 128, "f32s")
+    gpu_engine.load_program(0, blob, 2)
+    loc, score = gpu_engine.landmark_forward(sw.smooth_blob_images(2, 128, seed=9))
+    assert np.isnan(score[:, 7]).all() and np.isnan(loc[:, 14:16]).all()
+    ok = np.ones(98, bool)
+    ok[7] = False
+    assert np.isfinite(score[:, ok]).all() and np.isfinite(loc.reshape(2, 98, 2)[:, ok]).all()
+
+
+def test_detect_on_the_detectors_own_rows_matches_py_nms(gpu_engine, detector_weights):
+    """pf_detect end to end (letterbox -> net -> decode -> xywh2xyxy -> NMS -> scale_coords) against the numpy
+    restatement of face_detector.py:31-37,95-136 applied to the SAME decoded rows.  Random-init weights saturate the
+    objectness to exactly 1.0f (ties, whose order np.argsort leaves unspecified), so the objectness rows of the Detect
+    head are scaled down until every candidate score is distinct."""
+    w = {k: np.array(v).copy() for k, v in detector_weights.items()}
+    for i in range(3):
+        for a in range(3):
+            w[f"model.21.m.{i}.weight"][a * 16 + 4] *= 0.02
+            w[f"model.21.m.{i}.bias"][a * 16 + 4] = w[f"model.21.m.{i}.bias"][a * 16 + 4] * 0.02 - 0.05
+    frame, _ = make_frame(1080, 1920, 8, seed=7)
+    blob, _ = build_detector_program(w, (384, 640), "f32")
+    gpu_engine.load_program(1, blob, 1)
+    got = gpu_engine.detect(frame, 0.5, 0.3, max_n=1024)
+    lb, info = gpu_engine.letterbox(frame, (384, 640))
+    rows = gpu_engine.detector_forward(lb[None], 15120)[0]
+    cand = rows[rows[:, 4] > 0.5, 4]
+    assert cand.size > 50, cand.size
+    if np.unique(cand).size != cand.size:
+        pytest.skip("candidate scores still tie (%d of %d distinct)" % (np.unique(cand).size, cand.size))
+    ref = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+    n = min(ref.shape[0], 1024)
+    assert got.shape[0] == n and n > 0
+    assert np.array_equal(got[:n], ref[:n])
+    print("pf_detect vs py_nms on the detector's own rows: %d candidates -> %d kept, bit-identical" % (cand.size, n))
