@@ -40,5 +40,16 @@ __device__ __forceinline__ void pf_glds16(const void* gsrc, void* lds_lane_ptr) 
                                      (__attribute__((address_space(3))) void*)lds_lane_ptr, 16, 0, 0);
 }
 
+// Workgroup barrier that leaves the wave's N youngest VMEM operations (LDS-DMA requests, global loads) in flight:
+// "s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier".  __syncthreads() drains vmcnt to 0, which ends every software-pipeline
+// stage with a full global-memory latency; LDS-DMA stays in flight across s_barrier (MI355X_MICROARCH.md).
+template <int N> __device__ __forceinline__ void pf_wait_vm_barrier() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    // no fence builtins here: a workgroup-scope release fence is lowered to s_waitcnt vmcnt(0) whenever LDS-DMA is
+    // pending, which is exactly the drain this barrier exists to avoid; the memory clobber keeps the compiler from moving
+    // LDS / global accesses across it, lgkmcnt(0) retires this wave's own LDS writes before the rendezvous
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
+}
+
 #define PF_BUILD_TAG "gfx950"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

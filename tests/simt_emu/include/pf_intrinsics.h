@@ -69,5 +69,7 @@ inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
 inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
 
+template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous
+
 #define PF_BUILD_TAG "simt-emu"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -81,3 +81,27 @@ def test_student_f16_tracks_oracle(emu_engine, student_weights):
     if safe.any():
         idx_ok = np.abs(loc - oloc).reshape(B, 98, 2).max(2)[safe]
         assert idx_ok.max() < (4 * hm_err) / 64 + 1e-3
+
+
+@pytest.mark.parametrize("size,variant", [(128, "block"), (128, "patch"), (256, "block")])
+def test_production_f32s_program_with_fused_decoder_front_end(emu_library, student_weights, size, variant, monkeypatch):
+    """The production f32s program (arena reuse, fused MBConv/EXPDW blocks, fused 98-channel head and the fused
+    DecoderBlock front end: bilinear x2 + concat + depthwise + pointwise in ONE launch) against the oracle.  Covers both
+    front-end kernels: the register-blocked producer (default) and the LDS class-filter one (PEPPA_SEPUP=patch), at
+    16/32-wide (size 128) and 32/64-wide (size 256) decoder maps."""
+    from peppa_pig_face_landmark_amd._native import Engine
+    monkeypatch.setenv("PEPPA_SEPUP", variant)
+    eng = Engine(0, emu_library)
+    try:
+        B = 1 if size == 256 else 2
+        blob, _ = build_student_program(student_weights, size, "f32s")
+        eng.load_program(0, blob, B)
+        crops = sw.smooth_blob_images(B, size, seed=1700 + size)
+        loc, score = eng.landmark_forward(crops)
+        oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+        safe = helpers.heat_margins(taps) > 1e-3
+        d = np.abs(loc - oloc).reshape(B, 98, 2).max(2)
+        assert safe.mean() > 0.9 and d[safe].max() < 1e-4, d[safe].max()
+        assert np.abs(score - oscore)[safe].max() < 2e-3
+    finally:
+        eng.close()
