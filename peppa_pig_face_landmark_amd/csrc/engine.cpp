@@ -70,8 +70,6 @@ struct pf_handle {
     unsigned long long alloc_epoch = 0;
     // kernel-variant switches for A/B timing on the GPU (environment, read once at pf_create): PEPPA_SEPUP=patch
     // selects the previous LDS-class-filter decoder front end instead of the register-blocked one
-    int sepup_variant = 0;
-    int hero_variant = 0;    // PEPPA_HERO=v1: previous halo-resident 3x3 kernel (weights one tap ahead, 128-pixel tiles)
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
     int expdw_variant = 0;   // PEPPA_EXPDW=wide: fused expand+depthwise kernels with 256 VGPRs (one workgroup per CU, no spills)
     // RCCL communicator for pf_broadcast_weights (comm.inl); created lazily, one per handle
@@ -205,10 +203,6 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         (a.outW == 16 || a.outW == 32 || a.outW == 64) && ((a.outH * a.outW) % 128) == 0 && a.inH == a.outH && a.inW == a.outW &&
         (a.Npad == 128 || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
         if constexpr (SPLIT) {
-            if (a.Npad == 128 && h->hero_variant == 0 && ((a.outH * a.outW) % 256) == 0) {   // weights two taps ahead, 256-pixel tiles
-                PF_LAUNCH((conv3x3_halo_split_v2_kernel<128>), dim3(pf_div_up(M, 256), 1), dim3(1024), h->stream, a);
-                return 0;
-            }
             grid = dim3(pf_div_up(M, 128), 1);
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 80) PF_LAUNCH((conv3x3_halo_split_kernel<80, 8, 1>), grid, dim3(512), h->stream, a);
@@ -293,18 +287,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "sepup_c%d_n%d_%dx%d", a.inC, a.N, to.H, to.W);
                     ProfScope ps(h, tagbuf);
                     const bool patch_ok = (to.W == 16 || to.W == 32 || to.W == 64) && ((to.H * to.W) % 128) == 0 && (tl.C % 32) == 0;
-                    if (patch_ok && h->sepup_variant != 1 && (a.Npad == 256 || a.Npad <= 128) && (a.inC % 2) == 0 && (to.H % 2) == 0) {
-                        // register-blocked producer: plain depthwise taps instead of the position-class filters
-                        a.dw_w = (const float*)p.cptr(f[13]);
-                        if (a.Npad == 256) {
-                            grid.y = 1;
-                            PF_LAUNCH((sepup_block_kernel<256, 4, 2, 2>), grid, dim3(512), h->stream, a);
-                        } else if (h->sepup_variant == 2) {
-                            PF_LAUNCH((sepup_block_kernel<128, 4, 2, 2>), grid, dim3(512), h->stream, a);
-                        } else {
-                            PF_LAUNCH((sepup_block_kernel<128, 4, 2, 4>), grid, dim3(512), h->stream, a);
-                        }
-                    } else if (patch_ok && a.Npad == 256) {
+                    if (patch_ok && a.Npad == 256) {
                         grid.y = 1;
                         PF_LAUNCH((sepup_patch_kernel<256, 4, 2>), grid, dim3(512), h->stream, a);
                     } else if (patch_ok && a.Npad <= 128) {
@@ -627,9 +610,7 @@ int pf_create(int device_id, pf_handle** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return 1; }
     pf_handle* h = new pf_handle();
     h->device = device_id;
-    if (const char* v = getenv("PEPPA_SEPUP")) h->sepup_variant = strcmp(v, "patch") == 0 ? 1 : (strcmp(v, "block1") == 0 ? 2 : 0);
     if (const char* v = getenv("PEPPA_DBG")) h->dbg = atoi(v);
-    if (const char* v = getenv("PEPPA_HERO")) h->hero_variant = strcmp(v, "v1") == 0 ? 1 : 0;
     if (const char* v = getenv("PEPPA_EXPDW")) h->expdw_variant = strcmp(v, "wide") == 0 ? 1 : 0;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {

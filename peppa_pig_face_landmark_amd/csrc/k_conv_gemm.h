@@ -52,10 +52,9 @@ struct ConvGemmArgs {
     // fused "pointwise expand -> depthwise kxk" (EPI != 0 kernels): dw_w2 = [K*K][N] depthwise weights, dw_b = [N]
     // bias, both BN folded; the depthwise output goes to `out`, its per-face channel means (SE squeeze) to gap_out
     float* gap_out;       // [B][N] or nullptr
-    // timing ablations (PEPPA_DBG bit mask, 0 in production; results are WRONG when set): 1 = weights fetched for the first
-    // K step only, 2 = producer skips its global loads of depthwise taps, 4 = producer skips the skip-connection loads,
-    // 8 = producer runs for the first K step only, 16 = no MFMAs, 32 = no output stores, 64 = input patch staged for the first
-    // channel chunk only, 128 = no per-tap barrier
+    // timing ablations of conv3x3_halo_split_kernel (PEPPA_DBG bit mask, 0 in production; results are WRONG when set):
+    // 1 = weights fetched for the first K step only, 16 = no MFMAs, 32 = no output stores, 64 = input patch staged for the
+    // first channel chunk only, 128 = no per-tap barrier.  What each part costs on MI355X is tabulated in DESIGN.md.
     int dbg;
 };
 
@@ -1299,451 +1298,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
         }
         __syncthreads();
-    }
-    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
-}
-
-// ---- fused DecoderBlock front end, register-blocked producer ---------------------------------------------------
-// Same operator as sepup_patch_kernel (bilinear x2 upsample + concat + depthwise 3x3 + BN as the producer of a
-// pointwise split-precision GEMM), restructured around what bounded that kernel: its producer issued 36 ds_read_b128
-// per (pixel, 8 channels) -- 4.5 LDS reads per operand element, more LDS cycles per K step than the MFMAs -- in a
-// phase of its own, two barriers per K step with nothing overlapping either of them.  Here
-//   * a thread owns a 2 x 2 block of output pixels x 2 channels.  The four pixels share ONE 3 x 3 low-res patch
-//     (DecoderBlock's interpolate is exactly x2), so the thread reads 9 float2 from the LDS patch, builds the 4 x 4
-//     window of the UPSAMPLED map in registers (separable bilinear: rows .75/.25, then columns; border replication is
-//     already in the patch, the depthwise conv's zero padding is a 0/1 factor on the outer row / column) and slides the
-//     plain 3 x 3 depthwise filter (9 float2, channel-only weights straight from global/L1 -- no position classes, no
-//     18 KB class-filter table in LDS) over it: 0.56 LDS reads per operand element instead of 4.5;
-//   * the pixel operand and the weights are double buffered, so the producer of step k+1 and the MFMAs of step k sit in
-//     the SAME barrier interval and overlap (VALU / LDS of one wave beside the matrix pipe of another); the second
-//     barrier of a step only fences the tiny patch hand-over (2 ds_write_b128 per thread);
-//   * skip-connection chunks (the last one or two) read their 4 x 4 window straight from the high-res tensor.
-// Host guarantees: W in {16, 32, 64} (= 2 x low-res width), (H * W) % 128 == 0, C1 % 32 == 0, even channel counts.
-// MINW = waves per SIMD the register allocation must allow: 4 = two workgroups per CU (<= 128 VGPRs), 2 = one (<= 256).
-template <int BN, int WARPS_M, int WARPS_N, int MINW>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, MINW) void sepup_block_kernel(ConvGemmArgs a) {
-    constexpr int BM = 128;
-    constexpr int NTHR = WARPS_M * WARPS_N * 64;
-    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
-    constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int MAXPP = 102;                           // 3 x 34 low-res pixels at W = 64 (4 x 18 at 32, 6 x 10 at 16)
-    constexpr int PU = (MAXPP * 8 + NTHR - 1) / NTHR;    // 16-byte patch units per thread
-    constexpr int P_BYTES = MAXPP * 128;
-    constexpr int PLANE_X = BM * 64;
-    constexpr int X_BYTES = 2 * PLANE_X;                 // hi | lo
-    constexpr int WCHUNKS = BN * 8 / NTHR;
-    constexpr int W_BYTES = BN * 128;
-    static_assert(NTHR == 512 && (BN * 8) % NTHR == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[P_BYTES + 2 * X_BYTES + 2 * W_BYTES];
-    float* pl = reinterpret_cast<float*>(smem);                      // [patch pixel][32 ch]
-    unsigned char* xbase = smem + P_BYTES;
-    unsigned char* wbase = xbase + 2 * X_BYTES;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int W = a.outW, H = a.outH, OHW = H * W;
-    const int M = a.B * OHW;
-    const int TR = BM / W;
-    const int PC = a.loW + 2;
-    const int PP = (TR / 2 + 2) * PC;
-    const int face = m0 / OHW;
-    const int y0 = (m0 - face * OHW) / W;
-    const int rmin = (y0 >> 1) - 1;                      // low-res row held in patch row 0 (before clamping)
-    const float* __restrict__ lo = a.up_lo + (size_t)face * a.loH * a.loW * a.loLd;
-    const float* __restrict__ sk = a.up_skip + (size_t)face * OHW * a.skipLd;
-    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
-    const int cblocks = a.Cpad / 32;
-    const size_t wrow_bytes = (size_t)cblocks * 128;
-    const int lo_chunks = a.C1 / 32;
-    const bool tile_ok = m0 < M;
-
-    // ---- patch units of this thread (border replication applied to the SOURCE coordinates) ---------------
-    int poff[PU], pdst[PU];
-#pragma unroll
-    for (int u = 0; u < PU; ++u) {
-        const int q = t + NTHR * u;
-        const int pp = q >> 3, c4 = q & 7;
-        const bool ok = pp < PP && tile_ok;
-        const int pr = pp / PC, pc = pp - pr * PC;
-        const int ry = min(max(rmin + pr, 0), a.loH - 1), rx = min(max(pc - 1, 0), a.loW - 1);
-        poff[u] = ok ? (ry * a.loW + rx) * a.loLd + c4 * 4 : -1;
-        pdst[u] = pp * 32 + c4 * 4;
-    }
-    pf_f32x4 preg[PU];
-    auto load_patch = [&](int cb) {
-#pragma unroll
-        for (int u = 0; u < PU; ++u) preg[u] = poff[u] >= 0 ? *reinterpret_cast<const pf_f32x4*>(lo + poff[u] + cb * 32) : pf_f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto store_patch = [&]() {
-#pragma unroll
-        for (int u = 0; u < PU; ++u)
-            if (poff[u] >= 0) *reinterpret_cast<pf_f32x4*>(pl + pdst[u]) = preg[u];
-    };
-    auto dma_weights = [&](int cb, int stage) {
-        unsigned char* wdst = wbase + stage * W_BYTES;
-#pragma unroll
-        for (int c = 0; c < WCHUNKS; ++c) {
-            const int sl = t + NTHR * c;
-            const int plane = sl >= BN * 4 ? 1 : 0;
-            const int row = (sl - plane * BN * 4) >> 2;
-            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-            const int n = min(n0 + row, a.Npad - 1);
-            pf_glds16(wt + (size_t)n * wrow_bytes + (size_t)cb * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
-        }
-    };
-
-    // ---- this thread's producer task: channels (2 * pair, 2 * pair + 1) of the chunk, output block (br, bc) --------------
-    const int pair = t & 15;
-    const int blk = t >> 4;                              // 0..31 = (TR / 2) x (W / 2) blocks of 2 x 2 pixels
-    const int hw2 = W >> 1;
-    const int br = blk / hw2, bc = blk - br * hw2;
-    const int my = (y0 >> 1) + br, mx = bc;              // low-res pixel under the block
-    // zero padding of the depthwise conv on the UPSAMPLED map: window row 0 is y = 2 my - 1, row 3 is y = 2 my + 2
-    const float vz0 = my == 0 ? 0.f : 1.f, vz3 = my == a.loH - 1 ? 0.f : 1.f;
-    const float hz0 = mx == 0 ? 0.f : 1.f, hz3 = mx == a.loW - 1 ? 0.f : 1.f;
-    const float* ppix = pl + (br * PC + bc) * 32 + 2 * pair;          // patch pixel (row br, col bc) == low-res (my - 1, mx - 1)
-    int xoff[2][2];                                      // byte offsets of this task's four pixels inside an x plane
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) xoff[r][s] = pf_lds_chunk_off((2 * br + r) * W + 2 * bc + s, pair >> 2) + (pair & 3) * 4;
-
-    auto produce = [&](int cb, int stage) {
-        const int kelem = cb * 32 + 2 * pair;
-        pf_f32x2 o[2][2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) o[r][s] = pf_f32x2{0.f, 0.f};
-        if (tile_ok && kelem < a.inC) {
-            pf_f32x2 bias = pf_f32x2{0.1f, 0.1f};
-            pf_f32x2 wk[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) wk[k] = pf_f32x2{0.1f, 0.1f};
-            if (!(a.dbg & 2)) {
-                bias = *reinterpret_cast<const pf_f32x2*>(a.dw_b + kelem);
-#pragma unroll
-                for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const pf_f32x2*>(a.dw_w + (size_t)k * a.Cpad + kelem);
-            }
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) o[r][s] = bias;
-            if (cb < lo_chunks) {
-                pf_f32x2 L[3][3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) L[j][i] = *reinterpret_cast<const pf_f32x2*>(ppix + (j * PC + i) * 32);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {            // window row j: y = 2 my - 1 + j
-                    const int ja = j < 2 ? 0 : 1;        // rows (ja, ja + 1) of the patch
-                    const float ca = (j == 0 ? 0.75f * vz0 : (j == 1 ? 0.25f : (j == 2 ? 0.75f : 0.25f * vz3)));
-                    const float cbv = (j == 0 ? 0.25f * vz0 : (j == 1 ? 0.75f : (j == 2 ? 0.25f : 0.75f * vz3)));
-                    pf_f32x2 V[3], U[4];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) V[i] = L[ja][i] * ca + L[ja + 1][i] * cbv;
-                    U[0] = (V[0] * 0.75f + V[1] * 0.25f) * hz0;
-                    U[1] = V[0] * 0.25f + V[1] * 0.75f;
-                    U[2] = V[1] * 0.75f + V[2] * 0.25f;
-                    U[3] = (V[1] * 0.25f + V[2] * 0.75f) * hz3;
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const int k1 = j - r;            // filter row that maps window row j onto output row r
-                        if (k1 < 0 || k1 > 2) continue;
-#pragma unroll
-                        for (int s = 0; s < 2; ++s)
-#pragma unroll
-                            for (int k2 = 0; k2 < 3; ++k2) o[r][s] = o[r][s] + wk[k1 * 3 + k2] * U[s + k2];
-                    }
-                }
-            } else {
-                const float* sp = sk + (kelem - a.C1);
-                const int yb = y0 + 2 * br - 1, xb = 2 * bc - 1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int yy = yb + j;
-                    pf_f32x2 U[4];
-                    // branch-free: clamped address, value zeroed afterwards -- all 16 loads of the window go out back to back
-                    // (guarded loads compile to one exec-masked branch and one wait EACH)
-                    const int yc = min(max(yy, 0), H - 1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int xx = xb + i;
-                        const int xc = min(max(xx, 0), W - 1);
-                        const float keep = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? 1.f : 0.f;
-                        pf_f32x2 v = pf_f32x2{0.f, 0.f};
-                        if (!(a.dbg & 4)) v = *reinterpret_cast<const pf_f32x2*>(sp + ((size_t)yc * W + xc) * a.skipLd);
-                        U[i] = v * keep;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const int k1 = j - r;
-                        if (k1 < 0 || k1 > 2) continue;
-#pragma unroll
-                        for (int s = 0; s < 2; ++s)
-#pragma unroll
-                            for (int k2 = 0; k2 < 3; ++k2) o[r][s] = o[r][s] + wk[k1 * 3 + k2] * U[s + k2];
-                    }
-                }
-            }
-        }
-        unsigned char* xh = xbase + stage * X_BYTES;
-        unsigned char* xl = xh + PLANE_X;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                h2 hi, lo2;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const pf_half hv = (pf_half)o[r][s][e];
-                    hi[e] = hv;
-                    lo2[e] = (pf_half)(o[r][s][e] - (float)hv);
-                }
-                *reinterpret_cast<h2*>(xh + xoff[r][s]) = hi;
-                *reinterpret_cast<h2*>(xl + xoff[r][s]) = lo2;
-            }
-    };
-
-    pf_f32x4 acc[NT][MT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fchunk = lane >> 4;
-
-    // ---- prologue: patch 0 -> LDS, operand / weights of step 0, patch 1 -> LDS ------------------------------------------
-    if (lo_chunks > 0) {
-        load_patch(0);
-        store_patch();
-        if (lo_chunks > 1) load_patch(1);
-    }
-    __syncthreads();
-    dma_weights(0, 0);
-    produce(0, 0);
-    __syncthreads();
-    if (lo_chunks > 1) {
-        store_patch();
-        if (lo_chunks > 2) load_patch(2);
-    }
-    __syncthreads();
-    for (int cb = 0; cb < cblocks; ++cb) {
-        const int cur = cb & 1;
-        // ---- one interval: weights + pixel operand of step cb + 1  ||  MFMAs of step cb -----------------------------------
-        if (cb + 1 < cblocks) {
-            if (!(a.dbg & 1)) dma_weights(cb + 1, cur ^ 1);
-            if (!(a.dbg & 8)) produce(cb + 1, cur ^ 1);  // reads the patch of chunk cb + 1 (in LDS since the last barrier)
-        }
-        const unsigned char* xh = xbase + cur * X_BYTES;
-        const unsigned char* xl = xh + PLANE_X;
-        const unsigned char* wh = wbase + cur * W_BYTES;
-        const unsigned char* wl = wh + BN * 64;
-        // pixel fragments of both 16-pixel sub-tiles stay live, weight fragments are fetched one 16-channel tile at a time
-        // (MT <= NT: fewer live registers beside the producer's than holding all NT weight tiles)
-        pf_half8 xhf[MT], xlf[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
-            xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
-            xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
-        }
-        if (!(a.dbg & 16))
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-            const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wh + off);
-            const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wl + off);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
-        }
-        __syncthreads();
-        // ---- patch hand-over: chunk cb + 2 -> LDS (nobody reads the patch between these two barriers) --------------------
-        if (cb + 2 < lo_chunks) {
-            store_patch();
-            if (cb + 3 < lo_chunks) load_patch(cb + 3);
-            __syncthreads();
-        }
-    }
-    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
-}
-
-// ---- 3x3 halo-resident convolution, second generation: weights two taps ahead ------------------------------------
-// conv3x3_halo_split_kernel fetches the weights of tap k+1 while the MFMAs of tap k run and ends every tap with
-// "s_waitcnt vmcnt(0); s_barrier".  Timing ablations on MI355X (PEPPA_DBG) showed what that costs: a tap's 16 KB LDS-DMA
-// needs ~1.1 us from issue to landed under load (MI355X_MICROARCH.md, ldsdma-fill) but the tap's MFMAs only ~0.3 us, so
-// every one of the 36 K steps of a workgroup waited out a DMA latency and the matrix pipe idled half the time with two
-// workgroups per CU.  Here
-//   * one 1024-thread workgroup (16 waves, 8 x 2) owns 256 output pixels, so the two tiles that used to fetch the SAME
-//     weights separately on a CU share one copy (L2 -> LDS traffic halves);
-//   * the weights go through a ring of THREE 16 KB stages and are requested two taps ahead; the barrier that ends a tap
-//     waits only for the stage the next tap reads (s_waitcnt vmcnt(N) with the younger requests left in flight --
-//     LDS-DMA stays in flight across s_barrier);
-//   * the input patch ((rows + 2) x (W + 2) pixels x 32 channels, split to hi / lo) is still register-prefetched one
-//     channel chunk (nine taps) ahead.
-// Host guarantees: pad = dil = stride = 1, W in {16, 32, 64}, (H * W) % 256 == 0, no input gate, BN == Npad.
-template <int BN>
-__global__ __launch_bounds__(1024, 4) void conv3x3_halo_split_v2_kernel(ConvGemmArgs a) {
-    constexpr int BM = 256, WARPS_M = 8, WARPS_N = 2;
-    constexpr int NTHR = 1024;
-    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
-    constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int MAXHP = 400;                           // (4 + 2) x (64 + 2) = 396 halo pixels at W = 64 (340 / 324 at 32 / 16)
-    constexpr int XU = (MAXHP * 4 + NTHR - 1) / NTHR;    // (pixel, 8-float unit) pairs per thread
-    constexpr int PLANE_X = MAXHP * 64;
-    constexpr int W_SLOTS = BN * 8;                      // 16-byte slots of one weight stage (hi plane | lo plane)
-    constexpr int WCHUNKS = (W_SLOTS + NTHR - 1) / NTHR;
-    constexpr int W_BYTES = WCHUNKS * NTHR * 16;
-    constexpr int NSTAGE = 3;
-    static_assert(WM % 16 == 0 && WN % 16 == 0 && WCHUNKS == 1 && XU == 2, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + NSTAGE * W_BYTES];
-    unsigned char* xh = smem;
-    unsigned char* xl = smem + PLANE_X;
-    unsigned char* wbase = smem + 2 * PLANE_X;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
-    int mtile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware tile order
-    const int m0 = mtile * BM;
-    const int n0 = blockIdx.y * BN;
-    const int W = a.outW, H = a.outH, OHW = H * W;
-    const int M = a.B * OHW;
-    const int HW2 = W + 2;
-    const int TR = BM / W;
-    const int HP = (TR + 2) * HW2;
-    const int face = m0 / OHW;
-    const int y0 = (m0 - face * OHW) / W;
-    const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)face * OHW * a.inLd;
-    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
-    const int cblocks = a.Cpad / 32;
-    const size_t wrow_bytes = (size_t)9 * cblocks * 128;
-
-    int xoff[XU], xhp[XU];
-    const int xc = t & 3;
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-        const int hp = (t >> 2) + (NTHR / 4) * u;
-        xhp[u] = hp < HP ? hp : -1;
-        const int hy = hp / HW2, hx = hp - hy * HW2;
-        const int iy = y0 - 1 + hy, ix = hx - 1;
-        const bool ok = hp < HP && m0 < M && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xoff[u] = ok ? (iy * W + ix) * a.inLd + xc * 8 : -1;
-    }
-    pf_f32x4 xreg[XU][2];
-    auto load_x = [&](int cb) {
-#pragma unroll
-        for (int u = 0; u < XU; ++u)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xoff[u] >= 0 && cb * 32 + xc * 8 + 4 * h < a.inC) v = *reinterpret_cast<const pf_f32x4*>(in + xoff[u] + cb * 32 + 4 * h);
-                xreg[u][h] = v;
-            }
-    };
-    auto store_x = [&]() {
-#pragma unroll
-        for (int u = 0; u < XU; ++u) {
-            if (xhp[u] < 0) continue;
-            pf_half8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = xreg[u][e >> 2][e & 3];
-                const pf_half hv = (pf_half)v;
-                hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
-            }
-            const int off = pf_lds_chunk_off(xhp[u], xc);
-            *reinterpret_cast<pf_half8*>(xh + off) = hi;
-            *reinterpret_cast<pf_half8*>(xl + off) = lo;
-        }
-    };
-    // this thread's slot of a weight stage: (plane, row, rotated chunk) -- constant over the K loop
-    const int w_plane = t >= BN * 4 ? 1 : 0;
-    const int w_r = (t - w_plane * BN * 4) >> 2;
-    const int w_row = w_r < BN ? w_r : BN - 1;
-    const int w_chunk = ((t & 3) - 2 * (w_row >> 2)) & 3;
-    const unsigned char* w_src = wt + (size_t)min(n0 + w_row, a.Npad - 1) * wrow_bytes + w_plane * 64 + w_chunk * 16;
-    auto load_w = [&](int kt, int stage) {               // kt = cb * 9 + tap: the weight rows are [tap][cb] blocks of 128 bytes
-        const int cbk = kt / 9, tapk = kt - cbk * 9;
-        pf_glds16(w_src + ((size_t)tapk * cblocks + cbk) * 128, wbase + stage * W_BYTES + t * 16);
-    };
-
-    pf_f32x4 acc[NT][MT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fchunk = lane >> 4;
-    int hp0[MT];                                         // halo row of this lane's pixel at tap (0, 0)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int p = wm * WM + i * 16 + frow;
-        const int ty = p / W, tx = p - ty * W;
-        hp0[i] = ty * HW2 + tx;
-    }
-
-    const int nk = 9 * cblocks;
-    load_x(0);
-    load_w(0, 0);
-    if (nk > 1) load_w(1, 1);
-    store_x();
-    __syncthreads();
-    int tap = 0, cb = 0, stage = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool last_tap = tap == 8;
-        // requests of this tap, oldest first: (first tap of a chunk) the next patch, then the weights two taps ahead
-        if (tap == 0 && cb + 1 < cblocks) load_x(cb + 1);
-        if (kt + 2 < nk && !(a.dbg & 1)) load_w(kt + 2, stage >= 1 ? stage - 1 : 2);      // (stage + 2) % 3
-        const unsigned char* wh = wbase + stage * W_BYTES;
-        const unsigned char* wl = wh + BN * 64;
-        pf_half8 whf[NT], wlf[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-            whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
-            wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
-        }
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int shift = ky * HW2 + kx;
-        if (!(a.dbg & 16))
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int off = pf_lds_chunk_off(hp0[i] + shift, fchunk);
-            const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xh + off);
-            const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xl + off);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(wlf[j], xhf, acc[j][i]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xlf, acc[j][i]);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
-        }
-        if (last_tap && kt + 1 < nk) {
-            __syncthreads();                 // every wave is done with this chunk's patch (drains everything: once per 9 taps)
-            store_x();
-            __syncthreads();
-        } else {
-            // end of tap: the NEXT tap's weights (requested one tap ago) must have landed; only this tap's own DMA is
-            // younger than them and stays in flight.  The first tap of a chunk follows a full drain (its weights are there
-            // already) and may leave its 2 * XU patch loads in flight as well.
-            if (kt + 2 >= nk) __syncthreads();               // no request this tap: nothing younger to leave in flight
-            else if (tap == 0) pf_wait_vm_barrier<2 * XU + 1>();
-            else pf_wait_vm_barrier<1>();
-        }
-        if (last_tap) { tap = 0; ++cb; } else ++tap;
-        stage = stage == 2 ? 0 : stage + 1;
     }
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }

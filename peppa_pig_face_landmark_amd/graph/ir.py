@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 7
+VERSION = 6
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
@@ -407,13 +407,8 @@ class ProgramBuilder:
                 E[cy, cx] = np.einsum("kj,li,ckl->jic", ay[cy], ax[cx], wdw[:c1])
         dwe = self.const_f32(E.reshape(16 * 9, c1))
         dws = self.const_f32(np.transpose(wdw[c1:].reshape(c - c1, 9), (1, 0)))
-        # plain depthwise taps of ALL channels, [9][Cpad] zero padded: the register-blocked producer (sepup_block_kernel)
-        # rebuilds the upsampled window itself and needs no position classes
-        plain = np.zeros((9, cpad), np.float64)
-        plain[:, :c] = np.transpose(wdw.reshape(c, 9), (1, 0))
-        dwp = self.const_f32(plain)
         self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
-                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, dwp],
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws],
                  [self._tb(lo), self._tb(skip)], [self._tb(out)])
         return out
 

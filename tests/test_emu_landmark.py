@@ -83,14 +83,12 @@ def test_student_f16_tracks_oracle(emu_engine, student_weights):
         assert idx_ok.max() < (4 * hm_err) / 64 + 1e-3
 
 
-@pytest.mark.parametrize("size,variant", [(128, "block"), (128, "patch"), (256, "block")])
-def test_production_f32s_program_with_fused_decoder_front_end(emu_library, student_weights, size, variant, monkeypatch):
+@pytest.mark.parametrize("size", [128, 256])
+def test_production_f32s_program_with_fused_decoder_front_end(emu_library, student_weights, size):
     """The production f32s program (arena reuse, fused MBConv/EXPDW blocks, fused 98-channel head and the fused
-    DecoderBlock front end: bilinear x2 + concat + depthwise + pointwise in ONE launch) against the oracle.  Covers both
-    front-end kernels: the register-blocked producer (default) and the LDS class-filter one (PEPPA_SEPUP=patch), at
-    16/32-wide (size 128) and 32/64-wide (size 256) decoder maps."""
+    DecoderBlock front end: bilinear x2 + concat + depthwise + pointwise in ONE launch) against the oracle, at 16/32-wide
+    (size 128) and 32/64-wide (size 256) decoder maps -- the keep_all debug programs of the other tests never fuse it."""
     from peppa_pig_face_landmark_amd._native import Engine
-    monkeypatch.setenv("PEPPA_SEPUP", variant)
     eng = Engine(0, emu_library)
     try:
         B = 1 if size == 256 else 2
