@@ -102,12 +102,15 @@ def cpu_baseline(n_faces: int, frame_hw, faces_per_frame: int):
     from oracle import synth_weights as sw
     from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
 
+    from peppa_pig_face_landmark_amd.graph.detector import random_detector_weights
+    from peppa_pig_face_landmark_amd.graph.random_init import random_student_weights
+
     t_all = time.perf_counter()
-    W = ln.to_torch(sw.student_weights())
+    W = ln.to_torch(random_student_weights(0))       # the weights the GPU legs run (timing does not depend on their values)
     crops = sw.smooth_blob_images(8, 256, seed=99)
     x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
     ncpu = os.cpu_count() or 1
-    cands = sorted({c for c in (8, 16, 32, 64, ncpu) if c <= ncpu} or {ncpu})
+    cands = sorted({c for c in (8, 16, 32) if c <= ncpu} or {ncpu})
     best_thr, best_t = cands[0], 1e30
     with torch.no_grad():
         for thr in cands:
@@ -119,43 +122,49 @@ def cpu_baseline(n_faces: int, frame_hw, faces_per_frame: int):
             if dt < best_t:
                 best_thr, best_t = thr, dt
         torch.set_num_threads(best_thr)
+        setup_s = time.perf_counter() - t_all
         ln.student_forward(W, x[:1])
-        t0 = time.perf_counter()
-        for i in range(n_faces):
-            ln.student_forward(W, x[i % 8:i % 8 + 1])
+        # every leg runs for a fixed wall-time budget (about 16 s of CPU work in total), at least n_faces faces
+        n_b1, t0 = 0, time.perf_counter()
+        while n_b1 < n_faces or time.perf_counter() - t0 < 6.0:
+            ln.student_forward(W, x[n_b1 % 8:n_b1 % 8 + 1])
+            n_b1 += 1
         dt_b1 = time.perf_counter() - t0
         ln.student_forward(W, x)
-        nb8 = max(1, n_faces // 8)
-        t0 = time.perf_counter()
-        for _ in range(nb8):
+        nb8, t0 = 0, time.perf_counter()
+        while nb8 < 2 or time.perf_counter() - t0 < 4.0:
             ln.student_forward(W, x)
+            nb8 += 1
         dt_b8 = time.perf_counter() - t0
-        # full pipeline on one frame (x faces_per_frame faces), the reference's order of operations
+        # full pipeline on whole frames (x faces_per_frame faces), the reference's order of operations
         H, Wd = frame_hw
         frame, boxes = make_frame(H, Wd, faces_per_frame, seed=7)
         rows = plant_rows(boxes, (H, Wd), 15120, (384, 640), 24, seed=7)
-        DW = ln.to_torch(sw.detector_weights())
-        t0 = time.perf_counter()
-        xin, info = pp.detector_preprocess(frame, (384, 640))
-        dn.detector_forward(DW, torch.from_numpy(xin))               # its output is replaced by the planted rows below
-        kept = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
-        sel = pp.sort_and_filter(kept, 1600.0, faces_per_frame)
-        for k in range(sel.shape[0]):
-            ci = pp.landmark_crop_box(sel[k], H, Wd)
-            crop = pp.landmark_crop(frame, ci, (256, 256))
-            loc, _ = ln.student_forward(W, torch.from_numpy(pp.landmark_input(crop)))[:2]
-            pp.landmark_backproject(loc[0].numpy(), ci)
+        DW = ln.to_torch(random_detector_weights(1))
+        dn.detector_forward(DW, torch.from_numpy(pp.detector_preprocess(frame, (384, 640))[0]))
+        n_frames, n_pipe, t0 = 0, 0, time.perf_counter()
+        while n_frames < 2 or time.perf_counter() - t0 < 5.0:
+            xin, info = pp.detector_preprocess(frame, (384, 640))
+            dn.detector_forward(DW, torch.from_numpy(xin))           # its output is replaced by the planted rows below
+            kept = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+            sel = pp.sort_and_filter(kept, 1600.0, faces_per_frame)
+            for k in range(sel.shape[0]):
+                ci = pp.landmark_crop_box(sel[k], H, Wd)
+                crop = pp.landmark_crop(frame, ci, (256, 256))
+                loc, _ = ln.student_forward(W, torch.from_numpy(pp.landmark_input(crop)))[:2]
+                pp.landmark_backproject(loc[0].numpy(), ci)
+            n_frames += 1
+            n_pipe += int(sel.shape[0])
         dt_pipe = time.perf_counter() - t0
-        n_pipe = int(sel.shape[0])
-    return {"value": round(n_faces / dt_b1, 2), "unit": "faces/s", "cores": best_thr, "kind": "port",
+    return {"value": round(n_b1 / dt_b1, 2), "unit": "faces/s", "cores": best_thr, "kind": "port",
             "sample": "%d faces, Student@256 landmark forward, batch=1 python loop (face_landmark.py:40-48 shape), torch-CPU f32 "
                       "oracle as stand-in for onnxruntime-CPU, %d torch threads (best of %s on a 2-face probe; host has %d "
-                      "logical cores); %.1f s" % (n_faces, best_thr, cands, ncpu, dt_b1),
-            "landmark_b8_faces_per_s": round(nb8 * 8 / dt_b8, 2),
-            "pipeline_faces_per_s": round(n_pipe / dt_pipe, 2), "pipeline_ms_per_frame": round(dt_pipe * 1e3, 1),
-            "pipeline_sample": "1 frame %dx%d x %d faces: numpy letterbox + torch detector + numpy NMS/top-k + per-face numpy crop/"
-                               "resize + B=1 forward + back-projection" % (Wd, H, n_pipe),
-            "total_cpu_s": round(time.perf_counter() - t_all, 1),
+                      "logical cores); %.1f s" % (n_b1, best_thr, cands, ncpu, dt_b1),
+            "landmark_b8_faces_per_s": round(nb8 * 8 / dt_b8, 2), "landmark_b8_sample": "%d batches of 8 in %.1f s" % (nb8, dt_b8),
+            "pipeline_faces_per_s": round(n_pipe / dt_pipe, 2), "pipeline_ms_per_frame": round(dt_pipe / n_frames * 1e3, 1),
+            "pipeline_sample": "%d frames %dx%d x %d faces in %.1f s: numpy letterbox + torch detector + numpy NMS/top-k + per-face "
+                               "numpy crop/resize + B=1 forward + back-projection" % (n_frames, Wd, H, faces_per_frame, dt_pipe),
+            "setup_s": round(setup_s, 1), "total_cpu_s": round(time.perf_counter() - t_all, 1),
             "note": "baseline, not target: a large GPU/CPU ratio says nothing about kernel quality, the roofline fractions do"}
 
 
@@ -278,6 +287,11 @@ def main():
             os.dup2(2, 1)
         def __exit__(self, *exc):
             sys.stdout.flush()
+            try:   # the banner sits in the C library's stdio buffer (stdout is a pipe/file here): push it out while
+                import ctypes                                   # fd 1 still points at stderr, or it lands after the JSON
+                ctypes.CDLL(None).fflush(None)
+            except Exception:  # noqa: BLE001
+                pass
             os.dup2(self.saved, 1)
             os.close(self.saved)
 

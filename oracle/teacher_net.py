@@ -5,7 +5,9 @@ features (``features_only=True, out_indices=[0,1,2,3]``, model.py:306-311) + the
 ``hm`` head / ``postp`` as the student with ``encoder.out_channels = [3,64,128,256,512]`` (:313-315).
 
 * decoder / heads / decode: reuse ``oracle.landmark_net`` pieces, PINNED against the reference's own
-  classes through ``oracle.ref_import.load_reference_cotrain(..., which='teacher')``.
+  ``TeacherNet`` classes: ``oracle.ref_import.load_reference_cotrain(student, teacher, inference='teacher')``
+  executed live (``tests/test_oracle_pinned.py::test_oracle_equals_reference_live``, bit-identical) and through
+  the committed golden ``tests/golden/landmark_teacher128.npz`` (``::test_teacher_oracle_reproduces_reference_golden``).
 * encoder: timm==0.6.11 ``HighResolutionNetFeatures`` (feature_location='incre') is NOT vendored in the
   reference: restated from the published architecture -- PARITY UNPINNED.
   hrnet_w18: stem conv3x3 s2 (3->64) [feature 0] -> conv3x3 s2 (64->64) -> layer1 = 4 Bottlenecks (->256)

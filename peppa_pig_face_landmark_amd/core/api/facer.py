@@ -31,14 +31,17 @@ def get_cfg(path: Optional[str] = None):
 
 
 def _load_weights(root, rel_path: str, what: str) -> Dict[str, np.ndarray]:
+    """``model_path`` of Skps.yml -> weight dictionary.  Accepts the reference's own files --
+    ``pretrained/yolov5n-0.5.onnx`` / ``pretrained/kps_student.onnx`` (Skps/config/Skps.yml:4,12; read without
+    onnx / onnxruntime, weights.weights_from_onnx) -- as well as ``.npz`` archives and torch checkpoints."""
+    from ...weights import load_weights
     path = rel_path if os.path.isabs(rel_path) else os.path.join(root, rel_path)
     if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{what} weights not found at {path}.  The reference's .onnx blobs are not redistributable here; "
-            "export the checkpoint's state_dict to an .npz (tensor names as in the reference) or pass "
-            "FaceAna(weights={'detector': {...}, 'keypoints': {...}}).")
-    with np.load(path) as z:
-        return {k: z[k] for k in z.files}
+            f"{what} weights not found at {path}.  Put the reference's model file there (the .onnx the reference "
+            "loads at onnx_model_base.py:14 works as is; so do an .npz of state_dict arrays or a .pth checkpoint) or "
+            "pass FaceAna(weights={'detector': {...}, 'keypoints': {...}}).")
+    return load_weights(path, what)
 
 
 def _box_iou(a, b) -> float:

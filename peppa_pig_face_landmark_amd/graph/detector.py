@@ -141,6 +141,8 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
 
 
 def detector_param_shapes() -> List[Tuple[str, Tuple[int, ...], str]]:
+    """(name, shape, kind) of every tensor the detector graph needs, in EXECUTION order (the order the convolutions
+    run in ``Model.forward`` of yolov5-face, hence the order of the Conv nodes of an ONNX export)."""
     out: List[Tuple[str, Tuple[int, ...], str]] = []
 
     def cv(p, cin, cout, k):
@@ -156,9 +158,9 @@ def detector_param_shapes() -> List[Tuple[str, Tuple[int, ...], str]]:
                     (f"{p}.branch2.3.weight", (bf, 1, 3, 3), "conv"), (f"{p}.branch2.4", (bf,), "bn"),
                     (f"{p}.branch2.5.weight", (bf, bf, 1, 1), "conv"), (f"{p}.branch2.6", (bf,), "bn")])
 
-    def c3(p, c1):
-        cv(f"{p}.cv1", c1, 32, 1); cv(f"{p}.cv2", c1, 32, 1); cv(f"{p}.cv3", 64, 64, 1)
-        cv(f"{p}.m.0.cv1", 32, 32, 1); cv(f"{p}.m.0.cv2", 32, 32, 3)
+    def c3(p, c1):   # execution order of C3.forward: cv3(cat(m(cv1(x)), cv2(x))) -- the ONNX importer relies on it
+        cv(f"{p}.cv1", c1, 32, 1); cv(f"{p}.m.0.cv1", 32, 32, 1); cv(f"{p}.m.0.cv2", 32, 32, 3)
+        cv(f"{p}.cv2", c1, 32, 1); cv(f"{p}.cv3", 64, 64, 1)
 
     cv("model.0.stem_1", 3, 16, 3); cv("model.0.stem_2a", 16, 8, 1); cv("model.0.stem_2b", 8, 16, 3); cv("model.0.stem_3", 32, 16, 1)
     for li, cin, cout, reps in _BACKBONE:

@@ -5,6 +5,8 @@ What each vector pins:
   landmark_student128.npz  COTRAIN(inference='student') from the reference's model.py (decoder, heads,
                            postp executed from reference source; encoder = oracle restatement of timm)
                            on the oracle's synthetic weights: inputs, loc_fix, score, arg-max margins.
+  landmark_teacher128.npz  COTRAIN(inference='teacher'): the reference's TeacherNet decoder / heads / postp executed from
+                           source (model.py:302-345) over the oracle's HRNet-W18 restatement, on synthetic teacher weights.
   detector_post.npz        the reference's own FaceDetector.xywh2xyxy / py_nms / scale_coords and
                            preprocess geometry on seeded rows / frame sizes.
   landmark_pre.npz         the reference's own FaceLandmark.preprocess 'detail' output (executed under
@@ -48,6 +50,22 @@ def main():
                         score=ref_score.numpy(), margin=flat[:, :, -1] - flat[:, :, -2],
                         hm_absmax=np.abs(hm).max(), hm_mean=hm.mean(), weight_checksum=np.float64(
                             sum(float(np.abs(v).sum()) for v in w.values())))
+    # ---- Teacher: the reference's TeacherNet decoder / heads / postp executed from source -----------------
+    from oracle import teacher_net as tn
+    tw = sw.teacher_weights(cache=False)
+    tmodel = ri.load_reference_cotrain(w, tw, inference="teacher")
+    tcrops = sw.smooth_blob_images(1, 128, seed=2025)
+    tx = torch.from_numpy(tcrops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        tref_loc, tref_score = tmodel(tx)
+        ttaps = {}
+        toloc, toscore = tn.teacher_forward(ln.to_torch(tw), tx, ttaps)
+    assert torch.equal(tref_loc, toloc) and torch.equal(tref_score, toscore), "teacher oracle != reference"
+    thm = ttaps["hm"].numpy()
+    tflat = np.sort(thm[:, :98].reshape(1, 98, -1), axis=2)
+    np.savez_compressed(os.path.join(OUT, "landmark_teacher128.npz"), crops=tcrops, loc_fix=tref_loc.numpy(),
+                        score=tref_score.numpy(), margin=tflat[:, :, -1] - tflat[:, :, -2],
+                        weight_checksum=np.float64(sum(float(np.abs(v).sum()) for v in tw.values())))
     # ---- detector post-processing -----------------------------------------------------------------
     det = ri.reference_detector_stage()
     rng = np.random.default_rng(11)

@@ -36,6 +36,22 @@ def test_landmark_oracle_reproduces_reference_golden(student_weights):
     assert np.abs(score.numpy() - g["score"]).max() < 1e-4
 
 
+def test_teacher_oracle_reproduces_reference_golden():
+    """TeacherNet (model.py:302-345): decoder / heads / postp of the golden come from the reference's own classes."""
+    from oracle import teacher_net as tn
+    g = np.load(os.path.join(GOLD, "landmark_teacher128.npz"))
+    tw = sw.teacher_weights()
+    chk = sum(float(np.abs(v).sum()) for v in tw.values())
+    assert abs(chk - float(g["weight_checksum"])) < 1e-6 * chk, "synthetic teacher weights are not reproducible"
+    x = torch.from_numpy(g["crops"].astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    with torch.no_grad():
+        loc, score = tn.teacher_forward(ln.to_torch(tw), x)
+    safe = g["margin"] > 1e-4
+    d = np.abs(loc.numpy() - g["loc_fix"]).reshape(1, 98, 2).max(2)
+    assert d[safe].max() < 1e-5
+    assert np.abs(score.numpy() - g["score"]).max() < 1e-4
+
+
 def test_detector_postprocess_reproduces_reference_golden():
     g = np.load(os.path.join(GOLD, "detector_post.npz"))
     mine = pp.detector_postprocess(g["rows"], [1.0 / 3.0, 0, 12], 0.3, 0.5)
@@ -79,6 +95,15 @@ def test_oracle_equals_reference_live(student_weights):
     with torch.no_grad():
         rloc, rscore = model(x)
         oloc, oscore = ln.student_forward(ln.to_torch(student_weights), x)
+    assert torch.equal(rloc, oloc) and torch.equal(rscore, oscore)
+    # Teacher: TeacherNet's decoder / heads / postp from the reference source over the oracle's HRNet restatement
+    from oracle import teacher_net as tn
+    tw = sw.teacher_weights()
+    tmodel = ri.load_reference_cotrain(student_weights, tw, inference="teacher")
+    xt = x[:1, :, ::2, ::2].contiguous()
+    with torch.no_grad():
+        rloc, rscore = tmodel(xt)
+        oloc, oscore = tn.teacher_forward(ln.to_torch(tw), xt)
     assert torch.equal(rloc, oloc) and torch.equal(rscore, oscore)
     det = ri.reference_detector_stage()
     rng = np.random.default_rng(5)
