@@ -16,6 +16,7 @@ PF_MEM_ROWS_DEVICE = 0x100
 PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 PF_OPT_HIP_GRAPH = 1
+PF_OPT_RANGE_CHECK = 2
 PF_COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -25,6 +25,6 @@ class FaceDetector:
     def __call__(self, image) -> np.ndarray:
         """image: BGR uint8 frame, or None for the frame made resident by Engine.set_frame()."""
         t0 = time.time()
-        boxes = self.engine.detect(image, float(self.score_thrs), float(self.iou_thrs))
+        boxes = self.model.guarded(self.engine.detect, image, float(self.score_thrs), float(self.iou_thrs))
         logger.info("detect done, time consume: %.5f", time.time() - t0)
         return boxes

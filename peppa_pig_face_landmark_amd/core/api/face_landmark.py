@@ -35,7 +35,7 @@ class FaceLandmark:
         if bboxes.shape[0] == 0:
             return np.array([]), np.array([])
         t0 = time.time()
-        kps, scores, valid = self.engine.landmarks(img, bboxes[:, :4])
+        kps, scores, valid = self.model.guarded(self.engine.landmarks, img, bboxes[:, :4])
         dt = time.time() - t0
         logger.info("keypoints done, time consume: %.5f and %.5f per face", dt, dt / len(bboxes))
         return kps[valid], scores[valid]

@@ -23,23 +23,41 @@ class HIPEngine:
 
     def __init__(self, weights: Dict[str, np.ndarray], kind: str, input_shape, device: int = 0, dtype: str = "f32",
                  max_batch: int = 8, engine: Optional[_native.Engine] = None, library: Optional[str] = None):
+        if kind not in ("keypoints", "detector"):
+            raise ValueError(kind)
         self.kind = kind
         self.engine = engine if engine is not None else _native.Engine(device, library)
-        if kind == "keypoints":
-            blob, self.info = build_student_program(weights, int(input_shape[0]), dtype)
-            self.slot = _native.PF_NET_LANDMARK
-        elif kind == "detector":
-            blob, self.info = build_detector_program(weights, (int(input_shape[0]), int(input_shape[1])), dtype)
-            self.slot = _native.PF_NET_DETECTOR
-        else:
-            raise ValueError(kind)
+        self.slot = _native.PF_NET_LANDMARK if kind == "keypoints" else _native.PF_NET_DETECTOR
         self.max_batch = max_batch
-        self.engine.load_program(self.slot, blob, max_batch)
+        self._weights, self._input_shape = weights, input_shape
+        self._load(dtype)
+
+    def _load(self, dtype: str):
+        if self.kind == "keypoints":
+            blob, self.info = build_student_program(self._weights, int(self._input_shape[0]), dtype)
+        else:
+            blob, self.info = build_detector_program(self._weights, (int(self._input_shape[0]), int(self._input_shape[1])), dtype)
+        self.dtype = dtype
+        self.engine.load_program(self.slot, blob, self.max_batch)
+
+    def guarded(self, fn, *args):
+        """Run ``fn(*args)``; if the engine's range guard reports activations the split-precision (f32s) convolutions
+        cannot represent (PF_OPT_RANGE_CHECK: outputs NaN + error), reload this network with exact-f32 MFMA convolutions
+        and run again -- slower, never wrong."""
+        try:
+            return fn(*args)
+        except _native.PeppaHipError as e:
+            if "activation range check failed" not in str(e) or self.dtype == "f32":
+                raise
+            from ...logger.logger import logger
+            logger.warning("%s network: %s -- falling back to dtype f32", self.kind, e)
+            self._load("f32")
+            return fn(*args)
 
     def __call__(self, data: np.ndarray) -> List[np.ndarray]:
         if data.shape[0] > self.max_batch:
             raise ValueError(f"batch {data.shape[0]} exceeds max_batch {self.max_batch}")
         if self.kind == "keypoints":
-            loc, score = self.engine.landmark_forward(data)
+            loc, score = self.guarded(self.engine.landmark_forward, data)
             return [loc, score]
-        return [self.engine.detector_forward(data, self.info["rows"])]
+        return [self.guarded(self.engine.detector_forward, data, self.info["rows"])]

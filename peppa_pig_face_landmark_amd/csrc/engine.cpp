@@ -72,6 +72,13 @@ struct pf_handle {
     // selects the previous LDS-class-filter decoder front end instead of the register-blocked one
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
     int expdw_variant = 0;   // PEPPA_EXPDW=wide: fused expand+depthwise kernels with 256 VGPRs (one workgroup per CU, no spills)
+    // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
+    // after a program load, measures max |x| of the input of every split-precision op
+    int range_every = 32;
+    unsigned long long n_calls = 0;
+    bool check_pending = true, check_now = false;
+    unsigned* d_range = nullptr; size_t range_cap = 0;
+    int* h_status = nullptr;            // page-locked, device-visible: {code, op, value bits, program slot}
     // RCCL communicator for pf_broadcast_weights (comm.inl); created lazily, one per handle
     void* comm = nullptr;
     unsigned char comm_id[128] = {0};
@@ -234,13 +241,44 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     return 0;
 }
 
+// range guard: max |x| of activation tensor `t` of program `p` into slot `oi` (checked forwards of f32s programs only)
+static int measure_range(pf_handle* h, const Program& p, int t, size_t oi, int B) {
+    const PfTensorRec& tr = p.tens[t];
+    AbsMaxArgs a{};
+    a.in = (const float*)p.tensor_ptr(t);
+    a.slot = h->d_range + oi;
+    a.pixels = (long long)B * tr.H * tr.W;
+    a.C = tr.C; a.ld = tr.ld;
+    if (tr.C % 4) PF_FAIL(h, "range guard: tensor with %d channels", tr.C);
+    const long long work = a.pixels * (tr.C / 4);
+    PF_LAUNCH(absmax_kernel, dim3((unsigned)std::min<long long>(1024, (work + 255) / 256)), dim3(256), h->stream, a);
+    return 0;
+}
+
 template <typename T, bool SPLIT>
 static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
     Program& p = h->prog[slot];
     constexpr int VE = PfVec<T>::N;
+    const bool guard = SPLIT && h->check_now && !h->capturing;
+    if (guard) {
+        if (h->range_cap < p.ops.size()) {
+            if (h->d_range) (void)hipFree(h->d_range);
+            h->d_range = nullptr;
+            PF_HIP(h, hipMalloc((void**)&h->d_range, p.ops.size() * sizeof(unsigned)));
+            h->range_cap = p.ops.size();
+        }
+        PF_HIP(h, hipMemsetAsync(h->d_range, 0, p.ops.size() * sizeof(unsigned), h->stream));
+    }
     for (size_t oi = 0; oi < p.ops.size(); ++oi) {
         const PfOpRec& op = p.ops[oi];
         const int32_t* f = op.f;
+        if (guard) {   // inputs of the ops that split activations into f16 hi / lo parts
+            const bool conv_split = op.code == PF_OP_CONV && f[23] != 0;
+            const bool mb_split = op.code == PF_OP_MBCONV && (f[21] == 0 || f[21] == 3);
+            if (conv_split || mb_split || op.code == PF_OP_EXPDW || op.code == PF_OP_SEPUP)
+                if (measure_range(h, p, f[0], oi, B)) return 1;
+            if (op.code == PF_OP_SEPUP && measure_range(h, p, f[1], oi, B)) return 1;
+        }
         switch (op.code) {
             case PF_OP_STEM: {
                 const PfTensorRec& to = p.tens[f[1]];
@@ -571,8 +609,39 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 PF_FAIL(h, "unknown op code %d at op %zu", op.code, oi);
         }
     }
+    if (guard) {
+        RangeVerdictArgs v{};
+        v.slots = h->d_range; v.n_ops = (int)p.ops.size();
+        v.lo = 0.0009765625f;            // 2^-10: below this a tensor's low halves sit in the f16 subnormal range
+        v.hi = 6.0e4f;                   // f16 overflows at 65504
+        v.status = h->h_status; v.prog_slot = slot;
+        v.poison0 = (float*)p.buf_ptr(p.hdr.out_buf0); v.n0 = (long long)B * p.bufs[p.hdr.out_buf0].elems_per_item;
+        if (p.hdr.out_buf1 >= 0 && p.hdr.out_buf1 != p.hdr.out_buf0) { v.poison1 = (float*)p.buf_ptr(p.hdr.out_buf1); v.n1 = (long long)B * p.bufs[p.hdr.out_buf1].elems_per_item; }
+        if (h->pipe.d_kps_for_decode) { v.poison2 = h->pipe.d_kps_for_decode; v.n2 = (long long)B * 98 * 2; }
+        PF_LAUNCH(range_verdict_kernel, dim3(1), dim3(256), h->stream, v);
+    }
     PF_HIP(h, hipGetLastError());
     return 0;
+}
+
+// Start of every forward-running entry point: is this one of the range-checked calls?
+static void begin_call(pf_handle* h) {
+    h->check_now = h->range_every > 0 && (h->check_pending || (h->n_calls % (unsigned long long)h->range_every) == 0);
+    h->check_pending = false;
+    h->n_calls++;
+}
+
+// After a stream synchronisation: did a range-checked forward find a tensor the f32s kernels cannot represent?
+static int check_numerics(pf_handle* h) {
+    if (!h->h_status || h->h_status[0] == 0) return 0;
+    const int code = h->h_status[0], op = h->h_status[1], slot = h->h_status[3];
+    float v;
+    memcpy(&v, &h->h_status[2], 4);
+    h->h_status[0] = 0;
+    h->check_pending = true;             // keep checking until a clean forward has been seen
+    PF_FAIL(h, "activation range check failed: input of op %d of program %d has max |x| = %g, %s the range [9.8e-4, 6e4] the "
+               "split-precision (f32s) convolutions can represent (outputs were set to NaN); rebuild the program with dtype 'f32'",
+            op, slot, (double)v, code == 1 ? "above" : "below");
 }
 
 static int run_program(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
@@ -618,6 +687,12 @@ int pf_create(int device_id, pf_handle** out) {
         delete h;
         return 1;
     }
+    if (hipHostMalloc((void**)&h->h_status, 4 * sizeof(int), hipHostMallocPortable) != hipSuccess) {
+        g_create_error = "hipHostMalloc(status) failed";
+        delete h;
+        return 1;
+    }
+    memset(h->h_status, 0, 4 * sizeof(int));
     *out = h;
     return 0;
 }
@@ -633,6 +708,8 @@ void pf_destroy(pf_handle* h) {
         if (p.d_arena) (void)hipFree(p.d_arena);
     }
     if (h->d_stage) (void)hipFree(h->d_stage);
+    if (h->d_range) (void)hipFree(h->d_range);
+    if (h->h_status) (void)hipHostFree(h->h_status);
     h->pipe.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -645,7 +722,7 @@ const char* pf_last_error(pf_handle* h) { return h ? h->err.c_str() : g_create_e
 int pf_sync(pf_handle* h) {
     if (!h) return 1;
     PF_HIP(h, hipStreamSynchronize(h->stream));
-    return 0;
+    return check_numerics(h);
 }
 
 int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int max_batch) {
@@ -694,6 +771,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes));
     PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
     p.loaded = true;
+    h->check_pending = true;             // the first forward of a new program is range-checked
     return 0;
 }
 
@@ -723,10 +801,14 @@ int pf_landmark_forward(pf_handle* h, const void* input, int input_kind, int mem
     const size_t px = (size_t)p.hdr.in_h * p.hdr.in_w * 3;
     h->pipe.d_crop_for_decode = nullptr;
     h->pipe.d_kps_for_decode = nullptr;
+    begin_call(h);
     if (net_forward_common(h, PF_NET_LANDMARK, input, input_kind, mem, batch, input_kind == PF_INPUT_U8_NHWC ? px : px * 4)) return 1;
     if (copy_out(h, p.buf_ptr(p.hdr.out_buf0), loc_fix, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf0), out_mem)) return 1;
     if (copy_out(h, p.buf_ptr(p.hdr.out_buf1), score, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf1), out_mem)) return 1;
-    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (out_mem == PF_MEM_HOST) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        return check_numerics(h);
+    }
     return 0;
 }
 
@@ -735,9 +817,13 @@ int pf_detector_forward(pf_handle* h, const void* input, int input_kind, int mem
     Program& p = h->prog[PF_NET_DETECTOR];
     if (!p.loaded) PF_FAIL(h, "detector program not loaded");
     const size_t px = (size_t)p.hdr.in_h * p.hdr.in_w * 3;
+    begin_call(h);
     if (net_forward_common(h, PF_NET_DETECTOR, input, input_kind, mem, batch, input_kind == PF_INPUT_U8_NHWC ? px : px * 4)) return 1;
     if (copy_out(h, p.buf_ptr(p.hdr.out_buf0), rows_out, (size_t)batch * p.buf_item_bytes(p.hdr.out_buf0), out_mem)) return 1;
-    if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (out_mem == PF_MEM_HOST) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        return check_numerics(h);
+    }
     return 0;
 }
 

@@ -632,3 +632,70 @@ __global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
     for (int e = 0; e < VE; ++e) o[e] = (T)sum[e];
     pf_stv<T>(static_cast<T*>(a.out) + (size_t)pix * a.outLd + cv * VE, o);
 }
+
+// --------------------------------------------------------------------------------------------
+// Range guard of the split-precision (f32s) convolutions.  Those kernels write every f32 activation as hi + lo with
+// hi = f16(v): |v| >= 65504 overflows to inf, and a tensor whose LARGEST magnitude is below ~1e-3 loses its low halves to
+// the f16 subnormal range.  Weights are pre-scaled per layer at pack time; activations depend on the data, so every N-th
+// forward (PF_OPT_RANGE_CHECK) the executor measures max |x| of the input of every split-precision op and, if a tensor is
+// outside [2^-10, 6e4], poisons the outputs with NaN and records (op, value): no silent inf, no silent garbage.
+struct AbsMaxArgs {
+    const float* in;       // [pixels][ld] f32 view
+    unsigned* slot;        // max |x| as float bits (non-negative floats order like unsigned integers)
+    long long pixels;
+    int C, ld;
+};
+
+__global__ __launch_bounds__(256) void absmax_kernel(AbsMaxArgs a) {
+    const int cv = a.C / 4;
+    const long long total = a.pixels * cv;
+    float m = 0.f;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long px = i / cv;
+        const int c = (int)(i - px * cv);
+        const pf_f32x4 v = *reinterpret_cast<const pf_f32x4*>(a.in + (size_t)px * a.ld + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float av = fabsf(v[e]);
+            bad |= !(av == av);                 // NaN
+            m = fmaxf(m, av);
+        }
+    }
+    if (bad) m = __builtin_inff();              // a NaN input reports as out of range
+    for (int mask = 1; mask < 64; mask <<= 1) m = fmaxf(m, pf_shfl_xor_f32(m, mask));
+    if ((threadIdx.x & 63) == 0) atomicMax(a.slot, __float_as_uint(m));
+}
+
+struct RangeVerdictArgs {
+    const unsigned* slots;   // [n_ops] float bits, 0 = op not measured
+    int n_ops;
+    float lo, hi;            // accepted range of a tensor's max |x|
+    int* status;             // [4] = code (0 ok, 1 overflow, 2 underflow), op index, value bits, program slot (host-mapped)
+    int prog_slot;
+    float* poison0; long long n0;   // outputs overwritten with NaN on violation (may be null)
+    float* poison1; long long n1;
+    float* poison2; long long n2;
+};
+
+__global__ __launch_bounds__(256) void range_verdict_kernel(RangeVerdictArgs a) {
+    __shared__ int s_code, s_op;
+    __shared__ unsigned s_val;
+    if (threadIdx.x == 0) {
+        s_code = 0; s_op = -1; s_val = 0;
+        for (int i = 0; i < a.n_ops; ++i) {
+            const unsigned bits = a.slots[i];
+            if (bits == 0) continue;                          // op not measured / all-zero tensor
+            const float v = __uint_as_float(bits);
+            if (!(v <= a.hi)) { s_code = 1; s_op = i; s_val = bits; break; }
+            if (v < a.lo && s_code == 0) { s_code = 2; s_op = i; s_val = bits; }
+        }
+        if (s_code != 0 && a.status[0] == 0) { a.status[1] = s_op; a.status[2] = (int)s_val; a.status[3] = a.prog_slot; a.status[0] = s_code; }
+    }
+    __syncthreads();
+    if (s_code == 0) return;
+    const float nan = __builtin_nanf("");
+    for (long long i = threadIdx.x; i < a.n0; i += 256) a.poison0[i] = nan;
+    for (long long i = threadIdx.x; i < a.n1; i += 256) a.poison1[i] = nan;
+    for (long long i = threadIdx.x; i < a.n2; i += 256) a.poison2[i] = nan;
+}

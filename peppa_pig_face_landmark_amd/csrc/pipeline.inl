@@ -180,11 +180,13 @@ int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, 
     const unsigned char* d_frames = nullptr;
     if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
     const LetterboxGeom g = letterbox_geom(height, width, det.hdr.in_h, det.hdr.in_w);
+    begin_call(h);
     if (run_detector_stage(h, d_frames, 1, height, width, row_stride, g)) return 1;
     if (run_nms_stage(h, (const float*)det.buf_ptr(det.hdr.out_buf0), rows, 1, g, score_thres, iou_thres, 0.f, 1, false)) return 1;
     int n = 0;
     PF_HIP(h, hipMemcpyAsync(&n, h->pipe.d_keep_count, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (check_numerics(h)) return 1;
     n = std::min(n, max_n);
     if (n > 0) PF_HIP(h, hipMemcpy(boxes, h->pipe.d_keep_rows, (size_t)n * 16 * sizeof(float), hipMemcpyDeviceToHost));
     *n_out = n;
@@ -203,6 +205,7 @@ int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     const unsigned char* d_frames = nullptr;
     if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
     PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    begin_call(h);
     if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n)) return 1;
     std::vector<int> params((size_t)n * 8);
     std::vector<float> hk((size_t)n * kNumPoints * 2), hs((size_t)n * kNumPoints);
@@ -210,6 +213,7 @@ int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     PF_HIP(h, hipMemcpyAsync(hk.data(), h->pipe.d_kps, hk.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipMemcpyAsync(hs.data(), lm.buf_ptr(lm.hdr.out_buf1), hs.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (check_numerics(h)) return 1;
     for (int i = 0; i < n; ++i) {
         const int ok = params[(size_t)i * 8];
         if (valid) valid[i] = ok;
@@ -276,11 +280,18 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     if (!h) return 1;
     if (out_mem != PF_MEM_HOST && out_mem != PF_MEM_DEVICE && out_mem != PF_MEM_HOST_PINNED) PF_FAIL(h, "pf_run_frames: bad out_mem %d", out_mem);
     // results into page-locked host memory are plain asynchronous copies on the stream: they capture into the graph too
-    const bool graphable = h->use_graphs && !h->profiling && mem == PF_MEM_DEVICE && (out_mem == PF_MEM_DEVICE || out_mem == PF_MEM_HOST_PINNED);
+    begin_call(h);
+    // a range-checked call (every PF_OPT_RANGE_CHECK-th, and the first after a program load) runs eagerly: the
+    // measurement kernels are not part of the captured graphs
+    const bool graphable = h->use_graphs && !h->profiling && !h->check_now && mem == PF_MEM_DEVICE &&
+                           (out_mem == PF_MEM_DEVICE || out_mem == PF_MEM_HOST_PINNED);
     if (!graphable) {
         if (enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
                                top_k, counts, boxes, kps, scores, out_mem)) return 1;
-        if (out_mem == PF_MEM_HOST) PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (out_mem == PF_MEM_HOST) {
+            PF_HIP(h, hipStreamSynchronize(h->stream));
+            return check_numerics(h);
+        }
         return 0;
     }
     GraphKey key{};
@@ -346,6 +357,12 @@ int pf_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? 0 : 1;
 int pf_set_option(pf_handle* h, int option, int value) {
     if (!h) return 1;
     if (option == PF_OPT_HIP_GRAPH) { h->use_graphs = value != 0; return 0; }
+    if (option == PF_OPT_RANGE_CHECK) {
+        if (value < 0) PF_FAIL(h, "PF_OPT_RANGE_CHECK: period must be >= 0");
+        h->range_every = value;
+        h->check_pending = value > 0;
+        return 0;
+    }
     PF_FAIL(h, "unknown option %d", option);
 }
 

@@ -1,0 +1,98 @@
+"""f32s hardening (round-1 verdict): the split-precision convolutions write activations as f16 hi + f16 lo, so data-
+dependent activation ranges outside f16's reach must never produce silent inf / garbage.  The engine measures max |x| of
+every split op's input on checked calls (PF_OPT_RANGE_CHECK) and fails loudly; the Python facade then reloads the network
+with exact-f32 convolutions.  Weights are rescaled here so activations reach ~1e5 and ~1e-6."""
+import numpy as np
+import pytest
+
+from oracle import synth_weights as sw
+from peppa_pig_face_landmark_amd import _native
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from tests import helpers
+
+
+def _scaled(student_weights, factor):
+    """Scale one BatchNorm's output so that everything a split-precision conv reads grows / shrinks by `factor`:
+    factor > 1: decoder.aspp.project.1 (input of both DecoderBlocks; ReLU is positively homogeneous and the downstream
+    BatchNorms keep their fixed statistics); factor < 1: decoder.upsampler2.conv1.1, whose output is the ONLY input of the
+    hero conv (a tensor that mixes tiny and O(1) channels is not an underflow: the tiny part is below f32 resolution of
+    the sum either way)."""
+    w = dict(student_weights)
+    bn = "decoder.aspp.project.1" if factor > 1 else "decoder.upsampler2.conv1.1"
+    for k in ("weight", "bias"):
+        w[f"{bn}.{k}"] = (np.asarray(w[f"{bn}.{k}"], np.float64) * factor).astype(np.float32)
+    return w
+
+
+def _run_guard_cases(make_engine, student_weights, size):
+    crops = sw.smooth_blob_images(2, size, seed=606)
+    for factor, side in ((3.0e5, "above"), (1.0e-7, "below")):
+        w = _scaled(student_weights, factor)
+        eng = make_engine()
+        try:
+            blob, _ = build_student_program(w, size, "f32s")
+            eng.load_program(0, blob, 2)
+            with pytest.raises(_native.PeppaHipError, match="activation range check failed.*" + side):
+                eng.landmark_forward(crops)
+            # the exact-f32 program of the SAME weights is the remedy and matches the oracle
+            blob, _ = build_student_program(w, size, "f32")
+            eng.load_program(0, blob, 2)
+            loc, score = eng.landmark_forward(crops)
+            oloc, oscore, taps = helpers.oracle_student(w, crops)
+            margins = helpers.heat_margins(taps)
+            safe = margins > 2e-3 * max(1.0, float(np.abs(taps["hm"].numpy()).max()))
+            # the offsets scale with the activations and cancel (f32 noise either way), so the scaled runs are judged on
+            # the heat-map maxima: relative 1e-3
+            assert np.isfinite(loc).all() and np.isfinite(score).all()
+            if safe.any():
+                assert (np.abs(score - oscore) / np.abs(oscore))[safe].max() < 1e-3
+        finally:
+            eng.close()
+    # in-range weights: checked calls pass and change nothing
+    eng = make_engine()
+    try:
+        eng.set_option(_native.PF_OPT_RANGE_CHECK, 1)          # check EVERY call
+        blob, _ = build_student_program(student_weights, size, "f32s")
+        eng.load_program(0, blob, 2)
+        a = eng.landmark_forward(crops)
+        eng.set_option(_native.PF_OPT_RANGE_CHECK, 0)
+        b = eng.landmark_forward(crops)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.isfinite(a[0]).all()
+    finally:
+        eng.close()
+
+
+def test_range_guard_emulator(emu_library, student_weights):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _run_guard_cases(lambda: Engine(0, emu_library), student_weights, 64)
+
+
+@pytest.mark.gpu
+def test_range_guard_gpu(hip_library, student_weights):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _run_guard_cases(lambda: Engine(0, hip_library), student_weights, 256)
+
+
+def _facade_fallback(library, student_weights, size):
+    from peppa_pig_face_landmark_amd.core.api.hip_model_base import HIPEngine
+    w = _scaled(student_weights, 3.0e5)
+    m = HIPEngine(w, "keypoints", [size, size, 3], dtype="f32s", max_batch=2, library=library)
+    try:
+        crops = sw.smooth_blob_images(2, size, seed=607)
+        loc, score = m(crops)                       # range guard trips -> reload as f32 -> answer
+        assert m.dtype == "f32" and np.isfinite(loc).all()
+        oloc, oscore, taps = helpers.oracle_student(w, crops)
+        safe = helpers.heat_margins(taps) > 2e-3 * max(1.0, float(np.abs(taps["hm"].numpy()).max()))
+        if safe.any():
+            assert (np.abs(score - oscore) / np.abs(oscore))[safe].max() < 1e-3
+    finally:
+        m.engine.close()
+
+
+def test_facade_falls_back_to_f32_emulator(emu_library, student_weights):
+    _facade_fallback(emu_library, student_weights, 64)
+
+
+@pytest.mark.gpu
+def test_facade_falls_back_to_f32_gpu(hip_library, student_weights):
+    _facade_fallback(hip_library, student_weights, 256)
