@@ -23,9 +23,9 @@ def test_pin_tool_runs_and_reports_what_it_can(tmp_path):
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "pin_third_party.py")], capture_output=True, text=True, timeout=600)
-    have = [m for m in ("cv2", "timm", "onnxruntime") if __import__("importlib").util.find_spec(m) is not None]
-    if not have:
-        assert r.returncode == 2 and "nothing to pin" in r.stdout
+    # (availability is judged by the tool's own fresh interpreter: other tests install cv2 / timm STUBS in this process)
+    if "nothing to pin" in r.stdout:
+        assert r.returncode == 2 and r.stdout.count("skip ") >= 3
     else:
         assert r.returncode in (0, 1), r.stderr[-800:]
 
