@@ -87,6 +87,12 @@ int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, 
  * the reference rejects (w or h <= 20 px, face_landmark.py:76-77) -- those rows are left untouched. */
 int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                  const float* boxes, int n, float* kps, float* scores, int* valid);
+/* Same for float64 box rows.  On tracked video frames FaceAna hands FaceLandmark a float64 array (track_box comes out of
+ * the float64 EMA / One-Euro arithmetic, facer.py:66-81, lk.py:19-56), and then every step of preprocess
+ * (face_landmark.py:74-93: widths, `bbox += add`, `// 2`, the store-back, astype(int32)) is float64 arithmetic: rounding
+ * the boxes to float32 first can move a floor division across an integer and shift the crop by one pixel. */
+int pf_landmarks_f64(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                     const double* boxes, int n, float* kps, float* scores, int* valid);
 
 /* Batched FaceAna.run()+reset() (facer.py:52-85 without tracking, demo.py:83-86) over F frames
  * of identical size resident in `frames` ([F][H][W][3] BGR): detect -> NMS -> drop area <=
@@ -122,6 +128,8 @@ int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, f
                 float score_thres, float iou_thres, float* kept, int max_n, int* n_out);
 int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                   const float* boxes, int n, int out_size, uint8_t* crops_host, int* params_host);
+int pf_crop_faces_f64(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                      const double* boxes, int n, int out_size, uint8_t* crops_host, int* params_host);   /* float64 rows, see pf_landmarks_f64 */
 
 /* Video mode (FaceAna.run on a stream, facer.py:52-85): upload the frame ONCE, keep it resident for the
  * following pf_detect / pf_landmarks calls (pass mem = PF_MEM_RESIDENT), and evaluate the frame-difference

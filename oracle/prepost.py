@@ -234,6 +234,8 @@ def landmark_crop_box(bbox_xyxy: Sequence[float], frame_h: int, frame_w: int,
     ``bbox`` is a float32 row; width/height are float32; ``(1+2*extend)*width`` and every
     ``// 2`` promote to float64; results are stored back into the float32 row and truncated
     by ``astype(int32)``."""
+    if np.asarray(bbox_xyxy).dtype == np.float64:
+        return _landmark_crop_box_f64(np.asarray(bbox_xyxy, np.float64)[:4].copy(), frame_h, frame_w, min_face, extend)
     b = np.asarray(bbox_xyxy, np.float32)[:4].copy()
     ci = CropInfo()
     w = np.float32(b[2] - b[0])
@@ -261,6 +263,31 @@ def landmark_crop_box(bbox_xyxy: Sequence[float], frame_h: int, frame_w: int,
     ph, pw = frame_h + 2 * add, frame_w + 2 * add
     # numpy slice semantics of bimg[y0:y1, x0:x1]; negative starts (face far outside the frame)
     # wrap around in the reference (SURVEY App. D "quirks") -- here they clamp to 0 instead.
+    xs, xe = min(max(x0, 0), pw), min(max(x1, 0), pw)
+    ys, ye = min(max(y0, 0), ph), min(max(y1, 0), ph)
+    ci.add, ci.x0, ci.y0, ci.x1, ci.y1 = add, x0, y0, x1, y1
+    ci.w_crop, ci.h_crop = max(xe - xs, 0), max(ye - ys, 0)
+    if ci.w_crop == 0 or ci.h_crop == 0:
+        ci.valid = False
+    return ci
+
+
+def _landmark_crop_box_f64(b: np.ndarray, frame_h: int, frame_w: int, min_face: float, extend: float) -> CropInfo:
+    """face_landmark.py:74-93 for a float64 row (tracked frames: FaceAna.track_box is float64): every operation is
+    float64 under numpy 1.23 and numpy 2 alike -- no float32 store-back between the steps."""
+    ci = CropInfo()
+    w, h = b[2] - b[0], b[3] - b[1]
+    ci.valid = not (w <= min_face or h <= min_face)
+    ci.add = ci.x0 = ci.y0 = ci.x1 = ci.y1 = ci.w_crop = ci.h_crop = 0
+    if not ci.valid:
+        return ci
+    add = int(max(w, h))
+    b = b + add
+    face_width = (1 + 2 * extend) * w
+    cx, cy = (b[0] + b[2]) // 2, (b[1] + b[3]) // 2
+    box = np.array([cx - face_width // 2, cy - face_width // 2, cx + face_width // 2, cy + face_width // 2], np.float64)
+    x0, y0, x1, y1 = (int(v) for v in box.astype(np.int32))
+    ph, pw = frame_h + 2 * add, frame_w + 2 * add
     xs, xe = min(max(x0, 0), pw), min(max(x1, 0), pw)
     ys, ye = min(max(y0, 0), ph), min(max(y1, 0), ph)
     ci.add, ci.x0, ci.y0, ci.x1, ci.y1 = add, x0, y0, x1, y1

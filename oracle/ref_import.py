@@ -164,6 +164,7 @@ def _install_cv2_stub():
             return pp.pad_constant(img, top, bottom, left, right, v)
 
         cv2.copyMakeBorder = copyMakeBorder
+        cv2.absdiff = lambda a, b: np.abs(a.astype(np.int16) - b.astype(np.int16)).astype(np.uint8)
         sys.modules["cv2"] = cv2
     if "onnxruntime" not in sys.modules:
         sys.modules["onnxruntime"] = types.ModuleType("onnxruntime")
@@ -198,3 +199,27 @@ def reference_landmark_stage(input_shape=(256, 256, 3)):
     l = FaceLandmark.__new__(FaceLandmark)
     l.min_face, l.keypoints_num, l.input_size, l.extend = 20, 98, list(input_shape), [0.2, 0.3]
     return l
+
+
+def reference_faceana(detector_model, landmark_model, top_k=5, min_face=1600, det_input=(384, 640, 3), kps_input=(256, 256, 3)):
+    """The reference's own ``FaceAna`` (Skps/core/api/facer.py:25-208) with its own FaceDetector / FaceLandmark /
+    GroupTrack / EmaFilter classes, executed from source; only the two ``ONNXEngine`` sessions are replaced by the given
+    callables (``detector_model(x[1,3,H,W]) -> [rows]``, ``landmark_model(x[1,3,S,S]) -> (landmark[1,196], score[1,98])``)
+    and cv2 by the oracle's restatement.  This is how the frame-to-frame logic -- diff gate, judge_boxs, sort_and_filter,
+    One-Euro smoothing, float64 track boxes -- is pinned."""
+    FaceDetector, FaceLandmark = load_reference_stages()
+    import logging
+    level = logging.getLogger().level
+    from core.api.facer import FaceAna
+    from core.smoother.lk import EmaFilter, GroupTrack
+    logging.getLogger().setLevel(level)
+    fa = FaceAna.__new__(FaceAna)
+    fa.face_detector = reference_detector_stage(det_input)
+    fa.face_detector.model = detector_model
+    fa.face_landmark = reference_landmark_stage(kps_input)
+    fa.face_landmark.model = landmark_model
+    fa.trace = GroupTrack({"pixel_thres": 3, "smooth_box": 0.3, "iou_thres": 0.5})
+    fa.track_box = fa.previous_image = fa.previous_box = None
+    fa.diff_thres, fa.top_k, fa.min_face, fa.iou_thres, fa.alpha = 5, top_k, min_face, 0.5, 0.3
+    fa.filter = EmaFilter(fa.alpha)
+    return fa

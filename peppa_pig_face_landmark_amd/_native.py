@@ -46,6 +46,10 @@ def _declare(lib):
     lib.pf_read_tensor.argtypes = [vp, i, i, i, fp, sz]
     lib.pf_detect.argtypes = [vp, vp, i, i, i, i, f, f, fp, i, ip]
     lib.pf_landmarks.argtypes = [vp, vp, i, i, i, i, fp, i, fp, fp, ip]
+    lib.pf_landmarks_f64.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_double), i, fp, fp, ip]
+    lib.pf_landmarks_f64.restype = i
+    lib.pf_crop_faces_f64.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_double), i, i, vp, ip]
+    lib.pf_crop_faces_f64.restype = i
     lib.pf_run_frames.argtypes = [vp, vp, i, i, i, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_run_frames_planted.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_letterbox.argtypes = [vp, vp, i, i, i, i, i, i, vp, fp]
@@ -291,14 +295,18 @@ class Engine:
     def landmarks(self, image_bgr, boxes: np.ndarray):
         """image_bgr: HxWx3 uint8, or None to use the frame stored by set_frame()."""
         ptr, mem, H, W, stride, _keep = self._frame_args(image_bgr)
-        b = np.ascontiguousarray(np.asarray(boxes, np.float32)[:, :4])
+        boxes = np.asarray(boxes)
+        # float64 rows (tracked frames of FaceAna) keep their precision: the reference's box arithmetic is float64 then
+        f64 = boxes.dtype == np.float64
+        b = np.ascontiguousarray(np.asarray(boxes, np.float64 if f64 else np.float32)[:, :4])
         n = b.shape[0]
         kps = np.zeros((n, 98, 2), np.float32)
         scores = np.zeros((n, 98), np.float32)
         valid = np.zeros((n,), np.int32)
         if n:
-            self._check(self.lib.pf_landmarks(self.h, ptr, mem, H, W,
-                                              stride, b.ctypes.data_as(C.POINTER(C.c_float)), n,
+            fn = self.lib.pf_landmarks_f64 if f64 else self.lib.pf_landmarks
+            self._check(fn(self.h, ptr, mem, H, W,
+                                              stride, b.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float)), n,
                                               kps.ctypes.data_as(C.POINTER(C.c_float)),
                                               scores.ctypes.data_as(C.POINTER(C.c_float)),
                                               valid.ctypes.data_as(C.POINTER(C.c_int))), "pf_landmarks")
@@ -361,12 +369,14 @@ class Engine:
     def crop_faces(self, image_bgr: np.ndarray, boxes: np.ndarray, out_size: int = 256):
         """FaceLandmark.preprocess: -> (crops uint8 [n,S,S,3], params int32 [n,8])."""
         img = np.ascontiguousarray(image_bgr)
-        b = np.ascontiguousarray(np.asarray(boxes, np.float32)[:, :4])
+        f64 = np.asarray(boxes).dtype == np.float64
+        b = np.ascontiguousarray(np.asarray(boxes, np.float64 if f64 else np.float32)[:, :4])
         n = b.shape[0]
         crops = np.zeros((n, out_size, out_size, 3), np.uint8)
         params = np.zeros((n, 8), np.int32)
-        self._check(self.lib.pf_crop_faces(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
-                                           b.ctypes.data_as(C.POINTER(C.c_float)), n, out_size, _ptr(crops),
+        fn = self.lib.pf_crop_faces_f64 if f64 else self.lib.pf_crop_faces
+        self._check(fn(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                           b.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float)), n, out_size, _ptr(crops),
                                            params.ctypes.data_as(C.POINTER(C.c_int))), "pf_crop_faces")
         return crops, params
 

@@ -31,7 +31,10 @@ class FaceLandmark:
 
     def __call__(self, img, bboxes):
         """img: BGR uint8 frame, or None for the frame made resident by Engine.set_frame()."""
-        bboxes = np.asarray(bboxes, np.float32).reshape(-1, np.asarray(bboxes).shape[-1] if len(bboxes) else 4)
+        bboxes = np.asarray(bboxes)
+        if bboxes.dtype != np.float64:       # float64 rows (tracked frames) are passed through as they are
+            bboxes = bboxes.astype(np.float32)
+        bboxes = bboxes.reshape(-1, bboxes.shape[-1] if len(bboxes) else 4)
         if bboxes.shape[0] == 0:
             return np.array([]), np.array([])
         t0 = time.time()

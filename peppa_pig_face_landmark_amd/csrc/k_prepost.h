@@ -34,6 +34,7 @@ struct PipelineScratch {
     float* d_keep_rows = nullptr;    // [F][max_keep][16]
     int* d_keep_count = nullptr;     // [F]
     float* d_sel_boxes = nullptr;    // [F][top_k][4]
+    double* d_boxes64 = nullptr; size_t boxes64_bytes = 0;   // float64 boxes of pf_landmarks_f64
     int* d_sel_count = nullptr;      // [F]
     int* d_crop_params = nullptr;    // [faces][8]
     float* d_cropf = nullptr;        // [faces][5]
@@ -42,7 +43,7 @@ struct PipelineScratch {
     unsigned char* d_nms_flags = nullptr;      // [F][cap]
     int cap_frames = 0, cap_faces = 0, cap_keep = 0, cap_topk = 0, cap_rows = 0;
     void release() {
-        void* ptrs[] = {d_cur, d_prev, d_diff_sum, d_frames, d_letterbox, d_crops, d_rows_planted, d_keep_rows, d_keep_count,
+        void* ptrs[] = {d_cur, d_prev, d_diff_sum, d_frames, d_letterbox, d_crops, d_rows_planted, d_boxes64, d_keep_rows, d_keep_count,
                         d_sel_boxes, d_sel_count, d_crop_params, d_cropf, d_kps, d_nms_keys, d_nms_flags};
         for (void* p : ptrs) if (p) (void)hipFree(p);
         *this = PipelineScratch();
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(1024) void nms_kernel(NmsArgs a) {
 // --------------------------------------------------------------------------------------------
 struct CropParamArgs {
     const float* boxes;   // [n][4] xyxy float32 (frame coordinates)
+    const double* boxes64;  // or [n][4] float64 rows (tracked frames: FaceAna.track_box is float64, facer.py:75-81) -- then
+                            // every step of face_landmark.py:74-93 is float64 arithmetic, no float32 store-back rounding
     const int* counts;    // optional [F]: faces actually present per frame (slots beyond are invalid)
     int* params;          // [n][8] = valid, add, x0, y0, xs, ys, w_crop, h_crop
     float* cropf;         // [n][5] = w_crop, h_crop, x0, y0, add  (face_landmark.py:104 "detail")
@@ -302,6 +305,25 @@ __global__ __launch_bounds__(64) void crop_params_kernel(CropParamArgs a) {
     for (int k = 0; k < 8; ++k) p[k] = 0;
     for (int k = 0; k < 5; ++k) cf[k] = 0.f;
     if (a.counts && (i % a.per_frame) >= a.counts[i / a.per_frame]) return;
+    if (a.boxes64) {
+        const double* b = a.boxes64 + (size_t)i * 4;
+        const double w = b[2] - b[0], h = b[3] - b[1];
+        if (w <= (double)a.min_face || h <= (double)a.min_face || !(w == w) || !(h == h)) return;
+        const int add = (int)fmax(w, h);
+        const double da = (double)add;
+        const double b0 = b[0] + da, b1 = b[1] + da, b2 = b[2] + da, b3 = b[3] + da;
+        const double cx = floor((b0 + b2) / 2.0), cy = floor((b1 + b3) / 2.0);
+        const double half = floor(a.width_factor * w / 2.0);
+        const int x0 = (int)(cx - half), y0 = (int)(cy - half), x1 = (int)(cx + half), y1 = (int)(cy + half);
+        const int ph = a.H + 2 * add, pw = a.W + 2 * add;
+        const int xs = min(max(x0, 0), pw), xe = min(max(x1, 0), pw);
+        const int ys = min(max(y0, 0), ph), ye = min(max(y1, 0), ph);
+        const int wc = xe - xs, hc = ye - ys;
+        if (wc <= 0 || hc <= 0) return;
+        p[0] = 1; p[1] = add; p[2] = x0; p[3] = y0; p[4] = xs; p[5] = ys; p[6] = wc; p[7] = hc;
+        cf[0] = (float)wc; cf[1] = (float)hc; cf[2] = (float)x0; cf[3] = (float)y0; cf[4] = (float)add;
+        return;
+    }
     const float* b = a.boxes + (size_t)i * 4;
     const float w = __fsub_rn(b[2], b[0]), h = __fsub_rn(b[3], b[1]);
     if (w <= a.min_face || h <= a.min_face || !(w == w) || !(h == h)) return;

@@ -127,11 +127,11 @@ int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const Lett
 
 // crop boxes -> uint8 crops (FaceLandmark.preprocess)
 int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
-                   const float* d_boxes, const int* d_counts, int faces, int per_frame, int S) {
+                   const float* d_boxes, const int* d_counts, int faces, int per_frame, int S, const double* d_boxes64 = nullptr) {
     PipelineScratch& s = h->pipe;
     if (ensure_dev(h, s.d_crops, s.crops_bytes, (size_t)faces * S * S * 3)) return 1;
     CropParamArgs ca{};
-    ca.boxes = d_boxes; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
+    ca.boxes = d_boxes; ca.boxes64 = d_boxes64; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
     ca.n = faces; ca.per_frame = per_frame; ca.H = H; ca.W = W;
     ca.min_face = 20.f;                  // FaceLandmark.min_face, face_landmark.py:26
     ca.width_factor = 1 + 2 * 0.2;       // (1 + 2*extend[0]) with extend = [0.2, 0.3], Skps.yml:14
@@ -151,11 +151,11 @@ int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, in
 
 // crops -> landmark program (with back-projection to frame coordinates)
 int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
-                       const float* d_boxes, const int* d_counts, int faces, int per_frame) {
+                       const float* d_boxes, const int* d_counts, int faces, int per_frame, const double* d_boxes64 = nullptr) {
     Program& lm = h->prog[PF_NET_LANDMARK];
     PipelineScratch& s = h->pipe;
     if (faces > lm.max_batch) PF_FAIL(h, "%d faces exceed the landmark program's max_batch %d", faces, lm.max_batch);
-    if (run_crop_stage(h, d_frames, H, W, row_stride, d_boxes, d_counts, faces, per_frame, lm.hdr.in_h)) return 1;
+    if (run_crop_stage(h, d_frames, H, W, row_stride, d_boxes, d_counts, faces, per_frame, lm.hdr.in_h, d_boxes64)) return 1;
     s.d_crop_for_decode = s.d_cropf;
     s.d_kps_for_decode = s.d_kps;
     const int rc = run_program(h, PF_NET_LANDMARK, s.d_crops, PF_INPUT_U8_NHWC, faces);
@@ -193,8 +193,23 @@ int pf_detect(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, 
     return 0;
 }
 
+static int landmarks_impl(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                          const float* boxes, const double* boxes64, int n, float* kps, float* scores, int* valid);
+
 int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                  const float* boxes, int n, float* kps, float* scores, int* valid) {
+    if (n > 0 && !boxes) { if (h) h->err = "pf_landmarks: boxes is NULL"; return 1; }
+    return landmarks_impl(h, bgr, mem, height, width, row_stride, boxes, nullptr, n, kps, scores, valid);
+}
+
+int pf_landmarks_f64(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                     const double* boxes, int n, float* kps, float* scores, int* valid) {
+    if (n > 0 && !boxes) { if (h) h->err = "pf_landmarks_f64: boxes is NULL"; return 1; }
+    return landmarks_impl(h, bgr, mem, height, width, row_stride, nullptr, boxes, n, kps, scores, valid);
+}
+
+static int landmarks_impl(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                          const float* boxes, const double* boxes64, int n, float* kps, float* scores, int* valid) {
     if (!h) return 1;
     Program& lm = h->prog[PF_NET_LANDMARK];
     if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
@@ -204,9 +219,16 @@ int pf_landmarks(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     if (ensure_pipeline(h, 1, n, n, 2)) return 1;
     const unsigned char* d_frames = nullptr;
     if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
-    PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    const double* d_b64 = nullptr;
+    if (boxes64) {
+        if (ensure_dev(h, h->pipe.d_boxes64, h->pipe.boxes64_bytes, (size_t)n * 4 * sizeof(double))) return 1;
+        PF_HIP(h, hipMemcpyAsync(h->pipe.d_boxes64, boxes64, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_b64 = h->pipe.d_boxes64;
+    } else {
+        PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
     begin_call(h);
-    if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n)) return 1;
+    if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n, d_b64)) return 1;
     std::vector<int> params((size_t)n * 8);
     std::vector<float> hk((size_t)n * kNumPoints * 2), hs((size_t)n * kNumPoints);
     PF_HIP(h, hipMemcpyAsync(params.data(), h->pipe.d_crop_params, params.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -448,16 +470,38 @@ int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, f
     return 0;
 }
 
+static int crop_faces_impl(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                           const float* boxes, const double* boxes64, int n, int out_size, uint8_t* crops_host, int* params_host);
+
 int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                   const float* boxes, int n, int out_size, uint8_t* crops_host, int* params_host) {
+    if (!boxes) { if (h) h->err = "pf_crop_faces: boxes is NULL"; return 1; }
+    return crop_faces_impl(h, bgr, mem, height, width, row_stride, boxes, nullptr, n, out_size, crops_host, params_host);
+}
+
+int pf_crop_faces_f64(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                      const double* boxes, int n, int out_size, uint8_t* crops_host, int* params_host) {
+    if (!boxes) { if (h) h->err = "pf_crop_faces_f64: boxes is NULL"; return 1; }
+    return crop_faces_impl(h, bgr, mem, height, width, row_stride, nullptr, boxes, n, out_size, crops_host, params_host);
+}
+
+static int crop_faces_impl(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                           const float* boxes, const double* boxes64, int n, int out_size, uint8_t* crops_host, int* params_host) {
     if (!h) return 1;
-    if (!bgr || !boxes || n < 1 || out_size < 1 || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_crop_faces: bad arguments");
+    if (!bgr || n < 1 || out_size < 1 || height < 1 || width < 1 || row_stride < width * 3) PF_FAIL(h, "pf_crop_faces: bad arguments");
     PF_HIP(h, hipSetDevice(h->device));
     if (ensure_pipeline(h, 1, n, n, 2)) return 1;
     const unsigned char* d_frames = nullptr;
     if (stage_frames(h, bgr, mem, (size_t)height * row_stride, &d_frames)) return 1;
-    PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    if (run_crop_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n, out_size)) return 1;
+    const double* d_b64 = nullptr;
+    if (boxes64) {
+        if (ensure_dev(h, h->pipe.d_boxes64, h->pipe.boxes64_bytes, (size_t)n * 4 * sizeof(double))) return 1;
+        PF_HIP(h, hipMemcpyAsync(h->pipe.d_boxes64, boxes64, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        d_b64 = h->pipe.d_boxes64;
+    } else {
+        PF_HIP(h, hipMemcpyAsync(h->pipe.d_sel_boxes, boxes, (size_t)n * 4 * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    }
+    if (run_crop_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, nullptr, n, n, out_size, d_b64)) return 1;
     if (crops_host) PF_HIP(h, hipMemcpyAsync(crops_host, h->pipe.d_crops, (size_t)n * out_size * out_size * 3, hipMemcpyDeviceToHost, h->stream));
     if (params_host) PF_HIP(h, hipMemcpyAsync(params_host, h->pipe.d_crop_params, (size_t)n * 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));

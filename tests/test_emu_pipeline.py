@@ -190,3 +190,39 @@ def test_pinned_host_buffer_roundtrip(emu_engine):
     b = emu_engine.pinned_empty((16,), np.float32)
     b[:] = 1.5
     assert float(b.sum()) == 24.0
+
+
+def _f64_boxes(n=300, seed=9):
+    """float64 box rows as FaceAna.track_box holds them on tracked frames, including rows whose float32 rounding crosses
+    a floor-division boundary (the case ADVICE r1 pointed at: the crop would shift by one pixel)."""
+    rng = np.random.default_rng(seed)
+    x1, y1 = rng.uniform(0, 380, n), rng.uniform(0, 180, n)
+    bw, bh = rng.uniform(15, 220, n), rng.uniform(15, 220, n)
+    b = np.stack([x1, y1, x1 + bw, y1 + bh], 1)
+    # (x1 + x2 + 2 add) just below an even integer: float32 rounding of the row pushes it over
+    k = np.arange(0, n, 7)
+    b[k, 0] = np.floor(b[k, 0])
+    b[k, 2] = np.floor(b[k, 2]) + 1.0 - 1e-9
+    return b
+
+
+def check_crop_faces_f64(eng):
+    frame, _ = make_frame(270, 480, 2, seed=6)
+    boxes = _f64_boxes()
+    S = 64
+    crops, params = eng.crop_faces(frame, boxes, S)
+    differs_from_f32 = 0
+    for i, b in enumerate(boxes):
+        ci = pp.landmark_crop_box(b, 270, 480)                          # float64 row -> float64 arithmetic
+        assert bool(params[i, 0]) == ci.valid, i
+        if not ci.valid or ci.x0 < 0 or ci.y0 < 0:
+            continue
+        assert (params[i, 1], params[i, 2], params[i, 3], params[i, 6], params[i, 7]) == (ci.add, ci.x0, ci.y0, ci.w_crop, ci.h_crop), i
+        assert np.array_equal(crops[i], pp.landmark_crop(frame, ci, (S, S))), i
+        c32 = pp.landmark_crop_box(b.astype(np.float32), 270, 480)
+        differs_from_f32 += (c32.x0, c32.y0, c32.w_crop, c32.add) != (ci.x0, ci.y0, ci.w_crop, ci.add)
+    assert differs_from_f32 > 0, "the test boxes never distinguish float64 from float32 box arithmetic"
+
+
+def test_crop_faces_float64_rows_bit_exact(emu_engine):
+    check_crop_faces_f64(emu_engine)

@@ -293,3 +293,9 @@ def test_c5_teacher_4k_32_faces(gpu_engine):
         worst = max(worst, float(np.abs(kps[0, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)))
     print("C5 Teacher 4K x 32: worst normalised landmark error %.2e" % worst)
     assert worst < 1e-3
+
+
+def test_crop_faces_float64_rows_bit_exact_gpu(gpu_engine):
+    """Tracked frames hand FaceLandmark float64 boxes (facer.py:66-81): pf_crop_faces_f64 / pf_landmarks_f64."""
+    from tests.test_emu_pipeline import check_crop_faces_f64
+    check_crop_faces_f64(gpu_engine)

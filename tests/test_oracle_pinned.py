@@ -117,3 +117,25 @@ def test_oracle_equals_reference_live(student_weights):
     kept = det.py_nms(r, 0.3, 0.5)
     kept[:, :4] = det.scale_coords(kept[:, :4], [0.5, 3, 7])
     assert np.array_equal(kept, pp.detector_postprocess(rows, [0.5, 3, 7], 0.3, 0.5))
+
+
+@pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
+def test_float64_box_rows_equal_reference_live():
+    """FaceLandmark.preprocess on float64 rows (tracked frames), executed from the reference source, against the oracle's
+    float64 path -- including rows whose float32 rounding would move the crop."""
+    from peppa_pig_face_landmark_amd.synth import make_frame
+    from tests.test_emu_pipeline import _f64_boxes
+    lm = ri.reference_landmark_stage()
+    frame, _ = make_frame(270, 480, 2, seed=1)
+    n = 0
+    for b in _f64_boxes(200, seed=21):
+        ci = pp.landmark_crop_box(b, 270, 480)
+        if ci.valid and (ci.x0 < 0 or ci.y0 < 0):
+            continue                         # negative slice starts wrap around in the reference (documented deviation)
+        crop, detail = lm.preprocess(frame, b.copy(), 0)
+        if crop is None:
+            assert not ci.valid
+            continue
+        assert (detail[0], detail[1], int(detail[2]), int(detail[3]), detail[4]) == (ci.h_crop, ci.w_crop, ci.y0, ci.x0, ci.add)
+        n += 1
+    assert n > 100
