@@ -163,10 +163,13 @@ def greedy_nms(rows: np.ndarray, iou_thres: float, score_thres: float) -> np.nda
     return rows[idx]
 
 
-def greedy_nms_indices(rows: np.ndarray, iou_thres: float, score_thres: float) -> np.ndarray:
+def greedy_nms_indices(rows: np.ndarray, iou_thres: float, score_thres: float, ties_by_row: bool = False) -> np.ndarray:
+    """``ties_by_row``: equal scores are visited in ascending row order (the engine's rule).  The reference's
+    ``np.argsort(...)[::-1]`` (face_detector.py:106) leaves the order of equal scores to the sort implementation, so with
+    ties present only this variant is a well-defined checker."""
     cand = np.nonzero(rows[:, 4] > score_thres)[0]
     sub = rows[cand]
-    order = np.argsort(sub[:, 4])[::-1]
+    order = np.argsort(-sub[:, 4], kind="stable") if ties_by_row else np.argsort(sub[:, 4])[::-1]
     x1, y1, x2, y2 = sub[:, 0], sub[:, 1], sub[:, 2], sub[:, 3]
     kept: List[int] = []
     with np.errstate(invalid="ignore", divide="ignore"):
@@ -196,11 +199,11 @@ def unletterbox(boxes_xyxy: np.ndarray, info) -> np.ndarray:
     return b
 
 
-def detector_postprocess(raw: np.ndarray, info, iou_thres=0.3, score_thres=0.5) -> np.ndarray:
+def detector_postprocess(raw: np.ndarray, info, iou_thres=0.3, score_thres=0.5, ties_by_row: bool = False) -> np.ndarray:
     """face_detector.py:31-37 on the raw network output (15120,16)."""
     out = np.array(raw, np.float32).reshape(-1, 16).copy()
     out[:, :4] = xywh_to_xyxy(out[:, :4])
-    kept = greedy_nms(out, iou_thres, score_thres)
+    kept = out[greedy_nms_indices(out, iou_thres, score_thres, ties_by_row)]
     kept[:, :4] = unletterbox(kept[:, :4], info)
     return kept
 

@@ -74,7 +74,7 @@ struct pf_handle {
     int expdw_variant = 0;   // PEPPA_EXPDW=wide: fused expand+depthwise kernels with 256 VGPRs (one workgroup per CU, no spills)
     // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
     // after a program load, measures max |x| of the input of every split-precision op
-    int range_every = 32;
+    int range_every = 256;
     unsigned long long n_calls = 0;
     bool check_pending = true, check_now = false;
     unsigned* d_range = nullptr; size_t range_cap = 0;

@@ -126,9 +126,11 @@ def test_detect_on_the_detectors_own_rows_matches_py_nms(gpu_engine, detector_we
     rows = gpu_engine.detector_forward(lb[None], 15120)[0]
     cand = rows[rows[:, 4] > 0.5, 4]
     assert cand.size > 50, cand.size
-    if np.unique(cand).size != cand.size:
-        pytest.skip("candidate scores still tie (%d of %d distinct)" % (np.unique(cand).size, cand.size))
-    ref = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5)
+    ties = cand.size - np.unique(cand).size
+    # a handful of the ~6 k float32 scores still collide; equal scores are visited in row order by the engine, an order
+    # the reference's argsort leaves unspecified, so the checker uses the same rule for them
+    assert ties < 0.01 * cand.size, (ties, cand.size)
+    ref = pp.detector_postprocess(rows, [np.float32(info[0]), info[1], info[2]], 0.3, 0.5, ties_by_row=True)
     n = min(ref.shape[0], 1024)
     assert got.shape[0] == n and n > 0
     assert np.array_equal(got[:n], ref[:n])

@@ -45,7 +45,7 @@ def _run_guard_cases(make_engine, student_weights, size):
             # the heat-map maxima: relative 1e-3
             assert np.isfinite(loc).all() and np.isfinite(score).all()
             if safe.any():
-                assert (np.abs(score - oscore) / np.abs(oscore))[safe].max() < 1e-3
+                assert np.abs(score - oscore)[safe].max() < 1e-3 * float(np.abs(taps["hm"].numpy()[:, :98]).max())
         finally:
             eng.close()
     # in-range weights: checked calls pass and change nothing
@@ -84,7 +84,7 @@ def _facade_fallback(library, student_weights, size):
         oloc, oscore, taps = helpers.oracle_student(w, crops)
         safe = helpers.heat_margins(taps) > 2e-3 * max(1.0, float(np.abs(taps["hm"].numpy()).max()))
         if safe.any():
-            assert (np.abs(score - oscore) / np.abs(oscore))[safe].max() < 1e-3
+            assert np.abs(score - oscore)[safe].max() < 1e-3 * float(np.abs(taps["hm"].numpy()[:, :98]).max())
     finally:
         m.engine.close()
 
