@@ -23,6 +23,7 @@ __device__ __forceinline__ pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32
 }
 __device__ __forceinline__ float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ int pf_shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 // Orders LDS traffic between the lanes of ONE wave (producer lanes write, other lanes read) without a
 // workgroup barrier: the wave issues its LDS instructions in order, so only the compiler has to be fenced.

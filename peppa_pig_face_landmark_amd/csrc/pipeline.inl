@@ -44,6 +44,7 @@ int ensure_pipeline(pf_handle* h, int frames, int faces, int top_k, int rows) {
         if (realloc_dev(h, s.d_keep_count, (size_t)F * sizeof(int))) return 1;
         if (realloc_dev(h, s.d_sel_boxes, (size_t)F * K * 4 * sizeof(float))) return 1;
         if (realloc_dev(h, s.d_sel_count, (size_t)F * sizeof(int))) return 1;
+        if (realloc_dev(h, s.d_cand_count, (size_t)F * sizeof(int))) return 1;
         if (realloc_dev(h, s.d_nms_keys, (size_t)F * cap * sizeof(unsigned long long))) return 1;
         if (realloc_dev(h, s.d_nms_flags, (size_t)F * cap)) return 1;
         s.cap_frames = F; s.cap_topk = K; s.cap_rows = R;
@@ -117,11 +118,13 @@ int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const Lett
     na.lb_scale = (float)g.scale; na.lb_left = (float)g.left; na.lb_top = (float)g.top;
     na.rows = d_rows; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
     na.sel_boxes = select ? s.d_sel_boxes : nullptr; na.sel_count = s.d_sel_count;
-    na.keys = s.d_nms_keys; na.flags = s.d_nms_flags;
+    na.keys = s.d_nms_keys; na.flags = s.d_nms_flags; na.cand_count = s.d_cand_count;
     na.R = rows; na.cap = next_pow2(std::max(s.cap_rows, 2)); na.max_keep = kMaxKeep; na.top_k = top_k;
     na.score_thres = score_thres; na.iou_thres = iou_thres; na.min_face = min_face;
     ProfScope ps(h, "nms");
-    PF_LAUNCH(nms_kernel, dim3(F), dim3(1024), h->stream, na);
+    PF_HIP(h, hipMemsetAsync(s.d_cand_count, 0, (size_t)F * sizeof(int), h->stream));
+    PF_LAUNCH(nms_compact_kernel, dim3(pf_div_up(rows, 1024), F), dim3(1024), h->stream, na);
+    PF_LAUNCH(nms_kernel, dim3(F), dim3(256), h->stream, na);
     return 0;
 }
 
@@ -144,7 +147,11 @@ int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, in
     ra.n = faces; ra.per_frame = per_frame; ra.H = H; ra.W = W; ra.row_stride = row_stride; ra.S = S;
     {
         ProfScope ps(h, "crop_resize");
-        PF_LAUNCH(crop_resize_kernel, dim3(pf_div_up(S * S, 256), faces), dim3(256), h->stream, ra);
+        // tiled kernel (source rows of 8 output rows through LDS, 32-bit global accesses) whenever an output row is a
+        // whole number of 32-bit words; it falls back to per-pixel loads per workgroup for faces too large for its LDS
+        const bool tiled = S <= 256 && (256 % S) == 0 && (S * 3) % 4 == 0;
+        if (tiled) PF_LAUNCH(crop_resize_kernel, dim3(pf_div_up(S, PF_CROP_TY), faces), dim3(256), h->stream, ra);
+        else PF_LAUNCH(crop_resize_direct_kernel, dim3(pf_div_up(S * S, 256), faces), dim3(256), h->stream, ra);
     }
     return 0;
 }

@@ -64,6 +64,7 @@ inline pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
 
 inline float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64); }
 inline int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
+inline int pf_shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
 inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 

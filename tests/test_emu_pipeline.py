@@ -226,3 +226,15 @@ def check_crop_faces_f64(eng):
 
 def test_crop_faces_float64_rows_bit_exact(emu_engine):
     check_crop_faces_f64(emu_engine)
+
+
+def test_crop_very_large_face_takes_the_per_pixel_path(emu_engine):
+    """A face whose source rows do not fit the tiled kernel's LDS budget (decided per workgroup on the device) and a
+    small one in the same call: both bit-exact."""
+    frame, _ = make_frame(540, 960, 1, seed=8)
+    boxes = np.array([[100.0, 40.0, 820.0, 500.0], [300.0, 200.0, 380.0, 290.0]], np.float32)
+    crops, params = emu_engine.crop_faces(frame, boxes, 64)
+    for i, b in enumerate(boxes):
+        ci = pp.landmark_crop_box(b, 540, 960)
+        assert ci.valid and bool(params[i, 0])
+        assert np.array_equal(crops[i], pp.landmark_crop(frame, ci, (64, 64))), i
