@@ -141,6 +141,27 @@ int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
                  unsigned long long* abs_diff_sum, int* has_prev);
 int pf_forget_frames(pf_handle* h);
 
+/* FaceAna.run(image) / reset() for ONE video stream with the tracking state on the device.  The
+ * reference keeps track_box, the previous landmark sets and their displacement on the host and walks the boxes through
+ * numpy between the two networks (judge_boxs facer.py:144-189, sort_and_filter :120-142, GroupTrack.calculate + the
+ * One-Euro filter core/smoother/lk.py:19-56,117-149, hull boxes facer.py:70-81).  Here all of it is device kernels over
+ * device state (float64, as the reference computes it under its pinned numpy): per frame the host reads back 8 bytes (the
+ * frame-difference sum that gates the detector, facer.py:98-118) and the results.  One handle = one stream; shard streams,
+ * never one stream, across handles / GPUs.  Outputs: *n_out faces (<= top_k); boxes [n][4] = the new track boxes, kps
+ * [n][98][2] = the smoothed landmarks (both float64), scores [n][98]; *detector_ran says whether the gate ran the detector.
+ * track_iou_thres / smooth_box = Skps.yml Trace.iou_thres / Trace.smooth_box, diff_thres = 5 in the reference. */
+int pf_track_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                   float score_thres, float nms_iou_thres, float min_face, int top_k,
+                   float track_iou_thres, float smooth_box, float diff_thres, int reserved,
+                   int* n_out, double* boxes, double* kps, float* scores, int* detector_ran);
+int pf_track_reset(pf_handle* h);
+/* Same with the decoded detector rows supplied by the caller whenever the gate runs the detector (planted-candidate
+ * protocol of pf_run_frames_planted: the network still runs, its output is replaced).  Test / benchmark instrument. */
+int pf_track_frame_planted(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
+                           const float* det_rows, int rows, float score_thres, float nms_iou_thres, float min_face, int top_k,
+                           float track_iou_thres, float smooth_box, float diff_thres,
+                           int* n_out, double* boxes, double* kps, float* scores, int* detector_ran);
+
 /* Frame ingest (replaces the pageable numpy arrays cv2.imread / VideoCapture.read hand to
  * FaceAna.run, demo.py:13-17,76): page-locked host memory for frame batches (decode straight into it) and for
  * results.  Frames passed with mem = PF_MEM_HOST from such a buffer are copied host->device asynchronously on the

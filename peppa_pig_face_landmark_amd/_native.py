@@ -50,6 +50,13 @@ def _declare(lib):
     lib.pf_landmarks_f64.restype = i
     lib.pf_crop_faces_f64.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_double), i, i, vp, ip]
     lib.pf_crop_faces_f64.restype = i
+    dp = C.POINTER(C.c_double)
+    lib.pf_track_frame.argtypes = [vp, vp, i, i, i, i, f, f, f, i, f, f, f, i, ip, dp, dp, fp, ip]
+    lib.pf_track_frame.restype = i
+    lib.pf_track_frame_planted.argtypes = [vp, vp, i, i, i, i, fp, i, f, f, f, i, f, f, f, ip, dp, dp, fp, ip]
+    lib.pf_track_frame_planted.restype = i
+    lib.pf_track_reset.argtypes = [vp]
+    lib.pf_track_reset.restype = i
     lib.pf_run_frames.argtypes = [vp, vp, i, i, i, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_run_frames_planted.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_letterbox.argtypes = [vp, vp, i, i, i, i, i, i, vp, fp]
@@ -379,6 +386,41 @@ class Engine:
                                            b.ctypes.data_as(C.POINTER(C.c_double if f64 else C.c_float)), n, out_size, _ptr(crops),
                                            params.ctypes.data_as(C.POINTER(C.c_int))), "pf_crop_faces")
         return crops, params
+
+    # ---- video stream with the tracking state on the device (pf_track_frame) -----------------------------------------
+    def track_frame(self, image_bgr: np.ndarray, score_thres: float, nms_iou_thres: float, min_face: float, top_k: int,
+                    track_iou_thres: float = 0.5, smooth_box: float = 0.3, diff_thres: float = 5.0,
+                    planted_rows: Optional[np.ndarray] = None):
+        """FaceAna.run(image) for this engine's stream: returns (track boxes float64 [n,4], smoothed landmarks float64
+        [n,98,2], scores float32 [n,98], detector_ran).  planted_rows (test instrument): decoded detector
+        rows [R,16] that replace the detector network's own output when the gate runs the detector."""
+        img = np.ascontiguousarray(image_bgr)
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        n = C.c_int(0)
+        ran = C.c_int(0)
+        boxes = np.zeros((top_k, 4), np.float64)
+        kps = np.zeros((top_k, 98, 2), np.float64)
+        scores = np.zeros((top_k, 98), np.float32)
+        outs = (C.byref(n), boxes.ctypes.data_as(C.POINTER(C.c_double)), kps.ctypes.data_as(C.POINTER(C.c_double)),
+                scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ran))
+        if planted_rows is None:
+            rc = self.lib.pf_track_frame(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                         float(score_thres), float(nms_iou_thres), float(min_face), int(top_k),
+                                         float(track_iou_thres), float(smooth_box), float(diff_thres), 0, *outs)
+        else:
+            pr = np.ascontiguousarray(planted_rows, np.float32)
+            rc = self.lib.pf_track_frame_planted(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                                 pr.ctypes.data_as(C.POINTER(C.c_float)), pr.shape[0],
+                                                 float(score_thres), float(nms_iou_thres), float(min_face), int(top_k),
+                                                 float(track_iou_thres), float(smooth_box), float(diff_thres), *outs)
+        self._check(rc, "pf_track_frame")
+        self._resident_shape = img.shape
+        k = n.value
+        return boxes[:k].copy(), kps[:k].copy(), scores[:k].copy(), bool(ran.value)
+
+    def track_reset(self):
+        self._check(self.lib.pf_track_reset(self.h), "pf_track_reset")
+        self._resident_shape = None
 
     def set_option(self, option: int, value: int):
         """PF_OPT_HIP_GRAPH (1): replay device-resident run_frames calls from a captured hipGraph."""

@@ -67,6 +67,11 @@ class FaceAna:
         det_w = weights.get("detector") or _load_weights(root, sk["Detect"]["model_path"], "detector")
         kps_w = weights.get("keypoints") or _load_weights(root, sk["Keypoints"]["model_path"], "keypoints")
 
+        # Engine.device_tracking: keep track_box / previous landmarks / One-Euro state on the GPU (pf_track_frame) instead of
+        # walking the boxes through numpy between the two networks on every frame
+        self.device_tracking = bool(eng_cfg.get("device_tracking", False))
+        self._planted_rows = None    # test instrument: callable returning decoded detector rows that replace the detector's own
+        self._det_cfg = sk["Detect"]
         self.top_k = sk["Detect"]["topk"]
         self.engine = _native.Engine(dev, library)      # one GPU, one stream, shared by both stages
         max_faces = max(int(eng_cfg.get("max_faces", 8)), int(self.top_k))
@@ -89,6 +94,14 @@ class FaceAna:
         # one host->device copy per frame: the frame stays resident for the gate, the detector and the
         # landmark stage; the frame-difference gate (facer.py:98-118) is evaluated on the GPU against the
         # previous resident frame (exact integer sum, same decision as the numpy code in diff_frames()).
+        if self.device_tracking:
+            boxes, kps, scores, _ = self.face_landmark.model.guarded(
+                self.engine.track_frame, image, float(self._det_cfg["score_thrs"]), float(self._det_cfg["iou_thrs"]),
+                float(self.min_face), int(self.top_k), float(self.iou_thres), float(self.alpha), float(self.diff_thres),
+                self._planted_rows() if self._planted_rows is not None else None)
+            self.previous_image = image
+            self.track_box = boxes
+            return self.to_dict(boxes, kps, scores)
         diff = self.engine.set_frame(image)
         self.previous_image = image
         if diff is None or self.track_box is None or diff > self.diff_thres:
@@ -148,4 +161,6 @@ class FaceAna:
         self.track_box = None
         self.previous_image = None
         self.previous_box = None
+        if self.device_tracking:
+            self.engine.track_reset()
         self.engine.forget_frames()

