@@ -124,6 +124,11 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
  *                    params [n][8] = valid, add, x0, y0, xs, ys, w_crop, h_crop */
 int pf_letterbox(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,
                  int out_h, int out_w, uint8_t* out_host, float* info3);
+/* cv2.resize(img, (out_w, out_h)) with the default INTER_LINEAR on a uint8 HxWx3 image (channel order untouched), the same
+ * fixed-point arithmetic as the letterbox / crop kernels.  Used by the WFLW evaluation harness (tools/eval_wflw.py), whose
+ * reference counterpart resizes an aspect-changing crop (TRAIN/face_landmark/tools/eval_WFLW.py:123). */
+int pf_resize(pf_handle* h, const uint8_t* img, int mem, int height, int width, int row_stride,
+              int out_h, int out_w, uint8_t* out_host);
 int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, float left, float top,
                 float score_thres, float iou_thres, float* kept, int max_n, int* n_out);
 int pf_crop_faces(pf_handle* h, const uint8_t* bgr, int mem, int height, int width, int row_stride,

@@ -61,6 +61,8 @@ def _declare(lib):
     lib.pf_run_frames_planted.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
     lib.pf_letterbox.argtypes = [vp, vp, i, i, i, i, i, i, vp, fp]
     lib.pf_nms_rows.argtypes = [vp, fp, i, f, f, f, f, f, fp, i, ip]
+    lib.pf_resize.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    lib.pf_resize.restype = i
     lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
     lib.pf_set_frame.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_ulonglong), ip]
     lib.pf_forget_frames.argtypes = [vp]
@@ -361,6 +363,15 @@ class Engine:
                                           out_hw[0], out_hw[1], _ptr(out), info.ctypes.data_as(C.POINTER(C.c_float))),
                     "pf_letterbox")
         return out, info
+
+    def resize(self, image: np.ndarray, out_hw) -> np.ndarray:
+        """cv2.resize(image, (out_w, out_h)) (INTER_LINEAR, uint8 HxWx3) on the GPU, bit-for-bit OpenCV's fixed point."""
+        img = np.ascontiguousarray(image)
+        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        out = np.empty((int(out_hw[0]), int(out_hw[1]), 3), np.uint8)
+        self._check(self.lib.pf_resize(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                       int(out_hw[0]), int(out_hw[1]), _ptr(out)), "pf_resize")
+        return out
 
     def nms_rows(self, rows: np.ndarray, scale: float, left: float, top: float, score_thres: float, iou_thres: float,
                  max_n: int = 1024) -> np.ndarray:

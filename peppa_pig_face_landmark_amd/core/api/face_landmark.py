@@ -25,8 +25,10 @@ class FaceLandmark:
         self.extend = cfg["base_extend_range"]
         if abs(float(self.extend[0]) - 0.2) > 1e-12:
             raise ValueError("the engine implements base_extend_range[0] == 0.2 (Skps.yml:14)")
+        # Keypoints.model: "student" (kps_student.onnx, the file the reference ships) or "teacher" (COTRAIN's TeacherNet,
+        # what convert_to_onnx.py --model teacher exports)
         self.model = HIPEngine(weights, "keypoints", self.input_size, device=device, dtype=dtype,
-                               max_batch=max_batch, engine=engine, library=library)
+                               max_batch=max_batch, engine=engine, library=library, arch=str(cfg.get("model", "student")))
         self.engine = self.model.engine
 
     def __call__(self, img, bboxes):

@@ -65,7 +65,8 @@ class FaceAna:
         root = pathlib.Path(__file__).resolve().parents[2]
         weights = weights or {}
         det_w = weights.get("detector") or _load_weights(root, sk["Detect"]["model_path"], "detector")
-        kps_w = weights.get("keypoints") or _load_weights(root, sk["Keypoints"]["model_path"], "keypoints")
+        kps_arch = str(sk["Keypoints"].get("model", "student"))
+        kps_w = weights.get("keypoints") or _load_weights(root, sk["Keypoints"]["model_path"], "teacher" if kps_arch == "teacher" else "keypoints")
 
         # Engine.device_tracking: keep track_box / previous landmarks / One-Euro state on the GPU (pf_track_frame) instead of
         # walking the boxes through numpy between the two networks on every frame

@@ -22,18 +22,25 @@ class HIPEngine:
     """
 
     def __init__(self, weights: Dict[str, np.ndarray], kind: str, input_shape, device: int = 0, dtype: str = "f32",
-                 max_batch: int = 8, engine: Optional[_native.Engine] = None, library: Optional[str] = None):
+                 max_batch: int = 8, engine: Optional[_native.Engine] = None, library: Optional[str] = None,
+                 arch: str = "student"):
         if kind not in ("keypoints", "detector"):
             raise ValueError(kind)
         self.kind = kind
         self.engine = engine if engine is not None else _native.Engine(device, library)
         self.slot = _native.PF_NET_LANDMARK if kind == "keypoints" else _native.PF_NET_DETECTOR
         self.max_batch = max_batch
+        if arch not in ("student", "teacher"):
+            raise ValueError("keypoint architecture must be 'student' or 'teacher'")
+        self.arch = arch           # TeacherNet (HRNet-W18 encoder, model.py:302-345) exports to the same two-output graph
         self._weights, self._input_shape = weights, input_shape
         self._load(dtype)
 
     def _load(self, dtype: str):
-        if self.kind == "keypoints":
+        if self.kind == "keypoints" and self.arch == "teacher":
+            from ...graph.teacher import build_teacher_program
+            blob, self.info = build_teacher_program(self._weights, int(self._input_shape[0]), dtype)
+        elif self.kind == "keypoints":
             blob, self.info = build_student_program(self._weights, int(self._input_shape[0]), dtype)
         else:
             blob, self.info = build_detector_program(self._weights, (int(self._input_shape[0]), int(self._input_shape[1])), dtype)

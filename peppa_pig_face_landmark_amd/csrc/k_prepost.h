@@ -92,6 +92,7 @@ struct LetterboxArgs {
     int F, H, W, row_stride, outH, outW, rw, rh, top, left;
     double scale_x, scale_y;      // 1/(rw/W), 1/(rh/H) as OpenCV derives them
     int pad_value;
+    int keep_order;               // 1: no BGR -> RGB swap (plain cv2.resize, pf_resize)
 };
 
 __global__ __launch_bounds__(256) void letterbox_kernel(LetterboxArgs a) {
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(256) void letterbox_kernel(LetterboxArgs a) {
             r[c] = pf_cv_vmix(h0, h1, ty.a0, ty.a1);
         }
     }
-    o[0] = (unsigned char)r[2];  // BGR -> RGB (face_detector.py:47)
+    o[0] = (unsigned char)r[a.keep_order ? 0 : 2];  // BGR -> RGB (face_detector.py:47)
     o[1] = (unsigned char)r[1];
-    o[2] = (unsigned char)r[0];
+    o[2] = (unsigned char)r[a.keep_order ? 2 : 0];
 }
 
 // --------------------------------------------------------------------------------------------

@@ -456,6 +456,27 @@ int pf_letterbox(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
     return 0;
 }
 
+int pf_resize(pf_handle* h, const uint8_t* img, int mem, int height, int width, int row_stride,
+              int out_h, int out_w, uint8_t* out_host) {
+    if (!h) return 1;
+    if (!img || !out_host || height < 1 || width < 1 || out_h < 1 || out_w < 1 || row_stride < width * 3) PF_FAIL(h, "pf_resize: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    const unsigned char* d_img = nullptr;
+    if (stage_frames(h, img, mem, (size_t)height * row_stride, &d_img)) return 1;
+    if (ensure_dev(h, h->pipe.d_letterbox, h->pipe.letterbox_bytes, (size_t)out_h * out_w * 3)) return 1;
+    LetterboxArgs la{};
+    la.frames = d_img; la.out = h->pipe.d_letterbox;
+    la.F = 1; la.H = height; la.W = width; la.row_stride = row_stride; la.outH = out_h; la.outW = out_w;
+    la.rw = out_w; la.rh = out_h; la.top = 0; la.left = 0;
+    la.scale_x = 1.0 / ((double)out_w / (double)width);     // OpenCV: scale = 1 / inv_scale
+    la.scale_y = 1.0 / ((double)out_h / (double)height);
+    la.pad_value = 0; la.keep_order = 1;
+    PF_LAUNCH(letterbox_kernel, dim3(pf_div_up(out_h * out_w, 256), 1), dim3(256), h->stream, la);
+    PF_HIP(h, hipMemcpyAsync(out_host, h->pipe.d_letterbox, (size_t)out_h * out_w * 3, hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 int pf_nms_rows(pf_handle* h, const float* rows_host, int n_rows, float scale, float left, float top,
                 float score_thres, float iou_thres, float* kept, int max_n, int* n_out) {
     if (!h) return 1;

@@ -299,3 +299,29 @@ def test_crop_faces_float64_rows_bit_exact_gpu(gpu_engine):
     """Tracked frames hand FaceLandmark float64 boxes (facer.py:66-81): pf_crop_faces_f64 / pf_landmarks_f64."""
     from tests.test_emu_pipeline import check_crop_faces_f64
     check_crop_faces_f64(gpu_engine)
+
+
+def test_faceana_facade_with_teacher(hip_library, detector_weights):
+    """Keypoints.model: teacher -- the FaceLandmark facade runs TeacherNet (model.py:302-345) instead of the Student."""
+    import torch
+    from Skps import FaceAna
+    from oracle import landmark_net as ln
+    from oracle import teacher_net as tn
+    from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+    tw = sw.teacher_weights()
+    cfg = get_cfg()
+    cfg["Skps"]["Keypoints"]["model"] = "teacher"
+    facer = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": tw}, library=hip_library)
+    frame, boxes = make_frame(1080, 1920, 2, seed=9)
+    lm, states = facer.face_landmark(frame, boxes)
+    assert lm.shape == (2, 98, 2)
+    for i in range(2):
+        ci = pp.landmark_crop_box(boxes[i], 1080, 1920)
+        crop = pp.landmark_crop(frame, ci, (256, 256))
+        with torch.no_grad():
+            taps = {}
+            oloc, _ = tn.teacher_forward(ln.to_torch(tw), torch.from_numpy(pp.landmark_input(crop)), taps)
+        ref = pp.landmark_backproject(oloc[0].numpy(), ci)
+        safe = helpers.heat_margins(taps)[0] > 2e-3
+        assert np.abs(lm[i] - ref)[safe].max() < 1e-3 * max(ci.w_crop, ci.h_crop)
+    facer.engine.close()

@@ -129,7 +129,9 @@ def _device_vs_host(library, student_weights, detector_weights):
                     assert (np.abs(x - y) / np.maximum(300.0, np.abs(x))).max() < 1e-3, (i, key)
                 assert np.abs(a["scores"] - b["scores"]).max() < 5e-3, i
         dev.reset()
-        assert len(dev.run(frames[0].copy())) == len(host.run(frames[0].copy())) or True
+        host.reset()
+        state["i"] = 0
+        assert len(dev.run(frames[0].copy())) == len(host.run(frames[0].copy()))      # reset() starts a fresh stream on both
     finally:
         host.engine.close()
         dev.engine.close()
