@@ -176,7 +176,12 @@ def random_teacher_weights(seed: int = 2) -> Dict[str, np.ndarray]:
         elif kind == "bias":
             w[name] = (rng.standard_normal(shape) * 0.05).astype(np.float32)
         else:
-            w[f"{name}.weight"] = rng.uniform(0.5, 1.5, shape).astype(np.float32)
+            # the BatchNorms that close a residual branch (BasicBlock.bn2 / Bottleneck.bn3) or feed a fuse sum get a small gain: HRNet stacks
+            # ~40 residual blocks and with unit gains the activations of a random net grow past 6e4 (the range guard of the
+            # f32s kernels fires, correctly); trained nets do not do that
+            damp = name.endswith((".bn2", ".bn3")) or "fuse_layers" in name
+            g_lo, g_hi = (0.08, 0.25) if damp else (0.5, 1.5)
+            w[f"{name}.weight"] = rng.uniform(g_lo, g_hi, shape).astype(np.float32)
             w[f"{name}.bias"] = (rng.standard_normal(shape) * 0.3).astype(np.float32)
             w[f"{name}.running_mean"] = np.zeros(shape, np.float32)
             w[f"{name}.running_var"] = np.full(shape, last_var, np.float32)
