@@ -422,6 +422,16 @@ def main():
                     "executed_mfma_tflops": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype], 2),
                     "executed_mfma_frac": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype] / PEAK_TFLOPS[args.dtype], 4)}
 
+    sq_path = os.path.join(ROOT, "profiles", "r02_run5_pmc_sq_hero_and_expdw.json")
+    if roofline is not None and args.dtype == "f32s" and os.path.exists(sq_path):
+        # matrix-pipe busy fraction of the same kernel from the committed rocprofv3 --pmc SQ pass:
+        # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) -- relative to the clock the chip actually ran at
+        with open(sq_path) as f:
+            sq = json.load(f)["derived"]
+        key = [k for k in sq if "conv3x3_halo_split_kernel<128" in k]
+        if key:
+            roofline["mfma_pipe_busy_pmc"] = sq[key[0]]["mfma_pipe_busy_frac"]
+            roofline["pmc_source"] = "profiles/r02_run5_pmc_sq_hero_and_expdw.json"
     if args.dump_profile and rank == 0:
         with open(args.dump_profile, "w") as f:
             json.dump({"steps": PROF_STEPS, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,

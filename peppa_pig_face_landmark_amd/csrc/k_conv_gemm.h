@@ -54,7 +54,8 @@ struct ConvGemmArgs {
     float* gap_out;       // [B][N] or nullptr
     // timing ablations of conv3x3_halo_split_kernel (PEPPA_DBG bit mask, 0 in production; results are WRONG when set):
     // 1 = weights fetched for the first K step only, 16 = no MFMAs, 32 = no output stores, 64 = input patch staged for the
-    // first channel chunk only, 128 = no per-tap barrier.  What each part costs on MI355X is tabulated in DESIGN.md.
+    // first channel chunk only, 128 = no per-tap barrier; conv_gemm_split_kernel: 16 as above, 256 = operands (pixels AND weights)
+    // fetched for the first K step only, 512 = no split / LDS store of the pixel operand.  Tables: profiles/r02_*ablations.md.
     int dbg;
 };
 
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (BN >= 256 || WIDE) ? WARPS
         const bool more = kt + 1 < nk;
         if (more) {
             if (++tap == taps) { tap = 0; ++cb; }
-            load_tile(tap, cb, cur ^ 1);
+            if (!(a.dbg & 256)) load_tile(tap, cb, cur ^ 1);
         }
         const unsigned char* xh = smem + cur * STAGE_BYTES;
         const unsigned char* xl = xh + PLANE_X;
@@ -660,6 +661,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (BN >= 256 || WIDE) ? WARPS
             whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
             wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
         }
+        if (!(a.dbg & 16))
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (BN >= 256 || WIDE) ? WARPS
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
         }
-        if (more) store_tile(cur ^ 1);
+        if (more && !(a.dbg & 512)) store_tile(cur ^ 1);
         __syncthreads();
     }
     if constexpr (EPI_K != 0) {
@@ -1054,27 +1056,52 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         if (tap == 0 && cb + 1 < cblocks && !(a.dbg & 64)) load_x(cb + 1);          // next chunk's patch: nine taps of latency cover
         const unsigned char* wh = wbase + cur * W_BYTES;
         const unsigned char* wl = wh + BN * 64;
-        pf_half8 whf[NT], wlf[NT];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-            whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
-            wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
-        }
         const int ky = tap / 3, kx = tap - ky * 3;
         const int shift = ky * HW2 + kx;
-        if (!(a.dbg & 16))
+        if (!(a.dbg & 16)) {
+            if constexpr (MT == 2) {
+                // pixel fragments of the (two) 16-pixel sub-tiles stay live, weight fragments come one 16-channel tile at a
+                // time: 24 fragment registers instead of 40, which is what keeps this kernel out of scratch at 128 VGPRs
+                pf_half8 xhf[MT], xlf[MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int off = pf_lds_chunk_off(hp0[i] + shift, fchunk);
-            const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xh + off);
-            const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xl + off);
+                for (int i = 0; i < MT; ++i) {
+                    const int off = pf_lds_chunk_off(hp0[i] + shift, fchunk);
+                    xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
+                    xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
+                }
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(wlf[j], xhf, acc[j][i]);
+                for (int j = 0; j < NT; ++j) {
+                    const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
+                    const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wh + off);
+                    const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wl + off);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xlf, acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
+                }
+            } else {
+                pf_half8 whf[NT], wlf[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
+                    whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
+                    wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int off = pf_lds_chunk_off(hp0[i] + shift, fchunk);
+                    const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xh + off);
+                    const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xl + off);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(wlf[j], xhf, acc[j][i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xlf, acc[j][i]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
+                }
+            }
         }
         if (last_tap && more && !(a.dbg & 64)) {
             __syncthreads();                 // every wave is done with this chunk's patch
