@@ -72,7 +72,6 @@ struct pf_handle {
     // kernel-variant switches for A/B timing on the GPU (environment, read once at pf_create): PEPPA_SEPUP=patch
     // selects the previous LDS-class-filter decoder front end instead of the register-blocked one
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
-    int expdw_variant = 0;   // PEPPA_EXPDW=wide: fused expand+depthwise kernels with 256 VGPRs (one workgroup per CU, no spills)
     // tracking state of the handle's video stream (pf_track_frame, k_track.h)
     TrackState track;
     // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
@@ -460,9 +459,11 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "expdw%dx%dd%d_c%d_n%d_%dx%d", K, K, dil, a.inC, a.N, to.H, to.W);
                     ProfScope ps(h, tagbuf);
-                    if (K == 3 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 3, 1>), grid, dim3(512), h->stream, a);
-                    else if (K == 5 && dil == 1 && h->expdw_variant == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 1, 1>), grid, dim3(512), h->stream, a);
-                    else if (K == 5 && dil == 2 && h->expdw_variant == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 2, 1>), grid, dim3(512), h->stream, a);
+                    const bool w16 = to.W == 16 && to.H == 16;      // image shape known at compile time: leaner depthwise epilogue
+                    if (K == 3 && dil == 1 && w16) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 3, 1, 16>), grid, dim3(512), h->stream, a);
+                    else if (K == 5 && dil == 1 && w16) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 1, 16>), grid, dim3(512), h->stream, a);
+                    else if (K == 5 && dil == 2 && w16) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 2, 16>), grid, dim3(512), h->stream, a);
+                    else if (K == 3 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 3, 1>), grid, dim3(512), h->stream, a);
                     else if (K == 5 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 1>), grid, dim3(512), h->stream, a);
                     else if (K == 5 && dil == 2) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 2>), grid, dim3(512), h->stream, a);
                     else PF_FAIL(h, "expdw: no kernel for k%d dil %d", K, dil);
@@ -684,7 +685,6 @@ int pf_create(int device_id, pf_handle** out) {
     pf_handle* h = new pf_handle();
     h->device = device_id;
     if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) { h->range_every = 0; h->check_pending = false; } }   // ablated kernels compute garbage
-    if (const char* v = getenv("PEPPA_EXPDW")) h->expdw_variant = strcmp(v, "wide") == 0 ? 1 : 0;
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         g_create_error = "stream/event creation failed";

@@ -332,7 +332,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 // per filter row it loads the W-pixel input row once and slides the filter along it in registers.  Also
 // emits the per-face channel means of the depthwise output (the SE squeeze), complete because a workgroup
 // owns whole images.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int K, int DIL>
+// WS = compile-time image width (16: the shape of every such layer of the Student at 256 x 256; 0 = read it from the
+// arguments): with the width known the per-pixel "x < W" selects, the row / image index divisions and the padding tests
+// fold away -- the epilogue is VALU-bound (57 % VALU busy, 12 % MFMA by SQ counters), so instruction count is its time.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int K, int DIL, int WS>
 __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (&acc)[BN / WARPS_N / 16][BM / WARPS_M / 16],
                                                unsigned char* smem, int m0, int n0, int wm, int wn, int t, int M) {
     constexpr int NTHR = WARPS_M * WARPS_N * 64;
@@ -371,7 +374,7 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
     for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
     const float bd = cok ? a.dw_b[n] : 0.f;
     __syncthreads();
-    const int W = a.outW, H = a.outH, OHW = H * W;
+    const int W = WS ? WS : a.outW, H = WS ? WS : a.outH, OHW = H * W;
     const int rows = BM / W;
     float fsum[MAXF];
 #pragma unroll
@@ -449,8 +452,8 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
 // fly -- bilinear x2 upsample of up_lo / pass-through of up_skip, depthwise 3x3 (+bias) -- so the
 // concatenated and the depthwise tensors never exist in HBM.
 // EPI_K != 0 (pointwise only): the epilogue is the fused depthwise EPI_K x EPI_K conv (dilation EPI_DIL) above.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1, int WIDE = 0>
-__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (BN >= 256 || WIDE) ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1, int EPI_W = 0>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
     // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves);
     // 256-channel tiles hold 64 accumulators + 64 weight-fragment registers and run one workgroup per CU;
     // the fused-depthwise variants keep an 80 KB tile in LDS (one workgroup per CU) and may use 256
@@ -681,7 +684,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, (BN >= 256 || WIDE) ? WARPS
     if constexpr (EPI_K != 0) {
         static_assert(KS == 1 && STAGE == 0, "fused depthwise epilogue: pointwise expand only");
         static_assert(2 * STAGE_BYTES >= (BM * (BN + 4) + (NTHR / BN) * 4 * BN) * 4, "E tile must fit the staging LDS");
-        expdw_epilogue<BM, BN, WARPS_M, WARPS_N, EPI_K, EPI_DIL>(a, acc, smem, m0, n0, wm, wn, t, M);   // loop ended on a barrier
+        expdw_epilogue<BM, BN, WARPS_M, WARPS_N, EPI_K, EPI_DIL, EPI_W>(a, acc, smem, m0, n0, wm, wn, t, M);   // loop ended on a barrier
     } else {
         conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
     }

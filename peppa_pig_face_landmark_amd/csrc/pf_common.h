@@ -25,7 +25,7 @@ template <int ACT> __device__ __forceinline__ float pf_act_c(float v) {
     else if constexpr (ACT == PF_ACT_HSWISH || ACT == PF_ACT_HSIGMOID) {
         // x * relu6(x + 3) / 6 with the division as a multiplication (onnxruntime's HardSigmoid alpha = 1/6 form)
         float r = v + 3.f;
-        r = (r < 0.f ? 0.f : (r > 6.f ? 6.f : r)) * (1.f / 6.f);
+        r = __builtin_fminf(__builtin_fmaxf(r, 0.f), 6.f) * (1.f / 6.f);   // one v_med3 / max+min instead of two compare+select pairs
         return ACT == PF_ACT_HSWISH ? v * r : r;
     } else if constexpr (ACT == PF_ACT_SILU) return v / (1.f + expf(-v));
     else if constexpr (ACT == PF_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
