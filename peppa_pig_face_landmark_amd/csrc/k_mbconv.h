@@ -60,15 +60,20 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
     constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
     constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
     constexpr int DS = 36;                     // D row stride: 16-lane fragment reads hit 64 distinct banks
-    constexpr int WORK = HPP * 16 + PP * DS;
+    // E pixel stride (floats).  The depthwise reads are ds_read_b32 of lanes (channel dc, pixel phase dg): two phases share a
+    // 32-lane bank group, S pixels apart, so S * EST must be 16 mod 32 for them to land on different bank halves: 16 at
+    // stride 1; at stride 2 the natural 16 puts them on the SAME banks (SQ_LDS_BANK_CONFLICT = 62-64 % of the LDS-active
+    // cycles of the stride-2 kernels in round 1's layout), 24 does not.
+    constexpr int EST = S == 2 ? 24 : 16;
+    constexpr int WORK = HPP * EST + PP * DS;
     constexpr int RED = MSPLIT > 1 ? MPW * MAXNT * 256 : 0;
     constexpr int WSZ = WORK > RED ? WORK : RED;
     static_assert(PP % 16 == 0 && (PW == 4 || PW == 8) && (MSPLIT == 1 || MSPLIT == 4), "patch shape");
 
     __shared__ __attribute__((aligned(16))) float smem[4][WSZ];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* es = smem[wave];                    // [HPP][16]  expanded sub-chunk
-    float* ds = es + HPP * 16;                 // [PP][DS]   depthwise output, 32 channels
+    float* es = smem[wave];                    // [HPP][EST]  expanded sub-chunk
+    float* ds = es + HPP * EST;                // [PP][DS]   depthwise output, 32 channels
 
     const int patchesX = (a.outW + PW - 1) / PW, patchesY = (a.outH + PH - 1) / PH;
     const int pid = MSPLIT > 1 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = fmaf(e[r], a.scale_exp, be[r]);
                 mb_act<4>(o, a.act);
-                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ok ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = ok ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
             fetch_expand(mnext);
             pf_wave_sync();
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
-                        s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
+                        s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * EST + dc], s);
                 dv[i] = s;
             }
             mb_act<PP / 4>(dv, a.act_dw);
@@ -294,12 +299,13 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
     constexpr int KK = CP / 16;
     constexpr int MAXNT = 2;                   // Cout <= 32
+    constexpr int EST = S == 2 ? 24 : 16;      // E pixel stride, see mbconv_wave_kernel
     static_assert(PP % 16 == 0 && (PW == 4 || PW == 8), "patch shape");
 
-    __shared__ __attribute__((aligned(16))) float smem[4][(HPP + PP) * 16];
+    __shared__ __attribute__((aligned(16))) float smem[4][HPP * EST + PP * 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float* es = smem[wave];                    // [HPP][16]: fragment stores cover 1 KB contiguously
-    float* ds = es + HPP * 16;                 // [PP][16]
+    float* es = smem[wave];                    // [HPP][EST]
+    float* ds = es + HPP * EST;                // [PP][16]
 
     const int patchesX = (a.outW + PW - 1) / PW, patchesY = (a.outH + PH - 1) / PH;
     const int pid = blockIdx.x * 4 + wave;
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
         for (int mt = 0; mt < MH; ++mt) {
             if constexpr (NOEXP) {
                 static_assert(!NOEXP || CP == 16, "depthwise-separable variant: 16 channels");
-                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = xf[mt][0];   // zero outside the image already
+                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = xf[mt][0];   // zero outside the image already
             } else {
                 pf_f32x4 e = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
                     for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
                 pf_f32x4 o = e + be;
                 pf_act_rh<4>(o, a.act);
-                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * 16 + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         if constexpr (!NOEXP) fetch_expand(mc + 16);
@@ -391,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * 16 + dc], s);
+                    s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * EST + dc], s);
             dv[i] = s;
         }
         pf_act_rh<PP / 4>(dv, a.act);
