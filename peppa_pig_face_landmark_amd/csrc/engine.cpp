@@ -220,6 +220,14 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
             return 0;
         }
     }
+    // heat-map score head: bias-only arg-max epilogue (nothing stored, tiles never straddle a face)
+    if (SPLIT && use_split && pointwise && cfg == 0 && a.amax_val && !a.store_out && !a.res && !a.fbias && !a.gate && a.act == PF_ACT_NONE &&
+        (M % 128) == 0) {
+        if constexpr (SPLIT) {
+            PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1>), grid, dim3(512), h->stream, a);
+            return 0;
+        }
+    }
     if (cfg == 8) {
         if constexpr (SPLIT) {
             PF_LAUNCH((conv_gemm_split_kernel<128, 160, 4, 2, 1>), grid, dim3(512), h->stream, a);

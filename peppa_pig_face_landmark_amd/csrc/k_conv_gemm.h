@@ -177,6 +177,60 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
     }
 }
 
+// ---- arg-max-only epilogue of the heat-map score head (COTRAIN.postp, model.py:520-522) ----------------------------------
+// The generic epilogue above serves every conv of both networks through run-time switches (residual, per-face bias, five
+// activations, strided stores, optional arg-max); on the score head -- bias only, nothing stored, 128-pixel tiles that
+// never straddle a face -- those switches and the ds_bpermute shuffles of its arg-max were most of the kernel (SQ
+// counters: VALU 56 % busy, MFMA 15 %).  This one does exactly the head's work: bias, running (max, first index) per
+// lane, then a 16-lane reduction by DPP row exchanges.  Host guarantees: OHW % BM == 0 (so every pixel of the tile exists and
+// belongs to one face), no residual / per-face bias / gate / activation, store_out == 0.
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__device__ __forceinline__ void conv_gemm_argmax_epilogue(const ConvGemmArgs& a, pf_f32x4 (&acc)[BN / WARPS_N / 16][BM / WARPS_M / 16],
+                                                          int m0, int n0, int wm, int wn, int lane, int OHW, float acc_scale) {
+    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    const int pcol = lane & 15;
+    const int crow = (lane >> 4) * 4;
+    const int b = m0 / OHW;
+    const int local0 = m0 - b * OHW + wm * WM + pcol;
+    const int nslots = (OHW / BM) * WARPS_M;
+    const int slot = ((m0 - b * OHW) / BM) * WARPS_M + wm;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + crow;
+        float best_v[4];
+        int best_i[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float bv = (n + r < a.Npad) ? a.bias[n + r] : 0.f;
+            best_v[r] = fmaf(acc[j][0][r], acc_scale, bv);
+            best_i[r] = local0;
+#pragma unroll
+            for (int i = 1; i < MT; ++i) {           // ascending pixel index: strict > keeps the first maximum
+                const float v = fmaf(acc[j][i][r], acc_scale, bv);
+                if (v > best_v[r]) { best_v[r] = v; best_i[r] = local0 + i * 16; }
+            }
+        }
+#define PF_AMAX_STEP(STEP)                                                                                   \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                              \
+        const float ov = pf_row_xchg_f32<STEP>(best_v[r]);                                                    \
+        const int oi = pf_row_xchg_i32<STEP>(best_i[r]);                                                      \
+        if (ov > best_v[r] || (ov == best_v[r] && oi < best_i[r])) { best_v[r] = ov; best_i[r] = oi; }        \
+    }
+        PF_AMAX_STEP(0) PF_AMAX_STEP(1) PF_AMAX_STEP(2) PF_AMAX_STEP(3)
+#undef PF_AMAX_STEP
+        if (pcol == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < a.amaxN) {
+                    const size_t o = ((size_t)b * a.amaxN + n + r) * nslots + slot;
+                    a.amax_val[o] = best_v[r];
+                    a.amax_idx[o] = best_i[r];
+                }
+        }
+    }
+}
+
 // KS = 1: pointwise conv (1x1, stride 1, no padding) -- tap arithmetic compiled out;
 // KS = 3: general kxk conv (any kernel size / stride / dilation / padding).
 template <typename T, int BM, int BN, int WARPS_M, int WARPS_N, int KS>
@@ -681,7 +735,9 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         if (more && !(a.dbg & 512)) store_tile(cur ^ 1);
         __syncthreads();
     }
-    if constexpr (EPI_K != 0) {
+    if constexpr (EPI_K < 0) {
+        conv_gemm_argmax_epilogue<BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, OHW, a.acc_scale);
+    } else if constexpr (EPI_K != 0) {
         static_assert(KS == 1 && STAGE == 0, "fused depthwise epilogue: pointwise expand only");
         static_assert(2 * STAGE_BYTES >= (BM * (BN + 4) + (NTHR / BN) * 4 * BN) * 4, "E tile must fit the staging LDS");
         expdw_epilogue<BM, BN, WARPS_M, WARPS_N, EPI_K, EPI_DIL, EPI_W>(a, acc, smem, m0, n0, wm, wn, t, M);   // loop ended on a barrier

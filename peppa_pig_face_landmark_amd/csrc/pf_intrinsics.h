@@ -25,6 +25,16 @@ __device__ __forceinline__ float pf_shfl_xor_f32(float v, int mask) { return __s
 __device__ __forceinline__ int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int pf_shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+// Cross-lane moves inside a 16-lane row by DPP (one VALU instruction, no LDS): lane ^ 1, lane ^ 2 (quad permutes), then the
+// mirror of an 8-lane half and of the whole row -- after the four steps of a reduction every lane of the row has seen all 16.
+template <int STEP> __device__ __forceinline__ int pf_row_xchg_i32(int v) {
+    constexpr int ctrl = STEP == 0 ? 0xB1 : (STEP == 1 ? 0x4E : (STEP == 2 ? 0x141 : 0x140));   // quad_perm[1,0,3,2] / [2,3,0,1] / row_half_mirror / row_mirror
+    return __builtin_amdgcn_update_dpp(v, v, ctrl, 0xF, 0xF, false);
+}
+template <int STEP> __device__ __forceinline__ float pf_row_xchg_f32(float v) {
+    return __int_as_float(pf_row_xchg_i32<STEP>(__float_as_int(v)));
+}
+
 // Orders LDS traffic between the lanes of ONE wave (producer lanes write, other lanes read) without a
 // workgroup barrier: the wave issues its LDS instructions in order, so only the compiler has to be fenced.
 __device__ __forceinline__ void pf_wave_sync() {

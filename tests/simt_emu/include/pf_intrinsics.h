@@ -66,6 +66,17 @@ inline float pf_shfl_xor_f32(float v, int mask) { return __shfl_xor(v, mask, 64)
 inline int pf_shfl_xor_i32(int v, int mask) { return __shfl_xor(v, mask, 64); }
 inline int pf_shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, 64); }
 
+template <int STEP> inline int pf_row_xchg_i32(int v) {      // same lane pairing as the DPP controls of the product header
+    const int l = pf_emu::lane_id();
+    const int src = STEP == 0 ? (l ^ 1) : (STEP == 1 ? (l ^ 2) : (STEP == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15)))));
+    return __shfl(v, src, 64);
+}
+template <int STEP> inline float pf_row_xchg_f32(float v) {
+    const int l = pf_emu::lane_id();
+    const int src = STEP == 0 ? (l ^ 1) : (STEP == 1 ? (l ^ 2) : (STEP == 2 ? ((l & ~7) | (7 - (l & 7))) : ((l & ~15) | (15 - (l & 15)))));
+    return __shfl(v, src, 64);
+}
+
 inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
 inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
