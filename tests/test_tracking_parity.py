@@ -8,7 +8,7 @@ import torch
 
 from oracle import landmark_net as ln
 from oracle import ref_import as ri
-from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
+from tests.tracking_video import GOLDEN, video as _video
 
 S = 64
 
@@ -25,20 +25,8 @@ class _PlantedDetector:
         return self.engine.nms_rows(self.rows_for(), np.float32(s), l, t, 0.5, 0.3)
 
 
-def _video():
-    """5 frames: f0, f0 again (static: detector skipped, float64 track boxes feed the landmark stage), a shifted scene
-    (detector runs, IoU-matched boxes are EMA-smoothed), the same again, and a frame with one face fewer."""
-    f0, b0 = make_frame(270, 480, 3, seed=11, face_w=330, face_h=430)
-    f1 = np.roll(f0, 6, axis=1)
-    b1 = b0 + np.float32([6, 0, 6, 0])
-    f2, b2 = make_frame(270, 480, 2, seed=12, face_w=330, face_h=430)
-    frames = [f0, f0, f1, f1, f2]
-    boxes = [b0, b0, b1, b1, b2]
-    rows = [plant_rows(b, (270, 480), 15120, (384, 640), 6, seed=3 + i) for i, b in enumerate(boxes)]
-    return frames, rows
-
-
-def _compare(make_facer, student_weights):
+def reference_run(student_weights):
+    """The reference's FaceAna (facer.py / lk.py from source) over the video: per frame, a list of result dicts."""
     frames, rows = _video()
     W = ln.to_torch(student_weights)
     state = {"i": 0}
@@ -52,6 +40,25 @@ def _compare(make_facer, student_weights):
         return loc.numpy(), score.numpy()
 
     ref = ri.reference_faceana(det_model, lmk_model, top_k=5, min_face=1600, kps_input=(S, S, 3))
+    out = []
+    for i, fr in enumerate(frames):
+        state["i"] = i
+        out.append([{k: np.asarray(v) for k, v in r.items()} for r in ref.run(fr.copy())])
+    return out, ref.track_box.dtype
+
+
+def golden_run():
+    """The same, from the committed vector (tests/golden/make_tracking_golden.py wrote it from reference_run)."""
+    g = np.load(GOLDEN)
+    out = []
+    for i, n in enumerate(g["counts"]):
+        out.append([{"box": g["box"][i, j], "kps": g["kps"][i, j], "scores": g["scores"][i, j]} for j in range(int(n))])
+    return out
+
+
+def _compare(make_facer, reference, track_dtype=None):
+    frames, rows = _video()
+    state = {"i": 0}
     facer = make_facer()
     if facer.device_tracking:
         facer._planted_rows = lambda: rows[state["i"]]
@@ -60,11 +67,12 @@ def _compare(make_facer, student_weights):
     try:
         for i, fr in enumerate(frames):
             state["i"] = i
-            r = ref.run(fr.copy())
+            r = reference[i]
             g = facer.run(fr.copy())
             assert len(r) == len(g) and len(r) >= 2, (i, len(r), len(g))
             for a, b in zip(r, g):
-                if not facer.device_tracking:     # the host facade follows numpy's promotion; the device state is always float64
+                if track_dtype is not None and not facer.device_tracking:
+                    # the host facade follows numpy's promotion; the device state is always float64
                     assert np.asarray(b["box"]).dtype == np.asarray(a["box"]).dtype, i
                 # north-star bound: 1e-3 of the crop size (crops here are >= 300 px); synthetic weights put some landmarks --
                 # and the hull boxes made from them -- thousands of pixels out, hence relative to the magnitude beyond that
@@ -75,7 +83,7 @@ def _compare(make_facer, student_weights):
         # (under numpy 1.23 -- the reference's pin -- track_box turns float64 after the first frame; under numpy >= 2 it
         # stays float32.  The facade follows whatever numpy does, as asserted per frame above; the float64 crop path of
         # the engine is pinned by tests/test_emu_pipeline.py::test_crop_faces_float64_rows_bit_exact.)
-        assert facer.device_tracking or facer.track_box.dtype == ref.track_box.dtype
+        assert track_dtype is None or facer.device_tracking or facer.track_box.dtype == track_dtype
     finally:
         facer.engine.close()
 
@@ -95,19 +103,38 @@ def _make_facer(library, student_weights, detector_weights, device_tracking=Fals
 
 @pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
 def test_faceana_video_matches_reference_source_emulator(emu_library, student_weights, detector_weights):
-    _compare(lambda: _make_facer(emu_library, student_weights, detector_weights), student_weights)
+    ref, dt = reference_run(student_weights)
+    _compare(lambda: _make_facer(emu_library, student_weights, detector_weights), ref, dt)
 
 
 @pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
 def test_device_tracking_matches_reference_source_emulator(emu_library, student_weights, detector_weights):
     """Same video through pf_track_frame: track boxes, landmark sets and One-Euro state never leave the device."""
-    _compare(lambda: _make_facer(emu_library, student_weights, detector_weights, device_tracking=True), student_weights)
+    ref, dt = reference_run(student_weights)
+    _compare(lambda: _make_facer(emu_library, student_weights, detector_weights, device_tracking=True), ref, dt)
+
+
+def test_golden_video_is_what_the_reference_produces(student_weights):
+    """The committed vector against the reference run live (build container) -- and, everywhere, its self-description."""
+    g = np.load(GOLDEN)
+    assert g["counts"].tolist() == [3, 3, 3, 3, 2] and g["kps"].shape[2:] == (98, 2)
+    if not ri.available():
+        pytest.skip("reference checkout not present (GPU box): the vector was checked where it was generated")
+    ref, _ = reference_run(student_weights)
+    gold = golden_run()
+    for r, q in zip(ref, gold):
+        assert len(r) == len(q)
+        for a, b in zip(r, q):
+            for key in ("box", "kps", "scores"):
+                assert np.array_equal(np.asarray(a[key], np.float64), np.asarray(b[key], np.float64)), key
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(not ri.available(), reason="reference checkout not present (GPU box)")
-def test_faceana_video_matches_reference_source_gpu(hip_library, student_weights, detector_weights):
-    _compare(lambda: _make_facer(hip_library, student_weights, detector_weights), student_weights)
+@pytest.mark.parametrize("device_tracking", [False, True])
+def test_faceana_video_matches_reference_golden_gpu(hip_library, student_weights, detector_weights, device_tracking):
+    """GPU twin: the reference's outputs for the video come from the committed vector (no reference on the GPU box)."""
+    _compare(lambda: _make_facer(hip_library, student_weights, detector_weights, device_tracking=device_tracking),
+             golden_run())
 
 
 def _device_vs_host(library, student_weights, detector_weights):
