@@ -17,6 +17,7 @@
 #include "k_conv_gemm.h"
 #include "k_layers.h"
 #include "k_mbconv.h"
+#include "k_chain.h"
 #include "k_prepost.h"
 #include "k_track.h"
 #include "pf_program.h"
@@ -213,9 +214,13 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         (a.Npad == 128 || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
         if constexpr (SPLIT) {
             grid = dim3(pf_div_up(M, 128), 1);
+            const bool big = ((a.outH * a.outW) % 256) == 0 && !(h->dbg & 1024);     // narrow variants: 256-pixel tiles
+            if (big && a.Npad <= 48) grid = dim3(pf_div_up(M, 256), 1);
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 80) PF_LAUNCH((conv3x3_halo_split_kernel<80, 8, 1>), grid, dim3(512), h->stream, a);
+            else if (a.Npad == 48 && big) PF_LAUNCH((conv3x3_halo_split_kernel<48, 8, 1, 256>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 48) PF_LAUNCH((conv3x3_halo_split_kernel<48, 8, 1>), grid, dim3(512), h->stream, a);
+            else if (big) PF_LAUNCH((conv3x3_halo_split_kernel<32, 8, 1, 256>), grid, dim3(512), h->stream, a);
             else PF_LAUNCH((conv3x3_halo_split_kernel<32, 8, 1>), grid, dim3(512), h->stream, a);
             return 0;
         }
@@ -413,6 +418,35 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     PF_MBCONV_CASE(1, 3, 4, 8, 5, 4)
                     PF_FAIL(h, "mbconv: no kernel for stride %d, %d input channels, %d output channels", S, a.Cin, a.Cout);
 #undef PF_MBCONV_CASE
+                }
+                break;
+            }
+            case PF_OP_CHAIN: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "BasicBlock chain op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    ChainArgs a{};
+                    a.in = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.B = B; a.inLd = ti.ld; a.outLd = to.ld;
+                    a.n_convs = f[2];
+                    const int C = f[3];
+                    if (a.n_convs < 2 || a.n_convs > PF_CHAIN_MAX_CONVS || (a.n_convs & 1)) PF_FAIL(h, "chain: %d convs", a.n_convs);
+                    if (ti.C != C || to.C != C || ti.H != to.H || ti.W != to.W || ti.H != ti.W) PF_FAIL(h, "chain: tensor shapes");
+                    for (int c = 0; c < a.n_convs; ++c) {
+                        a.wt[c] = p.cptr(f[4 + 3 * c]); a.bias[c] = (const float*)p.cptr(f[5 + 3 * c]);
+                        memcpy(&a.acc_scale[c], &f[6 + 3 * c], 4);
+                    }
+                    a.range_slot = guard ? h->d_range + oi : nullptr;
+                    a.dbg = h->dbg;
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "chain%d_c%d_%dx%d", a.n_convs, C, ti.H, ti.W);
+                    ProfScope ps(h, tagbuf);
+                    if (C == 72 && ti.H == 16) PF_LAUNCH((basic_chain_kernel<72, 16, 8, 1, 5>), dim3(B), dim3(512), h->stream, a);
+                    else if (C == 144 && ti.H == 8) PF_LAUNCH((basic_chain_kernel<144, 8, 4, 2, 5>), dim3(B), dim3(512), h->stream, a);
+                    else PF_FAIL(h, "chain: no kernel for %d channels at %dx%d", C, ti.H, ti.W);
                 }
                 break;
             }

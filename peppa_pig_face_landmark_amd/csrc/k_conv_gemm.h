@@ -996,13 +996,15 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
 // per tap (LDS-DMA, two stages).  Activation fetches, conversions and LDS writes drop ~4x (halo overhead 2.06x
 // at W = 64); the matrix-core work and the epilogue are unchanged.  Host guarantees: pad = dil = stride = 1,
 // W in {16, 32, 64}, (H * W) % 128 == 0, no input gate.
-template <int BN, int WARPS_M, int WARPS_N>
+template <int BN, int WARPS_M, int WARPS_N, int BM = 128>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv3x3_halo_split_kernel(ConvGemmArgs a) {
-    constexpr int BM = 128;
     constexpr int NTHR = WARPS_M * WARPS_N * 64;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
     constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int MAXHP = 272;                           // (2 + 2) x (64 + 2) = 264 halo pixels at W = 64 (204 / 180 at 32 / 16)
+    // halo pixels: BM = 128: (2 + 2) x (64 + 2) = 264 at W = 64 (204 / 180 at 32 / 16); BM = 256 (the narrow HRNet variants: twice
+    // the MFMAs per barrier, halo overhead 1.55x instead of 2.06x at W = 64): 6 x 66 = 396 (340 / 324 at 32 / 16)
+    constexpr int MAXHP = BM == 128 ? 272 : 400;
+    static_assert(BM == 128 || BM == 256, "tile rows");
     constexpr int XU = (MAXHP * 4 + NTHR - 1) / NTHR;    // (pixel, 8-float unit) pairs per thread
     constexpr int PLANE_X = MAXHP * 64;
     constexpr int WCHUNKS = (BN * 8 + NTHR - 1) / NTHR;

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 6
+#define PF_PROGRAM_VERSION 7
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -50,6 +50,8 @@ enum PfOpCode : int32_t {
     PF_OP_ADDUP = 13,   // f: a_t b_t out_t shift act      out = act(a + nearest_up(b, 2^shift))
     PF_OP_MBCONV = 14,  // f: in_t out_t res_t w_exp b_exp w_dw b_dw w_pwl b_pwl K stride pad dil act MidPad KS CoutPad Cout Mid16 scale_exp scale_pwl (float bits) variant(0 split: KS = Cin/32, 1 exact f32: KS field = CinPad16, 2 no expand, 3 ShuffleV2 unit: + act_dw act_out out_cs pass_src_t pass_dst_t)
     PF_OP_EXPDW = 15,   // f: in_t out_t gap_buf w_exp b_exp w_dw b_dw K pad dil act Cpad Npad N acc_scale(float bits) stride(0 = 1)
+    PF_OP_CHAIN = 16,   // f: in_t out_t n_convs C then n_convs x (wt bias acc_scale(float bits)): chain of BasicBlocks (two 3x3
+                        //    convs + identity residual each), one face's map resident in LDS (k_chain.h); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip)
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

@@ -17,14 +17,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 6
+VERSION = 7
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW = range(1, 16)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN = range(1, 17)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -370,6 +370,33 @@ class ProgramBuilder:
                             ACT[act], cpad, npad, mid, struct.unpack("<i", struct.pack("<f", acc_scale))[0], stride],
                  [self._tb(x)], [self._tb(out), gap])
         return out, gap
+
+    CHAIN_SHAPES = ((72, 16), (144, 8))       # (channels, map side) with a basic_chain_kernel instantiation
+    CHAIN_MAX_CONVS = 8
+
+    def basic_chain_supported(self, x: int, n_blocks: int) -> bool:
+        ti = self.tensors[x]
+        return (self.split and ti.H == ti.W and (ti.real_c, ti.H) in self.CHAIN_SHAPES and ti.C == ti.real_c
+                and 1 <= n_blocks <= self.CHAIN_MAX_CONVS // 2)
+
+    def basic_chain(self, x: int, blocks: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]], out_name: str = "") -> int:
+        """n BasicBlocks -- relu(conv2(relu(conv1(x))) + x), BN folded, both convs 3x3 / stride 1 / pad 1, C -> C -- in one
+        launch with the face's map resident in LDS (k_chain.h).  blocks: (w1, b1, w2, b2) per block."""
+        ti = self.tensors[x]
+        assert self.basic_chain_supported(x, len(blocks))
+        c = ti.real_c
+        out = self.tensor(ti.H, ti.W, c, name=out_name)
+        fields = [x, out, 2 * len(blocks), c]
+        for blk in blocks:
+            for wgt, bias in ((blk[0], blk[1]), (blk[2], blk[3])):
+                assert wgt.shape == (c, c, 3, 3)
+                woff, npad, cpad, acc_scale, _ = self.pack_conv_weight(wgt, force_split=True)
+                assert npad == _round_up(c, 16) and cpad == _round_up(c, 32)
+                b = np.zeros(npad, np.float64)
+                b[:c] = bias
+                fields += [woff, self.const_f32(b), struct.unpack("<i", struct.pack("<f", acc_scale))[0]]
+        self._op(OP_CHAIN, fields, [self._tb(x)], [self._tb(out)])
+        return out
 
     def upcat(self, lo: int, skip: int, out_name: str = "") -> int:
         tl, ts = self.tensors[lo], self.tensors[skip]

@@ -31,7 +31,7 @@ def _bn(w, prefix):
 
 
 def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f32s",
-                          keep_all: bool = False, debug_full_hm: bool = False):
+                          keep_all: bool = False, debug_full_hm: bool = False, fuse_chains: bool = True):
     assert input_size % 64 == 0
     w = weights
     pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
@@ -44,6 +44,11 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
     def basic(x, p):
         y = cb(x, f"{p}.conv1", f"{p}.bn1", "relu")
         return cb(y, f"{p}.conv2", f"{p}.bn2", "relu", res=x)          # relu(bn2(conv2) + x)
+
+    def basic_folded(p):
+        w1, b1 = ir.fold_bn(w[f"{p}.conv1.weight"], None, _bn(w, f"{p}.bn1"))
+        w2, b2 = ir.fold_bn(w[f"{p}.conv2.weight"], None, _bn(w, f"{p}.bn2"))
+        return w1, b1, w2, b2
 
     def bottleneck(x, p, name=""):
         sc = cb(x, f"{p}.downsample.0", f"{p}.downsample.1", "none") if f"{p}.downsample.0.weight" in w else x
@@ -65,6 +70,9 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
         for m in range(modules):
             p = f"{e}.stage{si}.{m}"
             for br in range(nb):
+                if fuse_chains and pb.basic_chain_supported(xs[br], 4):      # the branch's four blocks in one launch
+                    xs[br] = pb.basic_chain(xs[br], [basic_folded(f"{p}.branches.{br}.{blk}") for blk in range(4)])
+                    continue
                 for blk in range(4):
                     xs[br] = basic(xs[br], f"{p}.branches.{br}.{blk}")
             fused = []

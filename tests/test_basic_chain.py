@@ -1,0 +1,88 @@
+"""BasicBlock chains with the map resident in LDS (csrc/k_chain.h, PF_OP_CHAIN) against the same eight convs as separate
+launches (conv3x3_halo_split_kernel / conv_gemm_split_kernel with a residual epilogue) in one program: HRNet's two
+low-resolution branch shapes at a 256 x 256 crop, 72 channels @ 16 x 16 and 144 channels @ 8 x 8 (timm hrnet.py BasicBlock
+x 4 per HighResolutionModule branch; TeacherNet, TRAIN/face_landmark/lib/core/base_trainer/model.py:306-311)."""
+import numpy as np
+import pytest
+
+from peppa_pig_face_landmark_amd.graph import ir
+
+
+def _program(c, hw, n_blocks, seed):
+    rng = np.random.default_rng(seed)
+    pb = ir.ProgramBuilder("f32s", 2 * hw, 2 * hw, keep_all=True)
+    f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+    x = pb.conv(f0, rng.normal(0, 0.35, (c, 16, 1, 1)), rng.normal(0, 0.2, c), "none", out_name="x")
+    std = np.sqrt(2.0 / (9 * c))
+    blocks = [(rng.normal(0, std, (c, c, 3, 3)), rng.normal(0, 0.05, c), rng.normal(0, 0.6 * std, (c, c, 3, 3)), rng.normal(0, 0.05, c))
+              for _ in range(n_blocks)]
+    assert pb.basic_chain_supported(x, n_blocks)
+    y = pb.basic_chain(x, blocks, out_name="chain.out")
+    r = x
+    for i, (w1, b1, w2, b2) in enumerate(blocks):
+        m = pb.conv(r, w1, b1, "relu", pad=1)
+        r = pb.conv(m, w2, b2, "relu", pad=1, res=r, out_name=f"ref.block{i}")
+    loc, score = pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")
+    blob = pb.finish([loc, score])
+    return blob, {"tensors": dict(pb.tensor_names)}, y, r
+
+
+def _run(eng, c, hw, n_blocks, batch, seed):
+    blob, info, _, _ = _program(c, hw, n_blocks, seed)
+    eng.load_program(0, blob, batch)
+    rng = np.random.default_rng(seed + 1)
+    crops = rng.integers(0, 256, (batch, 2 * hw, 2 * hw, 3), dtype=np.uint8)
+    eng.landmark_forward(crops)
+    x = eng.read_tensor(0, info["tensors"]["x"], batch, (hw, hw, c))
+    got = eng.read_tensor(0, info["tensors"]["chain.out"], batch, (hw, hw, c))
+    ref = eng.read_tensor(0, info["tensors"][f"ref.block{n_blocks - 1}"], batch, (hw, hw, c))
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0.1 and (x < 0).any()      # the comparison is not vacuous
+    assert (np.abs(ref).reshape(batch, -1).max(1) > 0.05).all()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    assert rel < 2e-5, (c, hw, n_blocks, rel)
+
+
+@pytest.mark.parametrize("c,hw,n_blocks,batch", [(72, 16, 4, 2), (144, 8, 4, 3), (72, 16, 1, 1), (144, 8, 2, 1)])
+def test_chain_equals_separate_convs_emu(emu_engine, c, hw, n_blocks, batch):
+    _run(emu_engine, c, hw, n_blocks, batch, seed=100 + c + n_blocks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw,n_blocks,batch", [(72, 16, 4, 5), (144, 8, 4, 7), (72, 16, 2, 300), (144, 8, 1, 1)])
+def test_chain_equals_separate_convs_gpu(gpu_engine, c, hw, n_blocks, batch):
+    _run(gpu_engine, c, hw, n_blocks, batch, seed=200 + c + n_blocks)
+
+
+def _narrow_conv_case(eng, c, hw, batch, seed):
+    """HRNet's narrow 3x3 convs (conv3x3_halo_split_kernel<32 | 48, 8, 1, 256>: 256-pixel tiles) against torch conv2d on the
+    tensor the engine itself produced upstream."""
+    import torch
+    rng = np.random.default_rng(seed)
+    pb = ir.ProgramBuilder("f32s", 2 * hw, 2 * hw, keep_all=True)
+    f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+    x = pb.conv(f0, rng.normal(0, 0.35, (c, 16, 1, 1)), rng.normal(0, 0.2, c), "none", out_name="x")
+    w1, b1 = rng.normal(0, np.sqrt(2.0 / (9 * c)), (c, c, 3, 3)), rng.normal(0, 0.05, c)
+    y = pb.conv(x, w1, b1, "relu", pad=1, res=x, out_name="y")
+    blob = pb.finish([pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")])
+    eng.load_program(0, blob, batch)
+    eng.landmark_forward(rng.integers(0, 256, (batch, 2 * hw, 2 * hw, 3), dtype=np.uint8))
+    cp = (c + 3) // 4 * 4
+    xv = eng.read_tensor(0, pb.tensor_names["x"], batch, (hw, hw, cp))[..., :c]
+    got = eng.read_tensor(0, pb.tensor_names["y"], batch, (hw, hw, cp))
+    assert not got[..., c:].any()                       # vector padding channels are written as zeros
+    xt = torch.from_numpy(xv.astype(np.float64)).permute(0, 3, 1, 2)
+    ref = torch.relu(torch.nn.functional.conv2d(xt, torch.from_numpy(w1), torch.from_numpy(b1), padding=1) + xt)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    rel = np.abs(got[..., :c] - ref).max() / np.abs(ref).max()
+    assert rel < 2e-6, (c, hw, rel)
+
+
+@pytest.mark.parametrize("c,hw,batch", [(18, 16, 3), (18, 32, 1), (36, 16, 2)])
+def test_narrow_halo_convs_emu(emu_engine, c, hw, batch):
+    _narrow_conv_case(emu_engine, c, hw, batch, seed=300 + c + hw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2)])
+def test_narrow_halo_convs_gpu(gpu_engine, c, hw, batch):
+    _narrow_conv_case(gpu_engine, c, hw, batch, seed=400 + c + hw)

@@ -160,3 +160,37 @@ def test_teacher_256_matches_oracle(gpu_engine, dtype):
     gpu_engine.load_program(0, blob, batch)
     loc2, _ = gpu_engine.landmark_forward(crops)
     assert np.abs(loc2 - oloc.numpy()).reshape(batch, 98, 2).max(2)[safe].max() < 2e-4
+
+
+def test_teacher_f16_fast_mode_is_measured_not_claimed(gpu_engine):
+    """BASELINE config 5 names fp16 MFMA.  f16 storage + f16 MFMA (f32 accumulate) runs the Teacher, but whether it meets the
+    1e-3 landmark bound is a property of the weights: this measures it on the synthetic set (heat-map error, fraction of
+    landmarks within 1e-3, arg-max flips) and asserts only what the mode promises -- finite outputs that track the oracle."""
+    import torch
+    from oracle import landmark_net as ln
+    from oracle import teacher_net as tn
+    from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program
+    weights = sw.teacher_weights()
+    size, batch = 256, 3
+    blob, info = build_teacher_program(weights, size, "f16", keep_all=True, debug_full_hm=True)
+    gpu_engine.load_program(0, blob, batch)
+    crops = sw.smooth_blob_images(batch, size, seed=77)
+    loc, score = gpu_engine.landmark_forward(crops)
+    assert np.isfinite(loc).all() and np.isfinite(score).all()
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    taps = {}
+    with torch.no_grad():
+        oloc, oscore = tn.teacher_forward(ln.to_torch(weights), x, taps)
+    ref = helpers.tap_nhwc(taps, "hm")
+    got = helpers.read_engine_tensor(gpu_engine, 0, info, "hm", batch, ref.shape[1:], 8)
+    hm_err = float(np.abs(got - ref).max())
+    corr = float(np.corrcoef(got.ravel(), ref.ravel())[0, 1])
+    d = np.abs(loc - oloc.numpy()).reshape(batch, 98, 2).max(2)
+    margins = helpers.heat_margins(taps)
+    print(f"teacher f16: hm max err {hm_err:.4f} (range {np.abs(ref).max():.1f}), corr {corr:.6f}; landmarks within 1e-3: "
+          f"{(d < 1e-3).mean():.3f}, within 1/64 (one heat-map cell): {(d < 1.0 / 64 + 1e-3).mean():.3f}, max {d.max():.4f}; "
+          f"arg-max margins above 4x the heat-map error: {(margins > 4 * hm_err).mean():.3f}")
+    assert corr > 0.98
+    safe = margins > 4 * hm_err
+    if safe.any():
+        assert d[safe].max() < 4 * hm_err / 64 + 1e-3
