@@ -450,6 +450,34 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 }
                 break;
             }
+            case PF_OP_BLOCK: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "BasicBlock op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    BlockArgs a{};
+                    a.in = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.B = B; a.H = ti.H; a.inLd = ti.ld; a.outLd = to.ld; a.Cs = ti.C;
+                    const int C = f[2];
+                    if (to.C != ti.C || ti.H != to.H || ti.W != to.W || ti.H != ti.W || ti.C < C || ti.C >= C + 4) PF_FAIL(h, "block: tensor shapes");
+                    for (int c = 0; c < 2; ++c) {
+                        a.wt[c] = p.cptr(f[3 + 3 * c]); a.bias[c] = (const float*)p.cptr(f[4 + 3 * c]);
+                        memcpy(&a.acc_scale[c], &f[5 + 3 * c], 4);
+                    }
+                    a.range_slot = guard ? h->d_range + oi : nullptr;
+                    a.dbg = h->dbg;
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "block_c%d_%dx%d", C, ti.H, ti.W);
+                    ProfScope ps(h, tagbuf);
+                    if (C == 18 && ti.W == 64) PF_LAUNCH((basic_block_kernel<18, 64, 4, 7, 1>), dim3(B * (ti.H / 4)), dim3(512), h->stream, a);
+                    else if (C == 36 && ti.W == 32) PF_LAUNCH((basic_block_kernel<36, 32, 8, 1, 2>), dim3(B * (ti.H / 8)), dim3(512), h->stream, a);
+                    else if (C == 18 && ti.W == 16) PF_LAUNCH((basic_block_kernel<18, 16, 8, 7, 1>), dim3(B * (ti.H / 8)), dim3(512), h->stream, a);
+                    else PF_FAIL(h, "block: no kernel for %d channels at %dx%d", C, ti.H, ti.W);
+                }
+                break;
+            }
             case PF_OP_EXPDW: {
                 if constexpr (!SPLIT) {
                     PF_FAIL(h, "fused expand+depthwise op needs a split-precision (f32s) program");

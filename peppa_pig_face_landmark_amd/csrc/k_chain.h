@@ -21,6 +21,7 @@
 #pragma once
 #include "pf_common.h"
 #include "k_conv_gemm.h"
+#include <type_traits>
 
 #define PF_CHAIN_MAX_CONVS 8
 
@@ -224,6 +225,299 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
         if (n < C && !(a.dbg & 32)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) *reinterpret_cast<pf_f32x4*>(out + (size_t)pix[i] * a.outLd + n) = resid[j][i];
+        }
+    }
+    if (a.range_slot) {
+        if (vbad) vmax = __builtin_inff();
+        for (int mask = 1; mask < 64; mask <<= 1) vmax = fmaxf(vmax, pf_shfl_xor_f32(vmax, mask));
+        if (lane == 0) atomicMax(a.range_slot, __float_as_uint(vmax));
+    }
+}
+
+// ---- one BasicBlock per launch on the two high-resolution HRNet branches (18 channels @ 64 x 64, 36 @ 32 x 32) ---------------
+// Those maps do not fit in LDS, and as single convs they are neither HBM- nor matrix-core bound: a workgroup loads its patch,
+// waits, runs nine short tap steps with a barrier each, stores, and the 18 (36) channels are padded to a 32 (64) deep K step
+// and a 32 (48) wide N tile.  Here a workgroup computes TR output rows of one face through BOTH convs:
+//   * x patch (TR + 4 rows, zero ring) -> split hi / lo planes in LDS, ONE load of the tensor per block instead of two plus
+//     the intermediate's round trip;
+//   * K is the flattened (tap, 8-channel group) axis: pixel rows in the planes are CG x 16 bytes (CG = ceil(C / 8): 48 / 80
+//     bytes, conflict-free for 16-byte fragment reads), a 32-deep MFMA step takes four consecutive (tap, group) pairs, each
+//     lane reading ITS pair's shifted pixel -- 7 steps instead of 9 at 18 channels, 12 instead of 18 at 36;
+//   * conv1 runs on TR + 2 rows (one-row halo recompute), its relu output is split in registers and parked over the x planes
+//     (rows outside the image as zeros: they are conv2's padding), conv2 runs on the TR rows, and the f32 residual -- read
+//     from global at the start -- is added in the epilogue;
+//   * weights: [Npad][NCH][hi 32 | lo 32] with k = tap * 8 CG + c (ir.pack_flatk_weight); G chunks per LDS stage, either the
+//     whole conv at once (NBUF = 1: no barrier inside a conv) or double-buffered per chunk (NBUF = 2).
+template <int C, int W, int TR, int G, int NBUF>
+struct BlockCfg {
+    static constexpr int CG = (C + 7) / 8;               // 8-channel groups per pixel
+    static constexpr int ROWB = CG * 16;                 // bytes per pixel in one plane
+    static constexpr int KG = 9 * CG;                    // (tap, group) pairs
+    static constexpr int NCH = (KG + 3) / 4;             // 32-deep K steps
+    static constexpr int NTILES = (C + 15) / 16;
+    static constexpr int BN = NTILES * 16;
+    static constexpr int W2 = W + 2;
+    static constexpr int XROWS = TR + 4;
+    static constexpr int PLANE = XROWS * W2 * ROWB;      // hi (or lo) plane of the x patch; y1 reuses the first TR + 2 rows
+    static constexpr int M1T = (TR + 2) * W / 16, M2T = TR * W / 16;
+    static constexpr int MT1 = (M1T + 7) / 8, MT2 = M2T / 8;
+    static constexpr int NG = (NCH + G - 1) / G;         // weight stages per conv
+    static constexpr int WSLOTS = G * BN * 8;            // 16-byte slots of one weight stage
+    static constexpr int WROUNDS = (WSLOTS + 511) / 512;
+    static constexpr int W_BYTES = WSLOTS * 16;
+    static constexpr int LDS = 2 * PLANE + NBUF * W_BYTES;
+};
+
+struct BlockArgs {
+    const float* in;      // [B][H][W][inLd], channels [C, Cs) zero
+    float* out;           // [B][H][W][outLd]
+    int B, H, inLd, outLd, Cs;
+    const void* wt[2];    // flat-K split weights of conv1 / conv2
+    const float* bias[2]; // [BN]
+    float acc_scale[2];
+    unsigned* range_slot;
+    int dbg;
+};
+
+template <int C, int W, int TR, int G, int NBUF>
+__global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
+    using K = BlockCfg<C, W, TR, G, NBUF>;
+    constexpr int CG = K::CG, ROWB = K::ROWB, NCH = K::NCH, NTILES = K::NTILES, BN = K::BN, W2 = K::W2, PLANE = K::PLANE;
+    constexpr int MT1 = K::MT1, MT2 = K::MT2, NT = NTILES;
+    static_assert(W % 16 == 0 && K::M2T % 8 == 0 && (NBUF == 1 ? K::NG == 1 : G == 1), "tile shape");
+    static_assert(K::LDS <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[K::LDS];
+    unsigned char* xh = smem;
+    unsigned char* xl = smem + PLANE;
+    unsigned char* wbase = smem + 2 * PLANE;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int frow = lane & 15, fchunk = lane >> 4;
+    const int crow = fchunk * 4;
+    const int tiles_per_face = a.H / TR;
+    const int face = blockIdx.x / tiles_per_face;
+    const int y0 = (blockIdx.x - face * tiles_per_face) * TR;
+    const float* __restrict__ in = a.in + (size_t)face * a.H * W * a.inLd;
+    float* __restrict__ out = a.out + (size_t)face * a.H * W * a.outLd;
+
+    auto load_w = [&](int conv, int g, int buf) {
+        const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt[conv]);
+        unsigned char* wdst = wbase + buf * K::W_BYTES;
+#pragma unroll
+        for (int c = 0; c < K::WROUNDS; ++c) {
+            const int sl = t + 512 * c;
+            const int q = sl / (BN * 8);                 // chunk within the stage
+            const int s = sl - q * (BN * 8);
+            if (sl < K::WSLOTS && g * G + q < NCH) {
+                const int plane = s >= BN * 4 ? 1 : 0;
+                const int row = (s - plane * BN * 4) >> 2;
+                const int chunk = ((s & 3) - 2 * (row >> 2)) & 3;
+                pf_glds16(wt + ((size_t)row * NCH + g * G + q) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
+            }
+        }
+    };
+
+    // ---- x patch: zero fill, then the rows that exist, split to hi / lo --------------------------------------------------------
+    load_w(0, 0, 0);
+    for (int o = t * 16; o < 2 * PLANE; o += 512 * 16) *reinterpret_cast<pf_f32x4*>(smem + o) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int XUNITS = K::XROWS * W * CG;
+    constexpr int XU = (XUNITS + 511) / 512;
+    pf_f32x4 xreg[XU][2];
+    int xdst[XU];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        const int id = t + 512 * u;
+        const int px = id / CG, cg = id - px * CG;
+        const int xr = px / W, xc = px - xr * W;
+        const int iy = y0 - 2 + xr;
+        const bool ok = id < XUNITS && (unsigned)iy < (unsigned)a.H;
+        xdst[u] = ok ? (xr * W2 + xc + 1) * ROWB + cg * 16 : -1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && cg * 8 + 4 * h < a.Cs) v = *reinterpret_cast<const pf_f32x4*>(in + (size_t)(iy * W + xc) * a.inLd + cg * 8 + 4 * h);
+            xreg[u][h] = v;
+        }
+    }
+    // this wave's output tiles: conv1 tile i covers pixels (tile * 16 ..) of the (TR + 2) x W region, conv2 of the TR x W region
+    int hp1[MT1], hp2[MT2], opix[MT2];
+#pragma unroll
+    for (int i = 0; i < MT1; ++i) {
+        const int p = (i * 8 + wave) * 16 + frow;
+        const int r = p / W, c = p - r * W;
+        hp1[i] = (r * W2 + c) * ROWB;
+    }
+#pragma unroll
+    for (int i = 0; i < MT2; ++i) {
+        const int p = (i * 8 + wave) * 16 + frow;
+        const int r = p / W, c = p - r * W;
+        hp2[i] = (r * W2 + c) * ROWB;
+        opix[i] = (y0 + r) * W + c;
+    }
+    // residual: x at this lane's output pixels / channels (accumulator layout), in flight while conv1 runs
+    pf_f32x4 resid[NT][MT2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) {
+            const int n = j * 16 + crow;
+            pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (n < a.Cs) v = *reinterpret_cast<const pf_f32x4*>(in + (size_t)opix[i] * a.inLd + n);
+            resid[j][i] = v;
+        }
+    // per K step, this lane's (tap, channel group) offset inside a plane
+    int koff[NCH];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+        int kg = q * 4 + fchunk;
+        if (kg >= K::KG) kg = 0;                          // zero weights there; any finite operand will do
+        const int tap = kg / CG, cg = kg - tap * CG;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        koff[q] = (ky * W2 + kx) * ROWB + cg * 16;
+    }
+    float vmax = 0.f;
+    bool vbad = false;
+    __syncthreads();                                      // zero fill done
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+        if (xdst[u] < 0) continue;
+        pf_half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = xreg[u][e >> 2][e & 3];
+            const pf_half hv = (pf_half)v;
+            hi[e] = hv;
+            lo[e] = (pf_half)(v - (float)hv);
+            const float av = fabsf(v);
+            vbad |= !(av == av);
+            vmax = fmaxf(vmax, av);
+        }
+        *reinterpret_cast<pf_half8*>(xh + xdst[u]) = hi;
+        *reinterpret_cast<pf_half8*>(xl + xdst[u]) = lo;
+    }
+    __syncthreads();                                      // planes and the first weight stage are in place
+
+    // one conv over this wave's MT tiles; weights stage `buf` holds chunk group g
+    auto mma_group = [&](auto& acc, const int* hp, auto mt_tag, int ntl, int g, int buf) {
+        constexpr int MT = decltype(mt_tag)::value;
+#pragma unroll
+        for (int qq = 0; qq < G; ++qq) {
+            const int q = g * G + qq;
+            if (q >= NCH) break;
+            const unsigned char* wh = wbase + buf * K::W_BYTES + qq * (BN * 128);
+            const unsigned char* wl = wh + BN * 64;
+            pf_half8 xhf[MT], xlf[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                if (i >= ntl) break;
+                xhf[i] = *reinterpret_cast<const pf_half8*>(xh + hp[i] + koff[q]);
+                xlf[i] = *reinterpret_cast<const pf_half8*>(xl + hp[i] + koff[q]);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int off = pf_lds_chunk_off(j * 16 + frow, fchunk);
+                const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wh + off);
+                const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wl + off);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    if (i >= ntl) break;
+                    acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
+                    acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
+                    acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
+                }
+            }
+        }
+    };
+    using Tag1 = std::integral_constant<int, MT1>;
+    using Tag2 = std::integral_constant<int, MT2>;
+    // tiles of conv1 this wave owns (the last round may be ragged)
+    const int nt1 = (K::M1T - wave + 7) / 8;
+
+    // ---- conv1 -----------------------------------------------------------------------------------------------------------------------
+    pf_f32x4 acc1[NT][MT1];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT1; ++i) acc1[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    if constexpr (NBUF == 1) {
+        if (!(a.dbg & 16)) mma_group(acc1, hp1, Tag1{}, nt1, 0, 0);
+        __syncthreads();                                  // everybody is done with x and with conv1's weights
+        load_w(1, 0, 0);
+    } else {
+        for (int g = 0; g < K::NG; ++g) {
+            if (g + 1 < K::NG) load_w(0, g + 1, buf ^ 1); else load_w(1, 0, buf ^ 1);
+            if (!(a.dbg & 16)) mma_group(acc1, hp1, Tag1{}, nt1, g, buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // ---- relu(conv1 + b1) -> split -> over the x planes (pixel (r, c) of the y1 region at plane pixel (r, c + 1)) --------------------
+    {
+        const float sc = a.acc_scale[0];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + crow;
+            if (n >= CG * 8) continue;                    // beyond the channel groups a plane row holds
+            const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(a.bias[0] + n);
+#pragma unroll
+            for (int i = 0; i < MT1; ++i) {
+                if (i >= nt1) break;
+                const int p = (i * 8 + wave) * 16 + frow;
+                const int r = p / W;
+                const bool inside = (unsigned)(y0 - 1 + r) < (unsigned)a.H;
+                pf_half4 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = pf_act_c<PF_ACT_RELU>(acc1[j][i][e] * sc + bv[e]);
+                    if (!inside) v = 0.f;
+                    const pf_half hv = (pf_half)v;
+                    hi[e] = hv;
+                    lo[e] = (pf_half)(v - (float)hv);
+                    const float av = fabsf(v);
+                    vbad |= !(av == av);
+                    vmax = fmaxf(vmax, av);
+                }
+                const int off = hp1[i] + ROWB + (n >> 3) * 16 + (n & 4) * 2;
+                *reinterpret_cast<pf_half4*>(xh + off) = hi;
+                *reinterpret_cast<pf_half4*>(xl + off) = lo;
+            }
+        }
+    }
+    __syncthreads();                                      // y1 parked (and, NBUF == 1, conv2's weights landed)
+
+    // ---- conv2 -----------------------------------------------------------------------------------------------------------------------
+    pf_f32x4 acc2[NT][MT2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT2; ++i) acc2[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (NBUF == 1) {
+        if (!(a.dbg & 16)) mma_group(acc2, hp2, Tag2{}, MT2, 0, 0);
+    } else {
+        for (int g = 0; g < K::NG; ++g) {
+            if (g + 1 < K::NG) load_w(1, g + 1, buf ^ 1);
+            if (!(a.dbg & 16)) mma_group(acc2, hp2, Tag2{}, MT2, g, buf);
+            if (g + 1 < K::NG) __syncthreads();
+            buf ^= 1;
+        }
+    }
+    {
+        const float sc = a.acc_scale[1];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 16 + crow;
+            if (n >= a.Cs || (a.dbg & 32)) continue;
+            const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(a.bias[1] + n);
+#pragma unroll
+            for (int i = 0; i < MT2; ++i) {
+                pf_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = pf_act_c<PF_ACT_RELU>(acc2[j][i][e] * sc + bv[e] + resid[j][i][e]);
+                *reinterpret_cast<pf_f32x4*>(out + (size_t)opix[i] * a.outLd + n) = v;
+            }
         }
     }
     if (a.range_slot) {

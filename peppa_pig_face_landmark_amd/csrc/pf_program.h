@@ -52,6 +52,8 @@ enum PfOpCode : int32_t {
     PF_OP_EXPDW = 15,   // f: in_t out_t gap_buf w_exp b_exp w_dw b_dw K pad dil act Cpad Npad N acc_scale(float bits) stride(0 = 1)
     PF_OP_CHAIN = 16,   // f: in_t out_t n_convs C then n_convs x (wt bias acc_scale(float bits)): chain of BasicBlocks (two 3x3
                         //    convs + identity residual each), one face's map resident in LDS (k_chain.h); split programs only
+    PF_OP_BLOCK = 17,   // f: in_t out_t C wt1 b1 s1 wt2 b2 s2 (s = acc_scale float bits): one BasicBlock, TR rows per workgroup, flat-K
+                        //    weights (k_chain.h basic_block_kernel); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip)
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

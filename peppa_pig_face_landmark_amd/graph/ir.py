@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN = range(1, 17)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK = range(1, 18)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -396,6 +396,49 @@ class ProgramBuilder:
                 b[:c] = bias
                 fields += [woff, self.const_f32(b), struct.unpack("<i", struct.pack("<f", acc_scale))[0]]
         self._op(OP_CHAIN, fields, [self._tb(x)], [self._tb(out)])
+        return out
+
+    BLOCK_SHAPES = ((18, 64), (36, 32), (18, 16))   # (channels, map side) with a basic_block_kernel instantiation
+
+    def basic_block_supported(self, x: int) -> bool:
+        ti = self.tensors[x]
+        return self.split and ti.H == ti.W and (ti.real_c, ti.H) in self.BLOCK_SHAPES and ti.C == _round_up(ti.real_c, 4)
+
+    def pack_flatk_weight(self, weight: np.ndarray) -> Tuple[int, int, float]:
+        """[N,C,3,3] -> (const offset, Npad, acc_scale): split weights with the (tap, 8-channel group) axis flattened,
+        [Npad][NCH][hi 32 x f16 | lo 32 x f16] of w * 2^s, k = tap * 8 * ceil(C/8) + c, NCH = ceil(9 * ceil(C/8) / 4)."""
+        n, c, kh, kw = weight.shape
+        assert (kh, kw) == (3, 3)
+        cg = (c + 7) // 8
+        nch = (9 * cg + 3) // 4
+        npad = _round_up(n, 16)
+        w = np.zeros((npad, 9, cg * 8), np.float64)
+        w[:n, :, :c] = np.transpose(weight.astype(np.float64), (0, 2, 3, 1)).reshape(n, 9, c)
+        flat = np.zeros((npad, nch * 32), np.float64)
+        flat[:, :9 * cg * 8] = w.reshape(npad, 9 * cg * 8)
+        wmax = float(np.abs(flat).max())
+        s = 0 if wmax == 0.0 else int(np.floor(np.log2(16384.0 / wmax)))
+        ws = (flat * (2.0 ** s)).astype(np.float32)
+        hi = ws.astype(np.float16)
+        lo = (ws - hi.astype(np.float32)).astype(np.float16)
+        blocks = np.stack([hi.reshape(npad, nch, 32), lo.reshape(npad, nch, 32)], axis=2)
+        return self.const(np.ascontiguousarray(blocks)), npad, float(2.0 ** (-s))
+
+    def basic_block(self, x: int, w1: np.ndarray, b1: np.ndarray, w2: np.ndarray, b2: np.ndarray, out_name: str = "") -> int:
+        """relu(conv2(relu(conv1(x))) + x), BN folded, 3x3 / stride 1 / pad 1, C -> C, one launch (k_chain.h basic_block_kernel)."""
+        ti = self.tensors[x]
+        assert self.basic_block_supported(x)
+        c = ti.real_c
+        out = self.tensor(ti.H, ti.W, ti.C, name=out_name)
+        self.tensors[out].real_c = c
+        fields = [x, out, c]
+        for wgt, bias in ((w1, b1), (w2, b2)):
+            assert wgt.shape == (c, c, 3, 3)
+            woff, npad, acc_scale = self.pack_flatk_weight(wgt)
+            b = np.zeros(npad, np.float64)
+            b[:c] = bias
+            fields += [woff, self.const_f32(b), struct.unpack("<i", struct.pack("<f", acc_scale))[0]]
+        self._op(OP_BLOCK, fields, [self._tb(x)], [self._tb(out)])
         return out
 
     def upcat(self, lo: int, skip: int, out_name: str = "") -> int:

@@ -74,7 +74,10 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                     xs[br] = pb.basic_chain(xs[br], [basic_folded(f"{p}.branches.{br}.{blk}") for blk in range(4)])
                     continue
                 for blk in range(4):
-                    xs[br] = basic(xs[br], f"{p}.branches.{br}.{blk}")
+                    if fuse_chains and pb.basic_block_supported(xs[br]):               # both convs of the block in one launch
+                        xs[br] = pb.basic_block(xs[br], *basic_folded(f"{p}.branches.{br}.{blk}"))
+                    else:
+                        xs[br] = basic(xs[br], f"{p}.branches.{br}.{blk}")
             fused = []
             for i in range(nb):
                 last_stage_module = (m == modules - 1)

@@ -86,3 +86,41 @@ def test_narrow_halo_convs_emu(emu_engine, c, hw, batch):
 @pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2)])
 def test_narrow_halo_convs_gpu(gpu_engine, c, hw, batch):
     _narrow_conv_case(gpu_engine, c, hw, batch, seed=400 + c + hw)
+
+
+def _block_case(eng, c, hw, batch, n_blocks, seed):
+    """PF_OP_BLOCK (both convs of a BasicBlock in one launch, flat-K weights, one-row halo recompute) against the two separate
+    conv launches, chained n_blocks deep; rows at the top / bottom image border and the ragged last conv1 tile round included."""
+    rng = np.random.default_rng(seed)
+    pb = ir.ProgramBuilder("f32s", 2 * hw, 2 * hw, keep_all=True)
+    f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+    x = pb.conv(f0, rng.normal(0, 0.35, (c, 16, 1, 1)), rng.normal(0, 0.2, c), "none", out_name="x")
+    std = np.sqrt(2.0 / (9 * c))
+    y = r = x
+    for i in range(n_blocks):
+        w1, b1, w2, b2 = rng.normal(0, std, (c, c, 3, 3)), rng.normal(0, 0.05, c), rng.normal(0, 0.6 * std, (c, c, 3, 3)), rng.normal(0, 0.05, c)
+        assert pb.basic_block_supported(y)
+        y = pb.basic_block(y, w1, b1, w2, b2, out_name=f"fused.block{i}")
+        m = pb.conv(r, w1, b1, "relu", pad=1)
+        r = pb.conv(m, w2, b2, "relu", pad=1, res=r, out_name=f"ref.block{i}")
+    blob = pb.finish([pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")])
+    eng.load_program(0, blob, batch)
+    eng.landmark_forward(rng.integers(0, 256, (batch, 2 * hw, 2 * hw, 3), dtype=np.uint8))
+    cp = (c + 3) // 4 * 4
+    for i in range(n_blocks):
+        got = eng.read_tensor(0, pb.tensor_names[f"fused.block{i}"], batch, (hw, hw, cp))
+        ref = eng.read_tensor(0, pb.tensor_names[f"ref.block{i}"], batch, (hw, hw, cp))
+        assert np.abs(ref).max() > 0.1 and not got[..., c:].any()
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        assert rel < 1e-5, (c, hw, i, rel)
+
+
+@pytest.mark.parametrize("c,hw,batch,n_blocks", [(18, 16, 3, 2), (18, 64, 1, 1), (36, 32, 1, 2)])
+def test_block_equals_separate_convs_emu(emu_engine, c, hw, batch, n_blocks):
+    _block_case(emu_engine, c, hw, batch, n_blocks, seed=500 + c + hw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,hw,batch,n_blocks", [(18, 64, 5, 4), (36, 32, 7, 4), (18, 16, 9, 2), (18, 64, 130, 1)])
+def test_block_equals_separate_convs_gpu(gpu_engine, c, hw, batch, n_blocks):
+    _block_case(gpu_engine, c, hw, batch, n_blocks, seed=600 + c + hw)
