@@ -114,9 +114,15 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
                     if (n + r < a.Npad) v[r] += a.fbias[(size_t)b * a.Npad + n + r];
             }
             if (res && mok) {
+                if (sizeof(T) == 4 && n + 3 < a.N && (a.resLd & 3) == 0) {      // one 16-byte load (views start on vector boundaries)
+                    const pf_f32x4 rv = *reinterpret_cast<const pf_f32x4*>(reinterpret_cast<const float*>(res) + (size_t)m * a.resLd + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.N) v[r] += (float)res[(size_t)m * a.resLd + n + r];
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r < a.N) v[r] += (float)res[(size_t)m * a.resLd + n + r];
+                }
             }
             pf_act_n<4>(v, a.act);
             if (want_amax && mok) {
