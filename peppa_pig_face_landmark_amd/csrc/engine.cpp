@@ -444,8 +444,10 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "chain%d_c%d_%dx%d", a.n_convs, C, ti.H, ti.W);
                     ProfScope ps(h, tagbuf);
-                    if (C == 72 && ti.H == 16) PF_LAUNCH((basic_chain_kernel<72, 16, 8, 1, 5>), dim3(B), dim3(512), h->stream, a);
-                    else if (C == 144 && ti.H == 8) PF_LAUNCH((basic_chain_kernel<144, 8, 4, 2, 5>), dim3(B), dim3(512), h->stream, a);
+                    // 16 / 12 waves per workgroup and a 3 / 4-stage weight ring: measured against 8 waves and against two stages
+                    // (profiles/r02_run14_teacher_*): 1.30 vs 1.38 / 1.39 ms and 0.68 vs 0.75 / 0.83 ms per 64 faces
+                    if (C == 72 && ti.H == 16) PF_LAUNCH((basic_chain_kernel<72, 16, 8, 2, 3, 3>), dim3(B), dim3(1024), h->stream, a);
+                    else if (C == 144 && ti.H == 8) PF_LAUNCH((basic_chain_kernel<144, 8, 4, 3, 3, 4>), dim3(B), dim3(768), h->stream, a);
                     else PF_FAIL(h, "chain: no kernel for %d channels at %dx%d", C, ti.H, ti.W);
                 }
                 break;

@@ -12,8 +12,12 @@
 //   * each wave keeps the f32 values of ITS output tile in registers for the whole chain: the accumulators of the conv in
 //     flight plus the block input it will need for the residual add.  Between two convs the wave splits its tile to hi / lo
 //     and overwrites its part of the planes (after a barrier: every wave has finished reading the previous tensor);
-//   * weights stream per (tap, 32-channel chunk) by LDS-DMA into two stages, one barrier per stage, prefetched across the
-//     conv boundaries.
+//   * weights stream per (tap, 32-channel chunk) by LDS-DMA into a ring of NSTG stages, one barrier per stage, running ahead
+//     across the conv boundaries.  The requests are issued from inline asm (pf_glds16_raw) and retired with partial vmcnt
+//     waits: with compiler-visible LDS-DMA every fragment read waits for ALL pending requests and the ring degenerates to
+//     one round trip per stage (0.88 us per stage measured, with or without the MFMAs);
+//   * 16 (72 channels) / 12 (144 channels) waves per workgroup: three to four waves per SIMD overlap one wave's fragment reads
+//     with another's MFMAs between the per-stage barriers (profiles/r02_run14_teacher_chain_variants.md).
 // HBM traffic per chain: the map in, the map out, the weights once per workgroup (L2 resident).  The arithmetic is the one
 // conv_gemm_split_kernel does on the same f32 tensors: activations split at the same point (hi = f16(v), lo = f16(v - hi)),
 // three v_mfma_f32_16x16x32_f16 per product, f32 accumulate, f32 bias / residual / relu.
@@ -37,9 +41,9 @@ struct ChainArgs {
     int dbg;
 };
 
-template <int C, int HW, int WARPS_M, int WARPS_N, int NT>
-__global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
-    constexpr int NTHR = 512;
+template <int C, int HW, int WARPS_M, int WARPS_N, int NT, int NSTG>
+__global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void basic_chain_kernel(ChainArgs a) {
+    constexpr int NTHR = WARPS_M * WARPS_N * 64;
     constexpr int CBLK = (C + 31) / 32;
     constexpr int NTILES = (C + 15) / 16;
     constexpr int BN = NTILES * 16;
@@ -51,12 +55,17 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
     constexpr int PLANE = HP * 64;                       // one (chunk, hi | lo) plane
     constexpr int ACT_BYTES = CBLK * 2 * PLANE;
     constexpr int WSLOTS = BN * 8;                       // 16-byte slots of one weight stage (hi plane, then lo plane)
-    constexpr int WCHUNKS = (WSLOTS + NTHR - 1) / NTHR;
-    constexpr int W_BYTES = WCHUNKS * NTHR * 16;
-    static_assert(WARPS_M * WARPS_N == 8 && WM % 16 == 0 && WARPS_N * NT >= NTILES && C % 4 == 0, "tile shape");
-    static_assert(ACT_BYTES + 2 * W_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + 2 * W_BYTES];
+    constexpr int WCHUNKS = (WSLOTS + NTHR - 1) / NTHR;      // LDS-DMA requests of a full wave per stage ...
+    constexpr int WFULL = (WSLOTS % NTHR) / 64;              // ... the last round is issued by the first WFULL waves only
+    constexpr int W_BYTES = WSLOTS * 16;
+    constexpr int AHEAD = NSTG - 1;                          // stages in flight
+    static_assert(NTHR <= 1024 && (WARPS_M * WARPS_N) % 4 == 0 && WM % 16 == 0 && WARPS_N * NT >= NTILES && C % 4 == 0, "tile shape");
+    static_assert(WSLOTS % 64 == 0 && WFULL > 0 && NSTG >= 2 && (AHEAD - 1) * WCHUNKS < 64, "weight ring");
+    constexpr int BIAS_BYTES = PF_CHAIN_MAX_CONVS * BN * 4;  // every conv's bias: no VMEM besides the weight ring inside the chain
+    static_assert(ACT_BYTES + NSTG * W_BYTES + BIAS_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[ACT_BYTES + NSTG * W_BYTES + BIAS_BYTES];
     unsigned char* wbase = smem + ACT_BYTES;
+    float* sbias = reinterpret_cast<float*>(smem + ACT_BYTES + NSTG * W_BYTES);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -71,9 +80,14 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
     // ---- zero the planes (halo ring and padding channels stay zero for the whole chain) ------------------------------
     for (int o = t * 16; o < ACT_BYTES; o += NTHR * 16) *reinterpret_cast<pf_f32x4*>(smem + o) = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto load_w = [&](int conv, int tap, int cb, int stage) {
+    // weight stage `s` of the chain (s = conv * NK + tap * CBLK + cb) -> ring slot s % NSTG
+    constexpr int NK = 9 * CBLK;
+    const int n_stages = a.n_convs * NK;
+    auto load_w = [&](int s) {
+        if (s >= n_stages) return;
+        const int conv = s / NK, kt = s - conv * NK;
         const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt[conv]);
-        unsigned char* wdst = wbase + stage * W_BYTES;
+        unsigned char* wdst = wbase + (s % NSTG) * W_BYTES;
 #pragma unroll
         for (int c = 0; c < WCHUNKS; ++c) {
             const int sl = t + NTHR * c;
@@ -81,8 +95,17 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
                 const int plane = sl >= BN * 4 ? 1 : 0;
                 const int row = (sl - plane * BN * 4) >> 2;
                 const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                pf_glds16(wt + ((size_t)(row * 9 + tap) * CBLK + cb) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
+                pf_glds16_raw(wt + ((size_t)row * NK + kt) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
             }
+        }
+    };
+    // "stage s has landed": everything this wave issued except the AHEAD - 1 younger stages is complete
+    auto wait_stage = [&](int s) {
+        if (s + AHEAD - 1 < n_stages) {
+            if (wave < WFULL) pf_wait_vm_barrier<(AHEAD - 1) * WCHUNKS>();
+            else pf_wait_vm_barrier<(AHEAD - 1) * (WCHUNKS - 1)>();
+        } else {
+            pf_wait_vm_barrier<0>();                       // the chain's last stages: drain
         }
     };
 
@@ -142,12 +165,12 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
             if (j < njt && n < C) v = *reinterpret_cast<const pf_f32x4*>(in + (size_t)pix[i] * a.inLd + n);
             resid[j][i] = v;
         }
-    load_w(0, 0, 0, 0);
-    __syncthreads();                                     // zero fill complete before anybody parks values
+    for (int i = t; i < a.n_convs * BN; i += NTHR) sbias[i] = a.bias[i / BN][i % BN];
+    __syncthreads();                                     // zero fill complete before anybody parks values (drains the x loads too)
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s) load_w(s);
     park(resid);
-    __syncthreads();
 
-    constexpr int NK = 9 * CBLK;
     int stage = 0;
     for (int conv = 0; conv < a.n_convs; ++conv) {
 #pragma unroll
@@ -155,11 +178,11 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         int tap = 0, cb = 0;
-        for (int kt = 0; kt < NK; ++kt) {
+        for (int kt = 0; kt < NK; ++kt, ++stage) {
             const bool last_cb = cb == CBLK - 1;
-            if (kt + 1 < NK) load_w(conv, last_cb ? tap + 1 : tap, last_cb ? 0 : cb + 1, stage ^ 1);
-            else if (conv + 1 < a.n_convs) load_w(conv + 1, 0, 0, stage ^ 1);
-            const unsigned char* wh = wbase + stage * W_BYTES;
+            wait_stage(stage);                           // this stage's weights landed; everybody left the previous stage (and parked)
+            load_w(stage + AHEAD);                       // into the slot the previous stage just released
+            const unsigned char* wh = wbase + (stage % NSTG) * W_BYTES;
             const unsigned char* wl = wh + BN * 64;
             const unsigned char* xh = smem + (size_t)(cb * 2) * PLANE;
             const unsigned char* xl = xh + PLANE;
@@ -187,13 +210,11 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
                     for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
                 }
             }
-            __syncthreads();
-            stage ^= 1;
             if (last_cb) { cb = 0; ++tap; } else ++cb;
         }
         // ---- epilogue in registers: bias, (residual), relu; the result is the next conv's operand ---------------------------
         const float sc = a.acc_scale[conv];
-        const float* __restrict__ bias = a.bias[conv];
+        const float* bias = sbias + conv * BN;
         const bool second = (conv & 1) != 0;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -212,8 +233,8 @@ __global__ __launch_bounds__(512, 2) void basic_chain_kernel(ChainArgs a) {
             }
         }
         if (conv + 1 < a.n_convs) {
-            park(acc);                                   // every wave left the K loop through a barrier: the planes are free
-            __syncthreads();
+            pf_wait_vm_barrier<63>();                    // everybody is done reading the planes (weights stay in flight)
+            park(acc);                                   // made visible by the next stage's barrier
         }
     }
 

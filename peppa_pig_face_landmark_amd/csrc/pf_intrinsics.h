@@ -51,6 +51,17 @@ __device__ __forceinline__ void pf_glds16(const void* gsrc, void* lds_lane_ptr) 
                                      (__attribute__((address_space(3))) void*)lds_lane_ptr, 16, 0, 0);
 }
 
+// The same copy issued from inline assembly.  The compiler orders every ds_read behind ALL pending LDS-DMA it knows about
+// (s_waitcnt vmcnt(0) before the read), which serialises a ring of more than two stages; requests issued here are invisible
+// to that bookkeeping, so the caller owns the ordering: pf_wait_vm_barrier<N>() before anybody reads the bytes.  m0 is saved
+// and restored because the compiler may hold a value there.
+__device__ __forceinline__ void pf_glds16_raw(const void* gsrc, void* lds_lane_ptr) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_lane_ptr);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(base) : "memory");
+}
+
 // Workgroup barrier that leaves the wave's N youngest VMEM operations (LDS-DMA requests, global loads) in flight:
 // "s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier".  __syncthreads() drains vmcnt to 0, which ends every software-pipeline
 // stage with a full global-memory latency; LDS-DMA stays in flight across s_barrier (MI355X_MICROARCH.md).

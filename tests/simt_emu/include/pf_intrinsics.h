@@ -80,6 +80,7 @@ template <int STEP> inline float pf_row_xchg_f32(float v) {
 inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
 inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
+inline void pf_glds16_raw(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
 
 template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous
 
