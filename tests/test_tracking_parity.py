@@ -79,7 +79,10 @@ def _compare(make_facer, reference, track_dtype=None):
                 for key in ("box", "kps"):
                     x, y = np.asarray(a[key], np.float64), np.asarray(b[key], np.float64)
                     assert (np.abs(x - y) / np.maximum(300.0, np.abs(x))).max() < 1e-3, (i, key)
-                assert np.abs(a["scores"] - b["scores"]).max() < 5e-3, i
+                # scores are heat-map maxima, up to ~100 with these weights at 64 x 64: judged against the face's heat-map range
+                # (1e-4 of it; the landmark nets' own parity tests hold 3e-3..5e-3 on O(1..30) maps)
+                sa, sb = np.asarray(a["scores"], np.float64), np.asarray(b["scores"], np.float64)
+                assert np.abs(sa - sb).max() < 1e-3 + 1e-4 * np.abs(sa).max(), i
         # (under numpy 1.23 -- the reference's pin -- track_box turns float64 after the first frame; under numpy >= 2 it
         # stays float32.  The facade follows whatever numpy does, as asserted per frame above; the float64 crop path of
         # the engine is pinned by tests/test_emu_pipeline.py::test_crop_faces_float64_rows_bit_exact.)
@@ -154,7 +157,10 @@ def _device_vs_host(library, student_weights, detector_weights):
                 for key in ("box", "kps"):
                     x, y = np.asarray(a[key], np.float64), np.asarray(b[key], np.float64)
                     assert (np.abs(x - y) / np.maximum(300.0, np.abs(x))).max() < 1e-3, (i, key)
-                assert np.abs(a["scores"] - b["scores"]).max() < 5e-3, i
+                # scores are heat-map maxima, up to ~100 with these weights at 64 x 64: judged against the face's heat-map range
+                # (1e-4 of it; the landmark nets' own parity tests hold 3e-3..5e-3 on O(1..30) maps)
+                sa, sb = np.asarray(a["scores"], np.float64), np.asarray(b["scores"], np.float64)
+                assert np.abs(sa - sb).max() < 1e-3 + 1e-4 * np.abs(sa).max(), i
         dev.reset()
         host.reset()
         state["i"] = 0
