@@ -96,3 +96,45 @@ def test_facade_falls_back_to_f32_emulator(emu_library, student_weights):
 @pytest.mark.gpu
 def test_facade_falls_back_to_f32_gpu(hip_library, student_weights):
     _facade_fallback(hip_library, student_weights, 256)
+
+
+def _fused_hrnet_guard(make_engine):
+    """PF_OP_CHAIN / PF_OP_BLOCK split intermediates that never reach HBM: an overflow INSIDE the op (block input in range,
+    conv1's output beyond f16) must be reported by the op itself."""
+    from peppa_pig_face_landmark_amd.graph import ir
+    for c, hw, fused in ((72, 16, "chain"), (18, 16, "block")):
+        for boost, fails in ((1.0, False), (4.0e5, True)):
+            rng = np.random.default_rng(77 + c)
+            pb = ir.ProgramBuilder("f32s", 2 * hw, 2 * hw)
+            f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+            x = pb.conv(f0, rng.normal(0, 0.35, (c, 16, 1, 1)), rng.normal(0, 0.2, c), "none")
+            std = np.sqrt(2.0 / (9 * c))
+            w1, b1 = rng.normal(0, std, (c, c, 3, 3)) * boost, rng.normal(0, 0.05, c)      # conv1's output reaches ~1e5
+            w2, b2 = rng.normal(0, std, (c, c, 3, 3)) / boost, rng.normal(0, 0.05, c)
+            y = pb.basic_chain(x, [(w1, b1, w2, b2)]) if fused == "chain" else pb.basic_block(x, w1, b1, w2, b2)
+            # the outputs must be activation buffers of the right size; a 1x1 conv to 4 channels gives (hw*hw*4) floats -- use
+            # plain F32 buffers instead and keep y alive through a consumer
+            pb.conv(y, rng.normal(0, 0.1, (16, c, 1, 1)), np.zeros(16), "none")
+            blob = pb.finish([pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")])
+            eng = make_engine()
+            try:
+                eng.load_program(0, blob, 2)
+                crops = rng.integers(0, 256, (2, 2 * hw, 2 * hw, 3), dtype=np.uint8)
+                if fails:
+                    with pytest.raises(_native.PeppaHipError, match="activation range check failed.*above"):
+                        eng.landmark_forward(crops)
+                else:
+                    eng.landmark_forward(crops)
+            finally:
+                eng.close()
+
+
+def test_fused_hrnet_ops_report_internal_overflow_emulator(emu_library):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _fused_hrnet_guard(lambda: Engine(0, emu_library))
+
+
+@pytest.mark.gpu
+def test_fused_hrnet_ops_report_internal_overflow_gpu(hip_library):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _fused_hrnet_guard(lambda: Engine(0, hip_library))
