@@ -388,16 +388,14 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
             if (n < a.Cs) v = *reinterpret_cast<const pf_f32x4*>(in + (size_t)opix[i] * a.inLd + n);
             resid[j][i] = v;
         }
-    // per K step, this lane's (tap, channel group) offset inside a plane
-    int koff[NCH];
-#pragma unroll
-    for (int q = 0; q < NCH; ++q) {
+    // per K step q, this lane's (tap, channel group) pair kg = 4 q + fchunk -> byte offset inside a plane
+    auto koff = [&](int q) {
         int kg = q * 4 + fchunk;
         if (kg >= K::KG) kg = 0;                          // zero weights there; any finite operand will do
         const int tap = kg / CG, cg = kg - tap * CG;
         const int ky = tap / 3, kx = tap - ky * 3;
-        koff[q] = (ky * W2 + kx) * ROWB + cg * 16;
-    }
+        return (ky * W2 + kx) * ROWB + cg * 16;
+    };
     float vmax = 0.f;
     bool vbad = false;
     __syncthreads();                                      // zero fill done
@@ -430,11 +428,12 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
             const unsigned char* wh = wbase + buf * K::W_BYTES + qq * (BN * 128);
             const unsigned char* wl = wh + BN * 64;
             pf_half8 xhf[MT], xlf[MT];
+            const int ko = koff(q);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 if (i >= ntl) break;
-                xhf[i] = *reinterpret_cast<const pf_half8*>(xh + hp[i] + koff[q]);
-                xlf[i] = *reinterpret_cast<const pf_half8*>(xl + hp[i] + koff[q]);
+                xhf[i] = *reinterpret_cast<const pf_half8*>(xh + hp[i] + ko);
+                xlf[i] = *reinterpret_cast<const pf_half8*>(xl + hp[i] + ko);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
