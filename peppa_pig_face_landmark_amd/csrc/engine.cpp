@@ -211,12 +211,14 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     // (the Student's hero conv; HRNet's 18 / 36 / 72-channel 3x3 stacks of the Teacher take the narrow variants)
     if (SPLIT && use_split && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && !a.gate && !a.amax_val &&
         (a.outW == 16 || a.outW == 32 || a.outW == 64) && ((a.outH * a.outW) % 128) == 0 && a.inH == a.outH && a.inW == a.outW &&
-        (a.Npad == 128 || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
+        (a.Npad == 128 || (a.Npad == 64 && a.outW == 64) || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
         if constexpr (SPLIT) {
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(h->dbg & 1024);     // narrow variants: 256-pixel tiles
-            if (big && a.Npad <= 48) grid = dim3(pf_div_up(M, 256), 1);
+            if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
+            else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
+            else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 80) PF_LAUNCH((conv3x3_halo_split_kernel<80, 8, 1>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 48 && big) PF_LAUNCH((conv3x3_halo_split_kernel<48, 8, 1, 256>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 48) PF_LAUNCH((conv3x3_halo_split_kernel<48, 8, 1>), grid, dim3(512), h->stream, a);

@@ -54,8 +54,8 @@ def test_chain_equals_separate_convs_gpu(gpu_engine, c, hw, n_blocks, batch):
 
 
 def _narrow_conv_case(eng, c, hw, batch, seed):
-    """HRNet's narrow 3x3 convs (conv3x3_halo_split_kernel<32 | 48, 8, 1, 256>: 256-pixel tiles) against torch conv2d on the
-    tensor the engine itself produced upstream."""
+    """HRNet's narrow 3x3 convs (conv3x3_halo_split_kernel<32 | 48, 8, 1, 256> and layer1's <64, 4, 2, 256>: 256-pixel tiles)
+    against torch conv2d on the tensor the engine itself produced upstream."""
     import torch
     rng = np.random.default_rng(seed)
     pb = ir.ProgramBuilder("f32s", 2 * hw, 2 * hw, keep_all=True)
@@ -74,16 +74,16 @@ def _narrow_conv_case(eng, c, hw, batch, seed):
     ref = torch.relu(torch.nn.functional.conv2d(xt, torch.from_numpy(w1), torch.from_numpy(b1), padding=1) + xt)
     ref = ref.permute(0, 2, 3, 1).numpy()
     rel = np.abs(got[..., :c] - ref).max() / np.abs(ref).max()
-    assert rel < 2e-6, (c, hw, rel)
+    assert rel < 5e-6, (c, hw, rel)          # f32 accumulation over up to 576 products
 
 
-@pytest.mark.parametrize("c,hw,batch", [(18, 16, 3), (18, 32, 1), (36, 16, 2)])
+@pytest.mark.parametrize("c,hw,batch", [(18, 16, 3), (18, 32, 1), (36, 16, 2), (64, 64, 1)])
 def test_narrow_halo_convs_emu(emu_engine, c, hw, batch):
     _narrow_conv_case(emu_engine, c, hw, batch, seed=300 + c + hw)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2)])
+@pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2), (64, 64, 3)])
 def test_narrow_halo_convs_gpu(gpu_engine, c, hw, batch):
     _narrow_conv_case(gpu_engine, c, hw, batch, seed=400 + c + hw)
 
