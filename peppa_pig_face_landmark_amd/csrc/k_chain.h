@@ -262,7 +262,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void
 //   * x patch (TR + 4 rows, zero ring) -> split hi / lo planes in LDS, ONE load of the tensor per block instead of two plus
 //     the intermediate's round trip;
 //   * K is the flattened (tap, 8-channel group) axis: pixel rows in the planes are CG x 16 bytes (CG = ceil(C / 8): 48 / 80
-//     bytes, conflict-free for 16-byte fragment reads), a 32-deep MFMA step takes four consecutive (tap, group) pairs, each
+//     bytes), a 32-deep MFMA step takes four consecutive (tap, group) pairs, each
 //     lane reading ITS pair's shifted pixel -- 7 steps instead of 9 at 18 channels, 12 instead of 18 at 36;
 //   * conv1 runs on TR + 2 rows (one-row halo recompute), its relu output is split in registers and parked over the x planes
 //     (rows outside the image as zeros: they are conv2's padding), conv2 runs on the TR rows, and the f32 residual -- read
