@@ -1307,7 +1307,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     if (lo_chunks > 1) load_patch(1);
     for (int cb = 0; cb < cblocks; ++cb) {
         // ---- phase 1: weights of this step || produce the pixel operand ----------------------------------------
-        dma_weights(cb);
+        if (!(a.dbg & 1) || cb == 0) dma_weights(cb);
         float o[8];
         const int kelem = cb * 32 + xc * 8;
 #pragma unroll
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         }
         __syncthreads();
         // ---- phase 2: next chunk's patch and filters || MFMAs -------------------------------------------------------
-        if (cb + 1 < lo_chunks) {
+        if (cb + 1 < lo_chunks && !(a.dbg & 64)) {
             store_patch();
             dma_filters(cb + 1);
             if (cb + 2 < lo_chunks) load_patch(cb + 2);
