@@ -341,7 +341,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "sepup_c%d_n%d_%dx%d", a.inC, a.N, to.H, to.W);
                     ProfScope ps(h, tagbuf);
-                    const bool patch_ok = (to.W == 16 || to.W == 32 || to.W == 64) && ((to.H * to.W) % 128) == 0 && (tl.C % 32) == 0;
+                    const bool patch_ok = (to.W == 16 || to.W == 32 || to.W == 64) && ((to.H * to.W) % 128) == 0 && (tl.C % 32) == 0 && a.Cpad <= 640;
                     if (patch_ok && a.Npad == 256) {
                         grid.y = 1;
                         PF_LAUNCH((sepup_patch_kernel<256, 4, 2>), grid, dim3(512), h->stream, a);

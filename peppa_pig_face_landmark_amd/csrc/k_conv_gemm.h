@@ -1206,7 +1206,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     constexpr int WCHUNKS = BN * 8 / NTHR;
     constexpr int W_BYTES = BN * 128;
     static_assert(NTHR == 512 && (BN * 8) % NTHR == 0 && PW_SLOTS == 2 * NTHR + 128, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[P_BYTES + PW_BYTES + 2 * PLANE_X + W_BYTES];
+    constexpr int MAXC = 640;                            // depthwise biases of every K step (global loads at the head of each step
+                                                         // were a full L2 round trip per step: 0.36 ms of "empty" skeleton)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[P_BYTES + PW_BYTES + 2 * PLANE_X + W_BYTES + MAXC * 4];
+    float* sdwb = reinterpret_cast<float*>(smem + P_BYTES + PW_BYTES + 2 * PLANE_X + W_BYTES);
     float* pl = reinterpret_cast<float*>(smem);                      // [patch pixel][32 ch]
     float* pw = reinterpret_cast<float*>(smem + P_BYTES);            // [class * 9 + tap][32 ch]
     unsigned char* xh = smem + P_BYTES + PW_BYTES;
@@ -1298,6 +1301,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fchunk = lane >> 4;
 
+    for (int i = t; i < MAXC; i += NTHR) sdwb[i] = i < a.inC ? a.dw_b[i] : 0.f;
     if (lo_chunks > 0) {
         load_patch(0);
         dma_filters(0);
@@ -1313,12 +1317,12 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
         if (pvalid && kelem < a.inC) {
-            const pf_f32x4 b0 = *reinterpret_cast<const pf_f32x4*>(a.dw_b + kelem), b1 = *reinterpret_cast<const pf_f32x4*>(a.dw_b + kelem + 4);
+            const pf_f32x4 b0 = *reinterpret_cast<const pf_f32x4*>(sdwb + kelem), b1 = *reinterpret_cast<const pf_f32x4*>(sdwb + kelem + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o[e] = b0[e]; o[4 + e] = b1[e]; }
             if (cb < lo_chunks) {
 #pragma unroll 1
-                for (int j = 0; j < 3; ++j)   // one patch row at a time keeps the live LDS reads (and VGPRs) bounded
+                for (int j = 0; j < ((a.dbg & 256) ? 1 : 3); ++j)   // one patch row at a time keeps the live LDS reads (and VGPRs) bounded
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const float* pp = ppix + (j * PC + i) * 32;
