@@ -146,6 +146,20 @@ int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
                  unsigned long long* abs_diff_sum, int* has_prev);
 int pf_forget_frames(pf_handle* h);
 
+/* Frame ingest: cv2.imread(path) for JPEG files (demo.py:76) without the host-side decode and the
+ * upload of a 6 MB frame.  The entropy-coded scan is decoded on the host (a serial bit stream, ~0.1 byte per pixel); the
+ * 16-bit coefficient blocks go to the device through page-locked memory and dequantisation, inverse DCT, chroma upsampling
+ * and YCbCr->BGR run as kernels, bit-identical with libjpeg(-turbo)'s default decoder (JDCT_ISLOW, fancy upsampling), i.e.
+ * with what cv2.imread returns.  The frame (packed BGR, 3*width bytes per row) stays in device memory owned by the handle until
+ * the next pf_decode_jpeg; *d_bgr is that pointer -- hand it to pf_set_frame / pf_detect / pf_landmarks / pf_run_frames /
+ * pf_track_frame with mem = PF_MEM_DEVICE.  bgr_host (may be NULL): host copy for drawing, height*width*3 bytes (sizes from
+ * pf_jpeg_info).  Supported: 8-bit baseline / extended-sequential Huffman JPEG, greyscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
+ * restart markers; progressive, arithmetic-coded, 12-bit, CMYK / Adobe-RGB files and other sampling grids are refused with an
+ * error (decode those with the host library).  subsampling: 0 grey, 444, 422 or 420. */
+int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int* components, int* subsampling);
+int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr,
+                   uint8_t* bgr_host);
+
 /* FaceAna.run(image) / reset() for ONE video stream with the tracking state on the device.  The
  * reference keeps track_box, the previous landmark sets and their displacement on the host and walks the boxes through
  * numpy between the two networks (judge_boxs facer.py:144-189, sort_and_filter :120-142, GroupTrack.calculate + the

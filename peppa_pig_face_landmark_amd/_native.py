@@ -64,6 +64,8 @@ def _declare(lib):
     lib.pf_resize.argtypes = [vp, vp, i, i, i, i, i, i, vp]
     lib.pf_resize.restype = i
     lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
+    lib.pf_jpeg_info.argtypes = [vp, sz, ip, ip, ip, ip]
+    lib.pf_decode_jpeg.argtypes = [vp, vp, sz, ip, ip, C.POINTER(vp), vp]
     lib.pf_set_frame.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_ulonglong), ip]
     lib.pf_forget_frames.argtypes = [vp]
     lib.pf_set_option.argtypes = [vp, i, i]
@@ -107,6 +109,22 @@ def _ptr(a):
     if isinstance(a, int):
         return C.c_void_p(a)
     return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceFrame:
+    """A packed BGR uint8 frame that already lives in device memory (``Engine.imread`` / ``decode_jpeg``): accepted wherever the
+    engine takes a frame.  ``shape`` mirrors the numpy array cv2.imread would have returned; ``numpy()`` is the host copy
+    (for drawing).  The memory belongs to the engine and is reused by its next decode: consume the frame first (``FaceAna.run``
+    copies it into its resident-frame slot on the device)."""
+
+    def __init__(self, ptr: int, height: int, width: int, host: Optional[np.ndarray] = None):
+        self.ptr, self.shape, self._host = int(ptr), (int(height), int(width), 3), host
+        self.dtype = np.dtype(np.uint8)
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            raise PeppaHipError("this DeviceFrame was decoded without a host copy (imread(..., want_host=False))")
+        return self._host
 
 
 class Engine:
@@ -264,12 +282,17 @@ class Engine:
         """Upload the frame once and keep it resident; returns the mean absolute difference to the
         previous resident frame exactly as FaceAna.diff_frames computes it (facer.py:111-113), or None
         when there is no previous frame of the same shape."""
-        img = np.ascontiguousarray(image_bgr)
-        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
         total = C.c_ulonglong(0)
         has_prev = C.c_int(0)
-        self._check(self.lib.pf_set_frame(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
-                                          C.byref(total), C.byref(has_prev)), "pf_set_frame")
+        if isinstance(image_bgr, DeviceFrame):
+            img = image_bgr
+            self._check(self.lib.pf_set_frame(self.h, C.c_void_p(img.ptr), PF_MEM_DEVICE, img.shape[0], img.shape[1], img.shape[1] * 3,
+                                              C.byref(total), C.byref(has_prev)), "pf_set_frame")
+        else:
+            img = np.ascontiguousarray(image_bgr)
+            assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+            self._check(self.lib.pf_set_frame(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+                                              C.byref(total), C.byref(has_prev)), "pf_set_frame")
         self._resident_shape = img.shape
         if not has_prev.value:
             return None
@@ -286,6 +309,8 @@ class Engine:
             if shp is None:
                 raise PeppaHipError("no resident frame: call set_frame() first")
             return None, PF_MEM_RESIDENT, shp[0], shp[1], shp[1] * 3, None
+        if isinstance(image_bgr, DeviceFrame):
+            return C.c_void_p(image_bgr.ptr), PF_MEM_DEVICE, image_bgr.shape[0], image_bgr.shape[1], image_bgr.shape[1] * 3, image_bgr
         img = np.ascontiguousarray(image_bgr)
         assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
         return _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0], img
@@ -356,10 +381,10 @@ class Engine:
     # ---- stage-level seams -----------------------------------------------------------------------
     def letterbox(self, image_bgr: np.ndarray, out_hw=(384, 640)):
         """FaceDetector.preprocess (uint8 stage): -> (RGB uint8 [H,W,3], [scale, left, top])."""
-        img = np.ascontiguousarray(image_bgr)
+        fptr, fmem, fh, fw, fstride, _keep = self._frame_args(image_bgr)
         out = np.empty((out_hw[0], out_hw[1], 3), np.uint8)
         info = np.zeros(3, np.float32)
-        self._check(self.lib.pf_letterbox(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+        self._check(self.lib.pf_letterbox(self.h, fptr, fmem, fh, fw, fstride,
                                           out_hw[0], out_hw[1], _ptr(out), info.ctypes.data_as(C.POINTER(C.c_float))),
                     "pf_letterbox")
         return out, info
@@ -372,6 +397,36 @@ class Engine:
         self._check(self.lib.pf_resize(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
                                        int(out_hw[0]), int(out_hw[1]), _ptr(out)), "pf_resize")
         return out
+
+    def jpeg_info(self, data: bytes) -> Tuple[int, int, int, int]:
+        """(height, width, components, subsampling 0 | 444 | 422 | 420) of a JPEG stream the decoder accepts."""
+        hh, ww, cc, ss = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        if self.lib.pf_jpeg_info(buf, len(data), C.byref(hh), C.byref(ww), C.byref(cc), C.byref(ss)) != 0:
+            raise PeppaHipError("pf_jpeg_info: not a JPEG stream this decoder accepts")
+        return hh.value, ww.value, cc.value, ss.value
+
+    def decode_jpeg(self, data: bytes, want_host: bool = True):
+        """cv2.imread for JPEG bytes (demo.py:76): Huffman decoding on the host, everything after it on the device.  Returns
+        (device pointer of the packed BGR frame -- valid until the next decode --, height, width, host copy or None)."""
+        buf = (C.c_ubyte * len(data)).from_buffer_copy(data)
+        try:
+            hh, ww, _, _ = self.jpeg_info(data)
+        except PeppaHipError:      # let the decoder itself say why (its message names the unsupported feature)
+            self._check(self.lib.pf_decode_jpeg(self.h, buf, len(data), None, None, None, None), "pf_decode_jpeg")
+            raise
+        out = np.empty((hh, ww, 3), np.uint8) if want_host else None
+        d = C.c_void_p(0)
+        h2, w2 = C.c_int(0), C.c_int(0)
+        self._check(self.lib.pf_decode_jpeg(self.h, buf, len(data), C.byref(h2), C.byref(w2), C.byref(d),
+                                            _ptr(out) if want_host else None), "pf_decode_jpeg")
+        return d.value, h2.value, w2.value, out
+
+    def imread(self, path_or_bytes, want_host: bool = True) -> "DeviceFrame":
+        """cv2.imread(path) for baseline JPEG files, decoded into device memory (see decode_jpeg)."""
+        data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
+        d, hh, ww, host = self.decode_jpeg(bytes(data), want_host)
+        return DeviceFrame(d, hh, ww, host)
 
     def nms_rows(self, rows: np.ndarray, scale: float, left: float, top: float, score_thres: float, iou_thres: float,
                  max_n: int = 1024) -> np.ndarray:
@@ -405,8 +460,7 @@ class Engine:
         """FaceAna.run(image) for this engine's stream: returns (track boxes float64 [n,4], smoothed landmarks float64
         [n,98,2], scores float32 [n,98], detector_ran).  planted_rows (test instrument): decoded detector
         rows [R,16] that replace the detector network's own output when the gate runs the detector."""
-        img = np.ascontiguousarray(image_bgr)
-        assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+        fptr, fmem, fh, fw, fstride, img = self._frame_args(image_bgr)
         n = C.c_int(0)
         ran = C.c_int(0)
         boxes = np.zeros((top_k, 4), np.float64)
@@ -415,12 +469,12 @@ class Engine:
         outs = (C.byref(n), boxes.ctypes.data_as(C.POINTER(C.c_double)), kps.ctypes.data_as(C.POINTER(C.c_double)),
                 scores.ctypes.data_as(C.POINTER(C.c_float)), C.byref(ran))
         if planted_rows is None:
-            rc = self.lib.pf_track_frame(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+            rc = self.lib.pf_track_frame(self.h, fptr, fmem, fh, fw, fstride,
                                          float(score_thres), float(nms_iou_thres), float(min_face), int(top_k),
                                          float(track_iou_thres), float(smooth_box), float(diff_thres), 0, *outs)
         else:
             pr = np.ascontiguousarray(planted_rows, np.float32)
-            rc = self.lib.pf_track_frame_planted(self.h, _ptr(img), PF_MEM_HOST, img.shape[0], img.shape[1], img.strides[0],
+            rc = self.lib.pf_track_frame_planted(self.h, fptr, fmem, fh, fw, fstride,
                                                  pr.ctypes.data_as(C.POINTER(C.c_float)), pr.shape[0],
                                                  float(score_thres), float(nms_iou_thres), float(min_face), int(top_k),
                                                  float(track_iou_thres), float(smooth_box), float(diff_thres), *outs)

@@ -119,6 +119,13 @@ class FaceAna:
         self.track_box = self.judge_boxs(boxes_return, np.array(hulls))
         return self.to_dict(self.track_box, landmarks, states)
 
+    def imread(self, path_or_bytes, want_host: bool = True):
+        """``cv2.imread(path)`` of the reference's demo (demo.py:76) for baseline JPEG files: the Huffman stream is decoded on
+        the host, dequantisation / inverse DCT / chroma upsampling / colour conversion run on the GPU (bit-identical with
+        cv2.imread's libjpeg) and the frame never exists in host memory unless asked for.  Returns a ``DeviceFrame`` that
+        ``run()`` accepts like an array; ``frame.numpy()`` is the BGR array for drawing."""
+        return self.engine.imread(path_or_bytes, want_host)
+
     def to_dict(self, bboxes, kps, states):
         return [{"box": bboxes[i], "kps": kps[i], "scores": states[i]} for i in range(len(bboxes))]
 

@@ -18,6 +18,7 @@
 #include "k_layers.h"
 #include "k_mbconv.h"
 #include "k_chain.h"
+#include "k_jpeg.h"
 #include "k_prepost.h"
 #include "k_track.h"
 #include "pf_program.h"
@@ -75,6 +76,7 @@ struct pf_handle {
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
     // tracking state of the handle's video stream (pf_track_frame, k_track.h)
     TrackState track;
+    JpegState jpeg;          // pf_decode_jpeg (jpeg.inl)
     // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
     // after a program load, measures max |x| of the input of every split-precision op
     int range_every = 256;
@@ -790,6 +792,7 @@ void pf_destroy(pf_handle* h) {
     if (h->h_status) (void)hipHostFree(h->h_status);
     h->pipe.release();
     h->track.release();
+    h->jpeg.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -965,3 +968,4 @@ int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int
 #include "pipeline.inl"
 #include "comm.inl"
 #include "track.inl"
+#include "jpeg.inl"

@@ -1,0 +1,422 @@
+// pf_jpeg_info / pf_decode_jpeg: JPEG file -> packed BGR frame in device memory (frame ingest; the
+// reference does cv2.imread(path) on the host and hands the array to FaceAna.run, demo.py:76).  Host: marker parsing and the
+// Huffman-coded scan(s) -> 16-bit coefficient blocks in page-locked memory (ITU T.81 F.2.2; jdhuff.c is the model for the
+// bit reader: byte stuffing, restart intervals, missing data decodes as zeros).  Device: k_jpeg.h.
+// Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), greyscale or YCbCr with luma sampling 1x1, 2x1 or 2x2
+// over 1x1 chroma (4:4:4, 4:2:2, 4:2:0), interleaved or one scan per component, restart markers.  Anything else -- progressive,
+// arithmetic coding, 12-bit, CMYK / Adobe RGB, other sampling grids -- is refused with a message, never decoded approximately.
+#include <vector>
+
+namespace {
+
+const unsigned char kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                   41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                   30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+struct JpegHuff {
+    bool present = false;
+    unsigned char bits[17] = {0};
+    unsigned char vals[256] = {0};
+    int maxcode[18];      // largest code of each length, -1 if none (maxcode[17] = sentinel)
+    int valoff[17];       // vals index of the first code of a length minus that code
+    unsigned short look[512];   // 9-bit prefix -> (length << 8) | symbol, 0 = longer code
+    bool build() {
+        int code = 0, k = 0;
+        for (int i = 0; i < 512; ++i) look[i] = 0;
+        for (int l = 1; l <= 16; ++l) {
+            valoff[l] = k - code;
+            if (bits[l]) {
+                for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
+                    if (k >= 256) return false;
+                    if (l <= 9) {
+                        const int lo = code << (9 - l), n = 1 << (9 - l);
+                        for (int j = 0; j < n; ++j) look[lo + j] = (unsigned short)((l << 8) | vals[k]);
+                    }
+                }
+                maxcode[l] = code - 1;
+            } else {
+                maxcode[l] = -1;
+            }
+            if (code > (1 << l)) return false;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7fffffff;
+        return true;
+    }
+};
+
+struct JpegComp {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int bw = 0, bh = 0;       // blocks per row / column of the plane (padded to whole MCUs)
+    int dw = 0, dh = 0;       // downsampled width / height that carry image data
+    int block0 = 0;           // first block in the coefficient buffer
+    int pred = 0;
+};
+
+struct JpegHeader {
+    int W = 0, H = 0, ncomp = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0, restart = 0, total_blocks = 0;
+    JpegComp c[3];
+    unsigned short q[4][64];      // natural order
+    bool qpresent[4] = {false, false, false, false};
+    JpegHuff dc[4], ac[4];
+    bool have_sof = false, adobe = false;
+    int adobe_transform = -1;
+};
+
+struct JpegBits {
+    const unsigned char* p;
+    const unsigned char* end;
+    unsigned long long acc = 0;
+    int n = 0;
+    bool hit_marker = false;
+    void fill() {
+        while (n <= 48) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p++;
+                if (b == 0xFF) {
+                    if (p < end && *p == 0) ++p;                 // stuffed zero
+                    else { --p; hit_marker = true; b = 0; }      // a marker: the segment ends, feed zeros (jdhuff.c does the same)
+                }
+            } else {
+                hit_marker = true;
+            }
+            acc = (acc << 8) | (unsigned)b;
+            n += 8;
+        }
+    }
+    int peek(int k) { if (n < k) fill(); return (int)((acc >> (n - k)) & ((1u << k) - 1)); }
+    void skip(int k) { n -= k; }
+    int get(int k) { if (k == 0) return 0; const int v = peek(k); n -= k; return v; }
+    void align_reset() { acc = 0; n = 0; hit_marker = false; }
+};
+
+inline int jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
+
+inline int jpeg_huff_decode(JpegBits& br, const JpegHuff& t) {
+    const int look = t.look[br.peek(9)];
+    if (look) { br.skip(look >> 8); return look & 0xFF; }
+    int code = br.peek(9), l = 9;
+    br.skip(9);
+    for (;;) {
+        code = (code << 1) | br.get(1);
+        ++l;
+        if (l > 16) return 0;                    // garbage in the stream: decode as a zero-length symbol
+        if (t.maxcode[l] >= 0 && code <= t.maxcode[l]) return t.vals[(code + t.valoff[l]) & 0xFF];
+    }
+}
+
+inline unsigned jpeg_be16(const unsigned char* p) { return ((unsigned)p[0] << 8) | p[1]; }
+
+// Parses the header up to (not including) the first SOS; *sos_at = offset of that marker's 0xFF.  Returns an error text or nullptr.
+const char* jpeg_parse_header(const unsigned char* d, size_t n, JpegHeader& hd, size_t* sos_at) {
+    if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) return "not a JPEG stream (no SOI)";
+    size_t pos = 2;
+    for (;;) {
+        while (pos < n && d[pos] != 0xFF) ++pos;
+        while (pos < n && d[pos] == 0xFF) ++pos;
+        if (pos >= n) return "truncated JPEG header";
+        const int m = d[pos++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) return "JPEG ends before any scan";
+        if (pos + 2 > n) return "truncated JPEG header";
+        const size_t len = jpeg_be16(d + pos);
+        if (len < 2 || pos + len > n) return "bad JPEG segment length";
+        const unsigned char* s = d + pos + 2;
+        const size_t sl = len - 2;
+        if (m == 0xDA) { *sos_at = pos - 2; break; }
+        if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || s[0] != 8) return "only 8-bit JPEG samples are supported";
+            hd.H = (int)jpeg_be16(s + 1); hd.W = (int)jpeg_be16(s + 3); hd.ncomp = s[5];
+            if (hd.H < 1 || hd.W < 1) return "JPEG with zero dimensions (DNL) is not supported";
+            if (hd.ncomp != 1 && hd.ncomp != 3) return "only greyscale and 3-component (YCbCr) JPEGs are supported";
+            if (sl < (size_t)6 + 3 * hd.ncomp) return "truncated SOF";
+            for (int i = 0; i < hd.ncomp; ++i) {
+                JpegComp& c = hd.c[i];
+                c.id = s[6 + 3 * i]; c.h = s[7 + 3 * i] >> 4; c.v = s[7 + 3 * i] & 15; c.tq = s[8 + 3 * i];
+                if (c.tq > 3) return "bad quantisation table index";
+            }
+            hd.have_sof = true;
+        } else if (m == 0xC2) {
+            return "progressive JPEG is not supported (re-encode as baseline)";
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            return "lossless / hierarchical / arithmetic-coded JPEG is not supported";
+        } else if (m == 0xCC) {
+            return "arithmetic-coded JPEG is not supported";
+        } else if (m == 0xDB) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                ++o;
+                if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) return "bad DQT segment";
+                for (int k = 0; k < 64; ++k) {
+                    hd.q[tq][kZigzag[k]] = pq ? (unsigned short)jpeg_be16(s + o + 2 * k) : s[o + k];
+                }
+                o += pq ? 128 : 64;
+                hd.qpresent[tq] = true;
+            }
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o < sl) {
+                if (o + 17 > sl) return "bad DHT segment";
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3) return "bad DHT table id";
+                JpegHuff& t = tc ? hd.ac[th] : hd.dc[th];
+                int cnt = 0;
+                t.bits[0] = 0;
+                for (int l = 1; l <= 16; ++l) { t.bits[l] = s[o + l]; cnt += t.bits[l]; }
+                o += 17;
+                if (cnt > 256 || o + cnt > sl) return "bad DHT segment";
+                for (int k = 0; k < cnt; ++k) t.vals[k] = s[o + k];
+                o += cnt;
+                if (!t.build()) return "bad Huffman table";
+                t.present = true;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) return "bad DRI segment";
+            hd.restart = (int)jpeg_be16(s);
+        } else if (m == 0xEE) {
+            if (sl >= 12 && s[0] == 'A' && s[1] == 'd' && s[2] == 'o' && s[3] == 'b' && s[4] == 'e') { hd.adobe = true; hd.adobe_transform = s[11]; }
+        }
+        pos += len;
+    }
+    if (!hd.have_sof) return "no SOF0 / SOF1 frame header before the scan";
+    if (hd.ncomp == 3 && hd.adobe && hd.adobe_transform == 0) return "Adobe RGB JPEG (no YCbCr transform) is not supported";
+    if (hd.ncomp == 1) { hd.c[0].h = hd.c[0].v = 1; }                 // a single component's sampling factors are irrelevant
+    else {
+        if (hd.c[1].h != 1 || hd.c[1].v != 1 || hd.c[2].h != 1 || hd.c[2].v != 1) return "chroma sampling factors other than 1x1 are not supported";
+        const int h = hd.c[0].h, v = hd.c[0].v;
+        if (!((h == 1 && v == 1) || (h == 2 && v == 1) || (h == 2 && v == 2))) return "only 4:4:4, 4:2:2 and 4:2:0 sampling are supported";
+    }
+    hd.hmax = hd.c[0].h; hd.vmax = hd.c[0].v;
+    hd.mcux = (hd.W + 8 * hd.hmax - 1) / (8 * hd.hmax);
+    hd.mcuy = (hd.H + 8 * hd.vmax - 1) / (8 * hd.vmax);
+    int blocks = 0;
+    for (int i = 0; i < hd.ncomp; ++i) {
+        JpegComp& c = hd.c[i];
+        c.bw = hd.mcux * c.h; c.bh = hd.mcuy * c.v;
+        c.dw = (hd.W * c.h + hd.hmax - 1) / hd.hmax; c.dh = (hd.H * c.v + hd.vmax - 1) / hd.vmax;
+        c.block0 = blocks;
+        blocks += c.bw * c.bh;
+        if (!hd.qpresent[c.tq]) return "quantisation table missing";
+    }
+    hd.total_blocks = blocks;
+    return nullptr;
+}
+
+inline void jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff& act, int& pred, short* blk) {
+    const int s = jpeg_huff_decode(br, dct);
+    const int diff = s ? jpeg_extend(br.get(s > 15 ? 15 : s), s > 15 ? 15 : s) : 0;
+    pred += diff;
+    blk[0] = (short)pred;
+    for (int k = 1; k < 64;) {
+        const int rs = jpeg_huff_decode(br, act);
+        const int r = rs >> 4, sz = rs & 15;
+        if (sz == 0) {
+            if (r != 15) break;                  // EOB
+            k += 16;
+            continue;
+        }
+        k += r;
+        if (k > 63) break;
+        blk[kZigzag[k]] = (short)jpeg_extend(br.get(sz), sz);
+        ++k;
+    }
+}
+
+// All scans -> coefficient blocks (zero-initialised by the caller).  Returns an error text or nullptr.
+const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, JpegHeader& hd, short* coef) {
+    bool seen[3] = {false, false, false};
+    for (;;) {
+        // at a marker
+        while (pos < n && d[pos] != 0xFF) ++pos;
+        while (pos < n && d[pos] == 0xFF) ++pos;
+        if (pos >= n) break;
+        const int m = d[pos++];
+        if (m == 0xD9) break;
+        if ((m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (pos + 2 > n) break;
+        const size_t len = jpeg_be16(d + pos);
+        if (len < 2 || pos + len > n) return "bad JPEG segment length";
+        const unsigned char* s = d + pos + 2;
+        if (m == 0xC4 || m == 0xDB || m == 0xDD) {               // tables may change between scans
+            // re-use the header parser's table code on this one segment (wrapped as SOI, the segment, an empty SOS)
+            unsigned char hdr[4] = {0xFF, 0xD8, 0xFF, (unsigned char)m};
+            std::vector<unsigned char> buf(hdr, hdr + 4);
+            buf.insert(buf.end(), d + pos, d + pos + len);
+            const unsigned char tail[4] = {0xFF, 0xDA, 0x00, 0x02};
+            buf.insert(buf.end(), tail, tail + 4);
+            size_t dummy = 0;
+            JpegHeader h2 = hd;
+            if (const char* e = jpeg_parse_header(buf.data(), buf.size(), h2, &dummy)) return e;
+            for (int i = 0; i < 4; ++i) { hd.dc[i] = h2.dc[i]; hd.ac[i] = h2.ac[i]; hd.qpresent[i] = h2.qpresent[i]; for (int k = 0; k < 64; ++k) hd.q[i][k] = h2.q[i][k]; }
+            hd.restart = h2.restart;
+            pos += len;
+            continue;
+        }
+        if (m != 0xDA) { pos += len; continue; }
+        const size_t sl = len - 2;
+        if (sl < 1) return "bad SOS segment";
+        const int ns = s[0];
+        if (ns < 1 || ns > hd.ncomp || sl < (size_t)1 + 2 * ns + 3) return "bad SOS segment";
+        int ci[3];
+        for (int i = 0; i < ns; ++i) {
+            int found = -1;
+            for (int j = 0; j < hd.ncomp; ++j) if (hd.c[j].id == s[1 + 2 * i]) found = j;
+            if (found < 0) return "SOS names an unknown component";
+            ci[i] = found;
+            hd.c[found].td = s[2 + 2 * i] >> 4; hd.c[found].ta = s[2 + 2 * i] & 15;
+            if (hd.c[found].td > 3 || hd.c[found].ta > 3 || !hd.dc[hd.c[found].td].present || !hd.ac[hd.c[found].ta].present) return "Huffman table missing";
+            seen[found] = true;
+        }
+        if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return "spectral selection / successive approximation need a progressive decoder";
+        pos += len;
+        JpegBits br{d + pos, d + n};
+        for (int j = 0; j < hd.ncomp; ++j) hd.c[j].pred = 0;
+        int mcus_x, mcus_y;
+        if (ns == 1) { const JpegComp& c = hd.c[ci[0]]; mcus_x = (c.dw + 7) / 8; mcus_y = (c.dh + 7) / 8; }
+        else { mcus_x = hd.mcux; mcus_y = hd.mcuy; }
+        int until_restart = hd.restart, next_rst = 0;
+        for (int my = 0; my < mcus_y; ++my) {
+            for (int mx = 0; mx < mcus_x; ++mx) {
+                if (hd.restart && until_restart == 0) {
+                    // byte-align, find RSTn
+                    const unsigned char* q = br.p;
+                    // bytes already pulled into the accumulator beyond the marker are zeros fed after hit_marker; step to the marker
+                    while (q + 1 < d + n && !(q[0] == 0xFF && q[1] >= 0xD0 && q[1] <= 0xD7)) {
+                        if (q[0] == 0xFF && q[1] != 0 && q[1] != 0xFF) break;      // some other marker: stop looking
+                        ++q;
+                    }
+                    if (q + 1 < d + n && q[0] == 0xFF && q[1] == 0xD0 + next_rst) q += 2;
+                    br.p = q;
+                    br.align_reset();
+                    next_rst = (next_rst + 1) & 7;
+                    until_restart = hd.restart;
+                    for (int j = 0; j < hd.ncomp; ++j) hd.c[j].pred = 0;
+                }
+                if (ns == 1) {
+                    JpegComp& c = hd.c[ci[0]];
+                    jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred, coef + ((size_t)c.block0 + (size_t)my * c.bw + mx) * 64);
+                } else {
+                    for (int i = 0; i < ns; ++i) {
+                        JpegComp& c = hd.c[ci[i]];
+                        for (int v = 0; v < c.v; ++v)
+                            for (int h = 0; h < c.h; ++h)
+                                jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred,
+                                                  coef + ((size_t)c.block0 + (size_t)(my * c.v + v) * c.bw + (mx * c.h + h)) * 64);
+                    }
+                }
+                if (hd.restart) --until_restart;
+            }
+        }
+        // continue after the entropy-coded segment: br.p sits at (or shortly before) the next marker
+        pos = (size_t)(br.p - d);
+    }
+    for (int j = 0; j < hd.ncomp; ++j) if (!seen[j]) return "a component has no scan";
+    return nullptr;
+}
+
+}  // namespace
+
+void JpegState::release() {
+    if (h_coef) (void)hipHostFree(h_coef);
+    if (d_coef) (void)hipFree(d_coef);
+    if (d_planes) (void)hipFree(d_planes);
+    if (d_bgr) (void)hipFree(d_bgr);
+    if (d_quant) (void)hipFree(d_quant);
+    *this = JpegState{};
+}
+
+extern "C" {
+
+int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int* components, int* subsampling) {
+    if (!jpeg) return 1;
+    JpegHeader hd;
+    size_t sos = 0;
+    if (jpeg_parse_header(jpeg, bytes, hd, &sos)) return 1;
+    if (height) *height = hd.H;
+    if (width) *width = hd.W;
+    if (components) *components = hd.ncomp;
+    if (subsampling) *subsampling = hd.ncomp == 1 ? 0 : (hd.hmax == 1 ? 444 : (hd.vmax == 1 ? 422 : 420));
+    return 0;
+}
+
+int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
+    if (!h) return 1;
+    if (!jpeg) PF_FAIL(h, "pf_decode_jpeg: null input");
+    PF_HIP(h, hipSetDevice(h->device));
+    JpegHeader hd;
+    size_t sos = 0;
+    if (const char* e = jpeg_parse_header(jpeg, bytes, hd, &sos)) PF_FAIL(h, "pf_decode_jpeg: %s", e);
+    JpegState& s = h->jpeg;
+    const size_t coef_bytes = (size_t)hd.total_blocks * 64 * sizeof(short);
+    if (s.coef_cap < coef_bytes) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (s.h_coef) (void)hipHostFree(s.h_coef);
+        if (s.d_coef) (void)hipFree(s.d_coef);
+        s.h_coef = nullptr; s.d_coef = nullptr; s.coef_cap = 0;
+        PF_HIP(h, hipHostMalloc((void**)&s.h_coef, coef_bytes, hipHostMallocPortable));
+        PF_HIP(h, hipMalloc((void**)&s.d_coef, coef_bytes));
+        s.coef_cap = coef_bytes;
+    }
+    const size_t plane_bytes = (size_t)hd.total_blocks * 64;
+    if (s.planes_cap < plane_bytes) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (s.d_planes) (void)hipFree(s.d_planes);
+        s.d_planes = nullptr; s.planes_cap = 0;
+        PF_HIP(h, hipMalloc((void**)&s.d_planes, plane_bytes));
+        s.planes_cap = plane_bytes;
+    }
+    const size_t out_bytes = (size_t)hd.H * hd.W * 3;
+    if (s.bgr_cap < out_bytes) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (s.d_bgr) (void)hipFree(s.d_bgr);
+        s.d_bgr = nullptr; s.bgr_cap = 0;
+        h->alloc_epoch++;                          // a captured graph may hold the old frame pointer
+        PF_HIP(h, hipMalloc((void**)&s.d_bgr, out_bytes));
+        s.bgr_cap = out_bytes;
+    }
+    if (!s.d_quant) PF_HIP(h, hipMalloc((void**)&s.d_quant, 3 * 64 * sizeof(unsigned short)));
+    PF_HIP(h, hipStreamSynchronize(h->stream));     // the previous decode's upload has left the pinned buffer
+    memset(s.h_coef, 0, coef_bytes);
+    if (const char* e = jpeg_decode_scans(jpeg, bytes, sos, hd, s.h_coef)) PF_FAIL(h, "pf_decode_jpeg: %s", e);
+    unsigned short qt[3 * 64];
+    for (int c = 0; c < hd.ncomp; ++c)
+        for (int k = 0; k < 64; ++k) qt[c * 64 + k] = hd.q[hd.c[c].tq][k];
+    PF_HIP(h, hipMemcpyAsync(s.d_quant, qt, (size_t)hd.ncomp * 64 * sizeof(unsigned short), hipMemcpyHostToDevice, h->stream));
+    PF_HIP(h, hipMemcpyAsync(s.d_coef, s.h_coef, coef_bytes, hipMemcpyHostToDevice, h->stream));
+    JpegIdctArgs ia{};
+    ia.coef = s.d_coef; ia.ncomp = hd.ncomp; ia.quant = s.d_quant;
+    for (int c = 0; c < hd.ncomp; ++c) {
+        ia.block0[c] = hd.c[c].block0; ia.bw[c] = hd.c[c].bw;
+        ia.plane[c] = s.d_planes + (size_t)hd.c[c].block0 * 64;
+    }
+    ia.block0[hd.ncomp] = hd.total_blocks;
+    {
+        ProfScope ps(h, "jpeg_idct");
+        PF_LAUNCH(jpeg_idct_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64)), dim3(64), h->stream, ia);
+    }
+    JpegColorArgs ca{};
+    ca.y = ia.plane[0]; ca.ys = hd.c[0].bw * 8;
+    ca.W = hd.W; ca.H = hd.H; ca.out = s.d_bgr;
+    if (hd.ncomp == 1) {
+        ca.mode = 0;
+    } else {
+        ca.cb = ia.plane[1]; ca.cr = ia.plane[2]; ca.cs = hd.c[1].bw * 8;
+        ca.cw = hd.c[1].dw; ca.ch = hd.c[1].dh;
+        ca.mode = hd.hmax == 1 ? 1 : (hd.vmax == 1 ? 2 : 3);
+        if (ca.mode >= 2 && hd.c[1].dw <= 2) ca.mode += 4;       // jdsample.c: the triangle filter needs more than two columns
+    }
+    {
+        ProfScope ps(h, "jpeg_color");
+        PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256)), dim3(256), h->stream, ca);
+    }
+    if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, s.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (height) *height = hd.H;
+    if (width) *width = hd.W;
+    if (d_bgr) *d_bgr = s.d_bgr;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+// Device half of the JPEG decoder behind pf_decode_jpeg (frame ingest, SURVEY 8 next-row N2: replaces cv2.imread at
+// demo.py:76 for .jpg files).  The entropy-coded segment is decoded on the host (jpeg.inl: it is a serial bit stream);
+// everything after it is per-block / per-pixel work and runs here, bit-identical with what cv2.imread / libjpeg(-turbo)
+// produce with their defaults (JDCT_ISLOW, fancy upsampling, YCbCr -> RGB by the 16-bit fixed-point tables):
+//   jpeg_idct_kernel   dequantisation + the 8x8 "islow" integer inverse DCT of the IJG code (jidctint.c: CONST_BITS 13,
+//                      PASS1_BITS 2, column pass then row pass, +128, range limit), one thread per block;
+//   jpeg_color_kernel  chroma upsampling -- none (4:4:4), h2v1 / h2v2 "fancy" triangle filters (jdsample.c, edge columns and
+//                      rows replicated exactly as the IJG main controller feeds them) -- and YCbCr -> BGR (jdcolor.c), or
+//                      grey -> BGR, written as packed 8-bit BGR rows like cv2.imread returns.
+#pragma once
+#include "pf_common.h"
+
+// per-handle buffers of the decoder (jpeg.inl)
+struct JpegState {
+    short* h_coef = nullptr;          // page-locked: coefficient blocks as the entropy decoder writes them
+    short* d_coef = nullptr;
+    size_t coef_cap = 0;
+    unsigned char* d_planes = nullptr;    // component planes after the inverse DCT
+    size_t planes_cap = 0;
+    unsigned char* d_bgr = nullptr;       // the decoded frame, packed BGR
+    size_t bgr_cap = 0;
+    unsigned short* d_quant = nullptr;
+    void release();
+};
+
+struct JpegIdctArgs {
+    const short* coef;            // [block][64] natural (row-major) order, NOT yet dequantised
+    int ncomp;
+    int block0[4];                // first block of each component (block0[ncomp] = total)
+    int bw[3];                    // blocks per row of the component's plane
+    unsigned char* plane[3];      // [bh * 8][bw * 8]
+    const unsigned short* quant;  // [ncomp][64] natural order
+};
+
+__device__ __forceinline__ int pf_jpeg_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// IJG sample_range_limit behind "& RANGE_MASK": the 10-bit value is a signed sample offset; +128, clamp to [0, 255]
+__device__ __forceinline__ unsigned char pf_jpeg_range_limit(int v) {
+    const int x = v & 1023;
+    return (unsigned char)(x < 128 ? x + 128 : (x < 512 ? 255 : (x < 896 ? 0 : x - 896)));
+}
+
+__device__ __forceinline__ void pf_jpeg_idct_1d(const int (&in)[8], int (&out)[8], int shift) {
+    constexpr int CONST_BITS = 13;
+    // even part
+    int z2 = in[2], z3 = in[6];
+    int z1 = (z2 + z3) * 4433;                      // FIX_0_541196100
+    int tmp2 = z1 + z3 * (-15137);                  // FIX_1_847759065
+    int tmp3 = z1 + z2 * 6270;                      // FIX_0_765366865
+    z2 = in[0]; z3 = in[4];
+    int tmp0 = (z2 + z3) << CONST_BITS;
+    int tmp1 = (z2 - z3) << CONST_BITS;
+    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    // odd part
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int z4 = tmp1 + tmp3;
+    const int z5 = (z3 + z4) * 9633;                // FIX_1_175875602
+    tmp0 *= 2446;                                   // FIX_0_298631336
+    tmp1 *= 16819;                                  // FIX_2_053119869
+    tmp2 *= 25172;                                  // FIX_3_072711026
+    tmp3 *= 12299;                                  // FIX_1_501321110
+    z1 *= -7373;                                    // FIX_0_899976223
+    z2 *= -20995;                                   // FIX_2_562915447
+    z3 *= -16069;                                   // FIX_1_961570560
+    z4 *= -3196;                                    // FIX_0_390180644
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = pf_jpeg_descale(tmp10 + tmp3, shift); out[7] = pf_jpeg_descale(tmp10 - tmp3, shift);
+    out[1] = pf_jpeg_descale(tmp11 + tmp2, shift); out[6] = pf_jpeg_descale(tmp11 - tmp2, shift);
+    out[2] = pf_jpeg_descale(tmp12 + tmp1, shift); out[5] = pf_jpeg_descale(tmp12 - tmp1, shift);
+    out[3] = pf_jpeg_descale(tmp13 + tmp0, shift); out[4] = pf_jpeg_descale(tmp13 - tmp0, shift);
+}
+
+__global__ __launch_bounds__(64) void jpeg_idct_kernel(JpegIdctArgs a) {
+    const int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= a.block0[a.ncomp]) return;
+    int c = 0;
+    while (c + 1 < a.ncomp && blk >= a.block0[c + 1]) ++c;
+    const int local = blk - a.block0[c];
+    const int by = local / a.bw[c], bx = local - by * a.bw[c];
+    const short* __restrict__ src = a.coef + (size_t)blk * 64;
+    const unsigned short* __restrict__ q = a.quant + c * 64;
+    int ws[8][8];                                    // [row][col]
+    // pass 1: columns (results scaled up by 2^PASS1_BITS)
+#pragma unroll
+    for (int col = 0; col < 8; ++col) {
+        int in[8], out[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int)src[r * 8 + col] * (int)q[r * 8 + col];
+        pf_jpeg_idct_1d(in, out, 13 - 2);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[r][col] = out[r];
+    }
+    // pass 2: rows, descale by 2^(CONST_BITS + PASS1_BITS + 3), +128 and clamp
+    unsigned char* dst = a.plane[c] + ((size_t)by * 8) * ((size_t)a.bw[c] * 8) + (size_t)bx * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int out[8];
+        pf_jpeg_idct_1d(ws[r], out, 13 + 2 + 3);
+        unsigned long long pk = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pk |= (unsigned long long)pf_jpeg_range_limit(out[i]) << (8 * i);
+        *reinterpret_cast<unsigned long long*>(dst + (size_t)r * a.bw[c] * 8) = pk;
+    }
+}
+
+struct JpegColorArgs {
+    const unsigned char* y;  int ys;       // luma plane and its row stride
+    const unsigned char* cb; const unsigned char* cr; int cs;   // chroma planes (null for greyscale) and their stride
+    int cw, ch;              // chroma plane size that exists (downsampled_width / height: edge replication starts there)
+    int mode;                // 0 grey, 1 4:4:4, 2 h2v1, 3 h2v2; +4: plain replication instead of the triangle filter (width <= 2)
+    int W, H;
+    unsigned char* out;      // [H][W][3] BGR
+};
+
+// one chroma sample at output pixel (x, yy), IJG upsampling rules
+__device__ __forceinline__ int pf_jpeg_chroma(const unsigned char* __restrict__ p, int cs, int cw, int ch, int mode, int x, int yy) {
+    if (mode == 1) return p[(size_t)yy * cs + x];
+    const int c = x >> 1;
+    if (mode == 2 || mode == 6) {
+        const unsigned char* r = p + (size_t)yy * cs;
+        if (mode == 6) return r[c];
+        const int v = r[c];
+        if (x & 1) return c == cw - 1 ? v : (v * 3 + r[c + 1] + 2) >> 2;
+        return c == 0 ? v : (v * 3 + r[c - 1] + 1) >> 2;
+    }
+    const int inrow = yy >> 1;
+    if (mode == 7) return p[(size_t)inrow * cs + c];
+    int other = (yy & 1) ? inrow + 1 : inrow - 1;     // upper output row leans on the row above, lower on the row below
+    other = other < 0 ? 0 : (other > ch - 1 ? ch - 1 : other);
+    const unsigned char* r0 = p + (size_t)inrow * cs;
+    const unsigned char* r1 = p + (size_t)other * cs;
+    const int cur = r0[c] * 3 + r1[c];
+    if (x & 1) {
+        if (c == cw - 1) return (cur * 4 + 7) >> 4;
+        return (cur * 3 + (r0[c + 1] * 3 + r1[c + 1]) + 7) >> 4;
+    }
+    if (c == 0) return (cur * 4 + 8) >> 4;
+    return (cur * 3 + (r0[c - 1] * 3 + r1[c - 1]) + 8) >> 4;
+}
+
+__device__ __forceinline__ unsigned char pf_jpeg_clamp8(int v) { return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ __launch_bounds__(256) void jpeg_color_kernel(JpegColorArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.W * a.H) return;
+    const int yy = (int)(i / a.W), x = (int)(i - (long long)yy * a.W);
+    const int Y = a.y[(size_t)yy * a.ys + x];
+    unsigned char* o = a.out + (size_t)i * 3;
+    if (a.mode == 0) { o[0] = o[1] = o[2] = (unsigned char)Y; return; }
+    const int cb = pf_jpeg_chroma(a.cb, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
+    const int cr = pf_jpeg_chroma(a.cr, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
+    // jdcolor.c build_ycc_rgb_table, SCALEBITS 16: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
+    const int r = Y + ((91881 * cr + 32768) >> 16);
+    const int b = Y + ((116130 * cb + 32768) >> 16);
+    const int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
+    o[0] = pf_jpeg_clamp8(b); o[1] = pf_jpeg_clamp8(g); o[2] = pf_jpeg_clamp8(r);
+}

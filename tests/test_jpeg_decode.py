@@ -1,0 +1,154 @@
+"""pf_decode_jpeg (frame ingest, SURVEY 8 next-row N2: cv2.imread at demo.py:76) against libjpeg's own decoder through PIL --
+the same library and defaults cv2.imread uses (JDCT_ISLOW, fancy upsampling): the device decoder must be BIT-identical, for
+every sampling grid it accepts, odd sizes (partial MCUs, replicated edge rows / columns), tiny images (the plain-replication
+rule below three chroma columns), restart intervals, non-default quantisation and optimised Huffman tables, greyscale."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL.Image")
+
+from peppa_pig_face_landmark_amd import _native
+from peppa_pig_face_landmark_amd.synth import make_frame
+
+
+def _image(h, w, seed):
+    rng = np.random.default_rng(seed)
+    frame, _ = make_frame(max(h, 64), max(w, 64), 2, seed=seed)
+    img = frame[:h, :w].astype(np.int16) + rng.integers(-12, 13, (h, w, 3))     # texture: every AC coefficient gets used
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _encode(bgr, **kw):
+    buf = io.BytesIO()
+    PIL.fromarray(bgr[..., ::-1] if bgr.ndim == 3 else bgr).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+def _pil_decode(data):
+    im = PIL.open(io.BytesIO(data))
+    a = np.asarray(im.convert("RGB") if im.mode != "L" else im)
+    return a[..., ::-1] if a.ndim == 3 else np.repeat(a[..., None], 3, axis=2)
+
+
+CASES = [  # (h, w, save kwargs)
+    (64, 96, dict(quality=90, subsampling=0)),
+    (64, 96, dict(quality=90, subsampling=1)),
+    (64, 96, dict(quality=90, subsampling=2)),
+    (67, 101, dict(quality=75, subsampling=2)),            # partial MCUs, odd chroma edge
+    (35, 53, dict(quality=60, subsampling=1)),
+    (33, 47, dict(quality=95, subsampling=0, optimize=True)),
+    (8, 5, dict(quality=85, subsampling=2)),               # three chroma columns
+    (6, 4, dict(quality=85, subsampling=2)),               # two chroma columns: plain replication
+    (1, 1, dict(quality=85, subsampling=2)),
+    (120, 160, dict(quality=30, subsampling=2, optimize=True)),
+    (120, 160, dict(quality=100, subsampling=2)),
+]
+
+
+def _check_cases(eng):
+    for h, w, kw in CASES:
+        img = _image(h, w, seed=h * 1000 + w)
+        data = _encode(img, **kw)
+        ref = _pil_decode(data)
+        info = eng.jpeg_info(data)
+        assert info[:2] == (h, w) and info[3] == {0: 444, 1: 422, 2: 420}[kw["subsampling"]]
+        d, hh, ww, got = eng.decode_jpeg(data)
+        assert (hh, ww) == (h, w) and d
+        assert np.array_equal(got, ref), (h, w, kw, int(np.abs(got.astype(int) - ref).max()))
+    grey = _image(50, 70, seed=9)[..., 1]
+    data = _encode(grey, quality=80)
+    _, _, _, got = eng.decode_jpeg(data)
+    assert eng.jpeg_info(data)[2:] == (1, 0) and np.array_equal(got, _pil_decode(data))
+    # restart intervals (Pillow >= 9.4 writes DRI on request; older versions ignore the keyword and the case is a repeat)
+    img = _image(72, 88, seed=5)
+    for kw in (dict(restart_marker_blocks=3), dict(restart_marker_rows=1)):
+        try:
+            data = _encode(img, quality=85, subsampling=2, **kw)
+        except TypeError:
+            continue
+        _, _, _, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data)), kw
+    # refused, not approximated
+    with pytest.raises(_native.PeppaHipError, match="progressive"):
+        eng.decode_jpeg(_encode(img, quality=85, progressive=True))
+    with pytest.raises(_native.PeppaHipError):
+        eng.decode_jpeg(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    # the decoded frame is a device frame like any other: detector pre-processing reads it where it lies
+    data = _encode(_image(270, 480, seed=3), quality=90, subsampling=2)
+    frame = eng.imread(data)
+    lb_dev, lb_host = eng.letterbox(frame), eng.letterbox(frame.numpy())
+    assert np.array_equal(lb_dev[0], lb_host[0]) and np.array_equal(lb_dev[1], lb_host[1])
+
+
+def test_decode_matches_libjpeg_emulator(emu_library):
+    eng = _native.Engine(0, emu_library)
+    try:
+        _check_cases(eng)
+    finally:
+        eng.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/figure/test1.jpg"), reason="reference checkout not present (GPU box)")
+def test_reference_sample_image_emulator(emu_library):
+    """The reference's own sample (figure/test1.jpg), as demo.py would cv2.imread it."""
+    data = open("/root/reference/figure/test1.jpg", "rb").read()
+    eng = _native.Engine(0, emu_library)
+    try:
+        _, h, w, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data)) and got.shape == (h, w, 3)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_decode_matches_libjpeg_gpu(hip_library):
+    eng = _native.Engine(0, hip_library)
+    try:
+        _check_cases(eng)
+        img = _image(1080, 1920, seed=77)
+        data = _encode(img, quality=90, subsampling=2)
+        _, _, _, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data))
+    finally:
+        eng.close()
+
+
+def _facade_case(library, student_weights, detector_weights):
+    """demo.py:76-86 with the engine's ingest: FaceAna.run(facer.imread(jpg)) equals FaceAna.run(<libjpeg-decoded array>)."""
+    from Skps import FaceAna
+    from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+    cfg = get_cfg()
+    cfg["Skps"]["Detect"]["input_shape"] = [96, 160, 3]
+    cfg["Skps"]["Keypoints"]["input_shape"] = [64, 64, 3]
+    cfg["Skps"]["Engine"]["dtype"] = "f32"
+    frame, _ = make_frame(270, 480, 3, seed=11, face_w=330, face_h=430)
+    data = _encode(frame, quality=92, subsampling=2)
+    a = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=library)
+    b = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=library)
+    try:
+        dev = a.imread(data)
+        assert dev.shape == (270, 480, 3) and np.array_equal(dev.numpy(), _pil_decode(data))
+        ra = a.run(dev)
+        rb = b.run(np.ascontiguousarray(_pil_decode(data)))
+        assert len(ra) == len(rb)
+        for x, y in zip(ra, rb):
+            for key in ("box", "kps", "scores"):
+                assert np.array_equal(np.asarray(x[key]), np.asarray(y[key])), key
+        a.reset()
+        dev2 = a.imread(data, want_host=False)          # second decode reuses the buffers; no host copy requested
+        assert len(a.run(dev2)) == len(ra)
+    finally:
+        a.engine.close()
+        b.engine.close()
+
+
+def test_faceana_runs_on_decoded_device_frame_emulator(emu_library, student_weights, detector_weights):
+    _facade_case(emu_library, student_weights, detector_weights)
+
+
+@pytest.mark.gpu
+def test_faceana_runs_on_decoded_device_frame_gpu(hip_library, student_weights, detector_weights):
+    _facade_case(hip_library, student_weights, detector_weights)
