@@ -159,6 +159,11 @@ int pf_forget_frames(pf_handle* h);
 int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int* components, int* subsampling);
 int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr,
                    uint8_t* bgr_host);
+/* n files of one size and sampling -> [n][height][width][3] in device memory (*d_frames, same ownership), ready for
+ * pf_run_frames(mem = PF_MEM_DEVICE): the files' Huffman streams are decoded on `threads` host threads (one file per task), the
+ * device stages run once over the whole batch. */
+int pf_decode_jpeg_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads, int* height,
+                         int* width, const uint8_t** d_frames);
 
 /* FaceAna.run(image) / reset() for ONE video stream with the tracking state on the device.  The
  * reference keeps track_box, the previous landmark sets and their displacement on the host and walks the boxes through

@@ -66,6 +66,7 @@ def _declare(lib):
     lib.pf_crop_faces.argtypes = [vp, vp, i, i, i, i, fp, i, i, vp, ip]
     lib.pf_jpeg_info.argtypes = [vp, sz, ip, ip, ip, ip]
     lib.pf_decode_jpeg.argtypes = [vp, vp, sz, ip, ip, C.POINTER(vp), vp]
+    lib.pf_decode_jpeg_batch.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), i, ip, ip, C.POINTER(vp)]
     lib.pf_set_frame.argtypes = [vp, vp, i, i, i, i, C.POINTER(C.c_ulonglong), ip]
     lib.pf_forget_frames.argtypes = [vp]
     lib.pf_set_option.argtypes = [vp, i, i]
@@ -421,6 +422,18 @@ class Engine:
         self._check(self.lib.pf_decode_jpeg(self.h, buf, len(data), C.byref(h2), C.byref(w2), C.byref(d),
                                             _ptr(out) if want_host else None), "pf_decode_jpeg")
         return d.value, h2.value, w2.value, out
+
+    def decode_jpeg_batch(self, files, threads: int = 16):
+        """n JPEG byte strings of one size -> (device pointer of [n][H][W][3] BGR, n, H, W) for run_frames_device: Huffman
+        decoding of the files on `threads` host threads, the device stages once over the batch."""
+        n = len(files)
+        bufs = [(C.c_ubyte * len(d)).from_buffer_copy(d) for d in files]
+        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+        sizes = (C.c_size_t * n)(*[len(d) for d in files])
+        hh, ww, d = C.c_int(0), C.c_int(0), C.c_void_p(0)
+        self._check(self.lib.pf_decode_jpeg_batch(self.h, n, ptrs, sizes, int(threads), C.byref(hh), C.byref(ww), C.byref(d)),
+                    "pf_decode_jpeg_batch")
+        return d.value, n, hh.value, ww.value
 
     def imread(self, path_or_bytes, want_host: bool = True) -> "DeviceFrame":
         """cv2.imread(path) for baseline JPEG files, decoded into device memory (see decode_jpeg)."""

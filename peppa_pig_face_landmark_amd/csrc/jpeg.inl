@@ -5,6 +5,7 @@
 // Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), greyscale or YCbCr with luma sampling 1x1, 2x1 or 2x2
 // over 1x1 chroma (4:4:4, 4:2:2, 4:2:0), interleaved or one scan per component, restart markers.  Anything else -- progressive,
 // arithmetic coding, 12-bit, CMYK / Adobe RGB, other sampling grids -- is refused with a message, never decoded approximately.
+#include <thread>
 #include <vector>
 
 namespace {
@@ -208,6 +209,7 @@ inline void jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff&
     const int s = jpeg_huff_decode(br, dct);
     const int diff = s ? jpeg_extend(br.get(s > 15 ? 15 : s), s > 15 ? 15 : s) : 0;
     pred += diff;
+    memset(blk, 0, 64 * sizeof(short));
     blk[0] = (short)pred;
     for (int k = 1; k < 64;) {
         const int rs = jpeg_huff_decode(br, act);
@@ -224,8 +226,8 @@ inline void jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff&
     }
 }
 
-// All scans -> coefficient blocks (zero-initialised by the caller).  Returns an error text or nullptr.
-const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, JpegHeader& hd, short* coef) {
+// All scans -> coefficient blocks (every block a scan reaches is zeroed before its coefficients are written).  Returns an error text or nullptr.
+const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, JpegHeader& hd, short* coef, bool /*blocks zeroed as decoded*/) {
     bool seen[3] = {false, false, false};
     for (;;) {
         // at a marker
@@ -341,15 +343,23 @@ int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int
     return 0;
 }
 
-int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
-    if (!h) return 1;
-    if (!jpeg) PF_FAIL(h, "pf_decode_jpeg: null input");
+// n equally shaped JPEGs -> [n][H][W][3] in device memory; the entropy decoding of the files runs on `threads` host threads
+static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads,
+                             int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
+    if (n < 1 || !jpegs || !sizes) PF_FAIL(h, "pf_decode_jpeg: bad arguments");
     PF_HIP(h, hipSetDevice(h->device));
-    JpegHeader hd;
-    size_t sos = 0;
-    if (const char* e = jpeg_parse_header(jpeg, bytes, hd, &sos)) PF_FAIL(h, "pf_decode_jpeg: %s", e);
+    std::vector<JpegHeader> hds((size_t)n);
+    std::vector<size_t> sos((size_t)n, 0);
+    for (int f = 0; f < n; ++f) {
+        if (!jpegs[f]) PF_FAIL(h, "pf_decode_jpeg: null input");
+        if (const char* e = jpeg_parse_header(jpegs[f], sizes[f], hds[f], &sos[f])) PF_FAIL(h, "pf_decode_jpeg: %s", e);
+        if (f && (hds[f].W != hds[0].W || hds[f].H != hds[0].H || hds[f].ncomp != hds[0].ncomp || hds[f].hmax != hds[0].hmax ||
+                  hds[f].vmax != hds[0].vmax))
+            PF_FAIL(h, "pf_decode_jpeg_batch: image %d differs in size or sampling from image 0", f);
+    }
+    const JpegHeader& hd = hds[0];
     JpegState& s = h->jpeg;
-    const size_t coef_bytes = (size_t)hd.total_blocks * 64 * sizeof(short);
+    const size_t coef_bytes = (size_t)hd.total_blocks * 64 * sizeof(short) * n;
     if (s.coef_cap < coef_bytes) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
         if (s.h_coef) (void)hipHostFree(s.h_coef);
@@ -360,14 +370,14 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
         s.coef_cap = coef_bytes;
     }
     const size_t plane_bytes = (size_t)hd.total_blocks * 64;
-    if (s.planes_cap < plane_bytes) {
+    if (s.planes_cap < plane_bytes * n) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
         if (s.d_planes) (void)hipFree(s.d_planes);
         s.d_planes = nullptr; s.planes_cap = 0;
-        PF_HIP(h, hipMalloc((void**)&s.d_planes, plane_bytes));
-        s.planes_cap = plane_bytes;
+        PF_HIP(h, hipMalloc((void**)&s.d_planes, plane_bytes * n));
+        s.planes_cap = plane_bytes * n;
     }
-    const size_t out_bytes = (size_t)hd.H * hd.W * 3;
+    const size_t out_bytes = (size_t)hd.H * hd.W * 3 * n;
     if (s.bgr_cap < out_bytes) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
         if (s.d_bgr) (void)hipFree(s.d_bgr);
@@ -376,17 +386,43 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
         PF_HIP(h, hipMalloc((void**)&s.d_bgr, out_bytes));
         s.bgr_cap = out_bytes;
     }
-    if (!s.d_quant) PF_HIP(h, hipMalloc((void**)&s.d_quant, 3 * 64 * sizeof(unsigned short)));
+    if (s.quant_cap < (size_t)n) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (s.d_quant) (void)hipFree(s.d_quant);
+        s.d_quant = nullptr; s.quant_cap = 0;
+        PF_HIP(h, hipMalloc((void**)&s.d_quant, (size_t)n * 3 * 64 * sizeof(unsigned short)));
+        s.quant_cap = (size_t)n;
+    }
     PF_HIP(h, hipStreamSynchronize(h->stream));     // the previous decode's upload has left the pinned buffer
-    memset(s.h_coef, 0, coef_bytes);
-    if (const char* e = jpeg_decode_scans(jpeg, bytes, sos, hd, s.h_coef)) PF_FAIL(h, "pf_decode_jpeg: %s", e);
-    unsigned short qt[3 * 64];
-    for (int c = 0; c < hd.ncomp; ++c)
-        for (int k = 0; k < 64; ++k) qt[c * 64 + k] = hd.q[hd.c[c].tq][k];
-    PF_HIP(h, hipMemcpyAsync(s.d_quant, qt, (size_t)hd.ncomp * 64 * sizeof(unsigned short), hipMemcpyHostToDevice, h->stream));
+    // ---- entropy decoding: one file per task ------------------------------------------------------------------------------------
+    std::vector<const char*> errs((size_t)n, nullptr);
+    const size_t fstride = (size_t)hd.total_blocks * 64;
+    auto work = [&](int first, int step) {
+        for (int f = first; f < n; f += step) {
+            short* coef = s.h_coef + (size_t)f * fstride;
+            // blocks no scan reaches (none in a well-formed file) must still read as zeros
+            errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], coef, true);
+        }
+    };
+    const int T = std::max(1, std::min(threads, n));
+    if (T == 1) {
+        work(0, 1);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; ++t) pool.emplace_back(work, t, T);
+        work(0, T);
+        for (auto& th : pool) th.join();
+    }
+    for (int f = 0; f < n; ++f)
+        if (errs[f]) PF_FAIL(h, "pf_decode_jpeg: image %d: %s", f, errs[f]);
+    std::vector<unsigned short> qt((size_t)n * 3 * 64, 0);
+    for (int f = 0; f < n; ++f)
+        for (int c = 0; c < hd.ncomp; ++c)
+            for (int k = 0; k < 64; ++k) qt[((size_t)f * 3 + c) * 64 + k] = hds[f].q[hds[f].c[c].tq][k];
+    PF_HIP(h, hipMemcpyAsync(s.d_quant, qt.data(), qt.size() * sizeof(unsigned short), hipMemcpyHostToDevice, h->stream));
     PF_HIP(h, hipMemcpyAsync(s.d_coef, s.h_coef, coef_bytes, hipMemcpyHostToDevice, h->stream));
     JpegIdctArgs ia{};
-    ia.coef = s.d_coef; ia.ncomp = hd.ncomp; ia.quant = s.d_quant;
+    ia.coef = s.d_coef; ia.ncomp = hd.ncomp; ia.quant = s.d_quant; ia.frame_blocks = (size_t)hd.total_blocks;
     for (int c = 0; c < hd.ncomp; ++c) {
         ia.block0[c] = hd.c[c].block0; ia.bw[c] = hd.c[c].bw;
         ia.plane[c] = s.d_planes + (size_t)hd.c[c].block0 * 64;
@@ -394,11 +430,11 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
     ia.block0[hd.ncomp] = hd.total_blocks;
     {
         ProfScope ps(h, "jpeg_idct");
-        PF_LAUNCH(jpeg_idct_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64)), dim3(64), h->stream, ia);
+        PF_LAUNCH(jpeg_idct_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ia);
     }
     JpegColorArgs ca{};
     ca.y = ia.plane[0]; ca.ys = hd.c[0].bw * 8;
-    ca.W = hd.W; ca.H = hd.H; ca.out = s.d_bgr;
+    ca.W = hd.W; ca.H = hd.H; ca.out = s.d_bgr; ca.frame_plane_bytes = plane_bytes;
     if (hd.ncomp == 1) {
         ca.mode = 0;
     } else {
@@ -409,7 +445,7 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
     }
     {
         ProfScope ps(h, "jpeg_color");
-        PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256)), dim3(256), h->stream, ca);
+        PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
     }
     if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, s.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
@@ -417,6 +453,17 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
     if (width) *width = hd.W;
     if (d_bgr) *d_bgr = s.d_bgr;
     return 0;
+}
+
+int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
+    if (!h) return 1;
+    return jpeg_decode_batch(h, 1, &jpeg, &bytes, 1, height, width, d_bgr, bgr_host);
+}
+
+int pf_decode_jpeg_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads, int* height, int* width,
+                         const uint8_t** d_frames) {
+    if (!h) return 1;
+    return jpeg_decode_batch(h, n, jpegs, sizes, threads, height, width, d_frames, nullptr);
 }
 
 }  // extern "C"

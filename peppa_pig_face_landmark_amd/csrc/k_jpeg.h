@@ -19,7 +19,8 @@ struct JpegState {
     size_t planes_cap = 0;
     unsigned char* d_bgr = nullptr;       // the decoded frame, packed BGR
     size_t bgr_cap = 0;
-    unsigned short* d_quant = nullptr;
+    unsigned short* d_quant = nullptr;    // [frames][3][64]
+    size_t quant_cap = 0;
     void release();
 };
 
@@ -29,7 +30,8 @@ struct JpegIdctArgs {
     int block0[4];                // first block of each component (block0[ncomp] = total)
     int bw[3];                    // blocks per row of the component's plane
     unsigned char* plane[3];      // [bh * 8][bw * 8]
-    const unsigned short* quant;  // [ncomp][64] natural order
+    const unsigned short* quant;  // [frame][3][64] natural order
+    size_t frame_blocks;          // blockIdx.y = frame of a batch of equally shaped images: coefficient / plane stride in blocks
 };
 
 __device__ __forceinline__ int pf_jpeg_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -79,8 +81,9 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(JpegIdctArgs a) {
     while (c + 1 < a.ncomp && blk >= a.block0[c + 1]) ++c;
     const int local = blk - a.block0[c];
     const int by = local / a.bw[c], bx = local - by * a.bw[c];
-    const short* __restrict__ src = a.coef + (size_t)blk * 64;
-    const unsigned short* __restrict__ q = a.quant + c * 64;
+    const size_t fo = (size_t)blockIdx.y * a.frame_blocks;
+    const short* __restrict__ src = a.coef + (fo + blk) * 64;
+    const unsigned short* __restrict__ q = a.quant + ((size_t)blockIdx.y * 3 + c) * 64;
     int ws[8][8];                                    // [row][col]
     // pass 1: columns (results scaled up by 2^PASS1_BITS)
 #pragma unroll
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(64) void jpeg_idct_kernel(JpegIdctArgs a) {
         for (int r = 0; r < 8; ++r) ws[r][col] = out[r];
     }
     // pass 2: rows, descale by 2^(CONST_BITS + PASS1_BITS + 3), +128 and clamp
-    unsigned char* dst = a.plane[c] + ((size_t)by * 8) * ((size_t)a.bw[c] * 8) + (size_t)bx * 8;
+    unsigned char* dst = a.plane[c] + fo * 64 + ((size_t)by * 8) * ((size_t)a.bw[c] * 8) + (size_t)bx * 8;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         int out[8];
@@ -111,7 +114,8 @@ struct JpegColorArgs {
     int cw, ch;              // chroma plane size that exists (downsampled_width / height: edge replication starts there)
     int mode;                // 0 grey, 1 4:4:4, 2 h2v1, 3 h2v2; +4: plain replication instead of the triangle filter (width <= 2)
     int W, H;
-    unsigned char* out;      // [H][W][3] BGR
+    unsigned char* out;      // [frame][H][W][3] BGR
+    size_t frame_plane_bytes;   // blockIdx.y = frame: stride of the plane set
 };
 
 // one chroma sample at output pixel (x, yy), IJG upsampling rules
@@ -146,11 +150,12 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(JpegColorArgs a) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)a.W * a.H) return;
     const int yy = (int)(i / a.W), x = (int)(i - (long long)yy * a.W);
-    const int Y = a.y[(size_t)yy * a.ys + x];
-    unsigned char* o = a.out + (size_t)i * 3;
+    const size_t po = (size_t)blockIdx.y * a.frame_plane_bytes;
+    const int Y = a.y[po + (size_t)yy * a.ys + x];
+    unsigned char* o = a.out + ((size_t)blockIdx.y * a.W * a.H + (size_t)i) * 3;
     if (a.mode == 0) { o[0] = o[1] = o[2] = (unsigned char)Y; return; }
-    const int cb = pf_jpeg_chroma(a.cb, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
-    const int cr = pf_jpeg_chroma(a.cr, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
+    const int cb = pf_jpeg_chroma(a.cb + po, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
+    const int cr = pf_jpeg_chroma(a.cr + po, a.cs, a.cw, a.ch, a.mode, x, yy) - 128;
     // jdcolor.c build_ycc_rgb_table, SCALEBITS 16: FIX(1.40200) = 91881, FIX(1.77200) = 116130, FIX(0.71414) = 46802, FIX(0.34414) = 22554
     const int r = Y + ((91881 * cr + 32768) >> 16);
     const int b = Y + ((116130 * cb + 32768) >> 16);

@@ -71,6 +71,20 @@ def _check_cases(eng):
             continue
         _, _, _, got = eng.decode_jpeg(data)
         assert np.array_equal(got, _pil_decode(data)), kw
+    # a batch of equally shaped files, entropy-decoded on several host threads
+    imgs = [_image(40, 56, seed=40 + i) for i in range(5)]
+    files = [_encode(im, quality=70 + 5 * i, subsampling=2) for i, im in enumerate(imgs)]
+    singles = [eng.decode_jpeg(f)[3] for f in files]
+    for f, one in zip(files, singles):
+        assert np.array_equal(one, _pil_decode(f))
+    d, n, hh, ww = eng.decode_jpeg_batch(files, threads=3)
+    assert (n, hh, ww) == (5, 40, 56) and d
+    for i, one in enumerate(singles):          # frame i of the batch, read through the detector's pre-processing kernel
+        got = eng.letterbox(_native.DeviceFrame(d + i * hh * ww * 3, hh, ww), (48, 64))
+        ref = eng.letterbox(one, (48, 64))
+        assert np.array_equal(got[0], ref[0]), i
+    with pytest.raises(_native.PeppaHipError, match="differs in size"):
+        eng.decode_jpeg_batch([files[0], _encode(_image(48, 56, seed=1), quality=80, subsampling=2)])
     # refused, not approximated
     with pytest.raises(_native.PeppaHipError, match="progressive"):
         eng.decode_jpeg(_encode(img, quality=85, progressive=True))
