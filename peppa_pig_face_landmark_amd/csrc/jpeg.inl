@@ -205,12 +205,14 @@ const char* jpeg_parse_header(const unsigned char* d, size_t n, JpegHeader& hd, 
     return nullptr;
 }
 
-inline void jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff& act, int& pred, short* blk) {
+// One block -> a packed record at rec: [length][coefficients in zigzag order up to the last non-zero one].  Returns the record's
+// size in 16-bit units.
+inline int jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff& act, int& pred, short* rec) {
     const int s = jpeg_huff_decode(br, dct);
     const int diff = s ? jpeg_extend(br.get(s > 15 ? 15 : s), s > 15 ? 15 : s) : 0;
     pred += diff;
-    memset(blk, 0, 64 * sizeof(short));
-    blk[0] = (short)pred;
+    rec[1] = (short)pred;
+    int last = 0;
     for (int k = 1; k < 64;) {
         const int rs = jpeg_huff_decode(br, act);
         const int r = rs >> 4, sz = rs & 15;
@@ -221,13 +223,19 @@ inline void jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff&
         }
         k += r;
         if (k > 63) break;
-        blk[kZigzag[k]] = (short)jpeg_extend(br.get(sz), sz);
+        for (int z = last + 1; z < k; ++z) rec[1 + z] = 0;
+        rec[1 + k] = (short)jpeg_extend(br.get(sz), sz);
+        last = k;
         ++k;
     }
+    rec[0] = (short)(last + 1);
+    return last + 2;
 }
 
-// All scans -> coefficient blocks (every block a scan reaches is zeroed before its coefficients are written).  Returns an error text or nullptr.
-const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, JpegHeader& hd, short* coef, bool /*blocks zeroed as decoded*/) {
+// All scans -> packed block records (tab[block] = record start in 16-bit units, 0xFFFFFFFF where no scan reached the block).  Returns an error text or nullptr.
+const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, JpegHeader& hd, unsigned* tab, short* data, size_t* used) {
+    size_t cur = 0;
+    for (int b = 0; b < hd.total_blocks; ++b) tab[b] = 0xFFFFFFFFu;
     bool seen[3] = {false, false, false};
     for (;;) {
         // at a marker
@@ -269,6 +277,7 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
             ci[i] = found;
             hd.c[found].td = s[2 + 2 * i] >> 4; hd.c[found].ta = s[2 + 2 * i] & 15;
             if (hd.c[found].td > 3 || hd.c[found].ta > 3 || !hd.dc[hd.c[found].td].present || !hd.ac[hd.c[found].ta].present) return "Huffman table missing";
+            if (seen[found]) return "a component appears in more than one scan";
             seen[found] = true;
         }
         if (s[1 + 2 * ns] != 0 || s[2 + 2 * ns] != 63 || s[3 + 2 * ns] != 0) return "spectral selection / successive approximation need a progressive decoder";
@@ -298,14 +307,18 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
                 }
                 if (ns == 1) {
                     JpegComp& c = hd.c[ci[0]];
-                    jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred, coef + ((size_t)c.block0 + (size_t)my * c.bw + mx) * 64);
+                    const size_t b = (size_t)c.block0 + (size_t)my * c.bw + mx;
+                    tab[b] = (unsigned)cur;
+                    cur += jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred, data + cur);
                 } else {
                     for (int i = 0; i < ns; ++i) {
                         JpegComp& c = hd.c[ci[i]];
                         for (int v = 0; v < c.v; ++v)
-                            for (int h = 0; h < c.h; ++h)
-                                jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred,
-                                                  coef + ((size_t)c.block0 + (size_t)(my * c.v + v) * c.bw + (mx * c.h + h)) * 64);
+                            for (int h = 0; h < c.h; ++h) {
+                                const size_t b = (size_t)c.block0 + (size_t)(my * c.v + v) * c.bw + (mx * c.h + h);
+                                tab[b] = (unsigned)cur;
+                                cur += jpeg_decode_block(br, hd.dc[c.td], hd.ac[c.ta], c.pred, data + cur);
+                            }
                     }
                 }
                 if (hd.restart) --until_restart;
@@ -315,13 +328,15 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
         pos = (size_t)(br.p - d);
     }
     for (int j = 0; j < hd.ncomp; ++j) if (!seen[j]) return "a component has no scan";
+    *used = cur;
     return nullptr;
 }
 
 }  // namespace
 
 void JpegState::release() {
-    if (h_coef) (void)hipHostFree(h_coef);
+    if (h_pack) (void)hipHostFree(h_pack);
+    if (d_pack) (void)hipFree(d_pack);
     if (d_coef) (void)hipFree(d_coef);
     if (d_planes) (void)hipFree(d_planes);
     if (d_bgr) (void)hipFree(d_bgr);
@@ -362,12 +377,21 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     const size_t coef_bytes = (size_t)hd.total_blocks * 64 * sizeof(short) * n;
     if (s.coef_cap < coef_bytes) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
-        if (s.h_coef) (void)hipHostFree(s.h_coef);
         if (s.d_coef) (void)hipFree(s.d_coef);
-        s.h_coef = nullptr; s.d_coef = nullptr; s.coef_cap = 0;
-        PF_HIP(h, hipHostMalloc((void**)&s.h_coef, coef_bytes, hipHostMallocPortable));
+        s.d_coef = nullptr; s.coef_cap = 0;
         PF_HIP(h, hipMalloc((void**)&s.d_coef, coef_bytes));
         s.coef_cap = coef_bytes;
+    }
+    // packed records: worst case 65 values per block (every block is written by exactly one scan: decode_scans refuses a component that appears twice)
+    const size_t frame_pack = ((size_t)hd.total_blocks * (4 + 65 * sizeof(short)) + 255) / 256 * 256;
+    if (s.pack_cap < frame_pack * n) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (s.h_pack) (void)hipHostFree(s.h_pack);
+        if (s.d_pack) (void)hipFree(s.d_pack);
+        s.h_pack = nullptr; s.d_pack = nullptr; s.pack_cap = 0;
+        PF_HIP(h, hipHostMalloc((void**)&s.h_pack, frame_pack * n, hipHostMallocPortable));
+        PF_HIP(h, hipMalloc((void**)&s.d_pack, frame_pack * n));
+        s.pack_cap = frame_pack * n;
     }
     const size_t plane_bytes = (size_t)hd.total_blocks * 64;
     if (s.planes_cap < plane_bytes * n) {
@@ -396,12 +420,12 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     PF_HIP(h, hipStreamSynchronize(h->stream));     // the previous decode's upload has left the pinned buffer
     // ---- entropy decoding: one file per task ------------------------------------------------------------------------------------
     std::vector<const char*> errs((size_t)n, nullptr);
-    const size_t fstride = (size_t)hd.total_blocks * 64;
+    std::vector<size_t> used((size_t)n, 0);
     auto work = [&](int first, int step) {
         for (int f = first; f < n; f += step) {
-            short* coef = s.h_coef + (size_t)f * fstride;
-            // blocks no scan reaches (none in a well-formed file) must still read as zeros
-            errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], coef, true);
+            unsigned char* region = s.h_pack + (size_t)f * frame_pack;
+            errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], reinterpret_cast<unsigned*>(region),
+                                        reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &used[f]);
         }
     };
     const int T = std::max(1, std::min(threads, n));
@@ -415,12 +439,20 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     for (int f = 0; f < n; ++f)
         if (errs[f]) PF_FAIL(h, "pf_decode_jpeg: image %d: %s", f, errs[f]);
+    for (int f = 0; f < n; ++f)      // only what the decoder wrote crosses PCIe: the block table and the records
+        PF_HIP(h, hipMemcpyAsync(s.d_pack + (size_t)f * frame_pack, s.h_pack + (size_t)f * frame_pack,
+                                 (size_t)hd.total_blocks * 4 + used[f] * sizeof(short), hipMemcpyHostToDevice, h->stream));
+    {
+        JpegUnpackArgs ua{};
+        ua.pack = s.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks;
+        ProfScope ps(h, "jpeg_unpack");
+        PF_LAUNCH(jpeg_unpack_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ua);
+    }
     std::vector<unsigned short> qt((size_t)n * 3 * 64, 0);
     for (int f = 0; f < n; ++f)
         for (int c = 0; c < hd.ncomp; ++c)
             for (int k = 0; k < 64; ++k) qt[((size_t)f * 3 + c) * 64 + k] = hds[f].q[hds[f].c[c].tq][k];
     PF_HIP(h, hipMemcpyAsync(s.d_quant, qt.data(), qt.size() * sizeof(unsigned short), hipMemcpyHostToDevice, h->stream));
-    PF_HIP(h, hipMemcpyAsync(s.d_coef, s.h_coef, coef_bytes, hipMemcpyHostToDevice, h->stream));
     JpegIdctArgs ia{};
     ia.coef = s.d_coef; ia.ncomp = hd.ncomp; ia.quant = s.d_quant; ia.frame_blocks = (size_t)hd.total_blocks;
     for (int c = 0; c < hd.ncomp; ++c) {

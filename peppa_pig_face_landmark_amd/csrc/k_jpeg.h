@@ -12,8 +12,10 @@
 
 // per-handle buffers of the decoder (jpeg.inl)
 struct JpegState {
-    short* h_coef = nullptr;          // page-locked: coefficient blocks as the entropy decoder writes them
-    short* d_coef = nullptr;
+    unsigned char* h_pack = nullptr;  // page-locked: per frame [block table u32 x blocks][records: length, coefficients in zigzag
+    unsigned char* d_pack = nullptr;  //   order up to the last non-zero one] -- what the entropy decoder writes and PCIe carries
+    size_t pack_cap = 0;
+    short* d_coef = nullptr;          // dense [block][64] natural-order blocks, expanded on the device
     size_t coef_cap = 0;
     unsigned char* d_planes = nullptr;    // component planes after the inverse DCT
     size_t planes_cap = 0;
@@ -23,6 +25,39 @@ struct JpegState {
     size_t quant_cap = 0;
     void release();
 };
+
+struct JpegUnpackArgs {
+    const unsigned char* pack;    // [frame] regions of frame_pack_bytes
+    size_t frame_pack_bytes;
+    short* coef;                  // [frame][blocks][64]
+    int blocks;
+};
+
+__device__ __forceinline__ int pf_jpeg_zigzag(int k) {      // zigzag position -> natural (row-major) index
+    constexpr unsigned char t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                                                 41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                                                 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return t[k];
+}
+
+// packed records -> dense natural-order blocks (zeros where the record ends or no scan reached the block)
+__global__ __launch_bounds__(64) void jpeg_unpack_kernel(JpegUnpackArgs a) {
+    const int blk = blockIdx.x * 64 + threadIdx.x;
+    if (blk >= a.blocks) return;
+    const unsigned char* region = a.pack + (size_t)blockIdx.y * a.frame_pack_bytes;
+    const unsigned start = reinterpret_cast<const unsigned*>(region)[blk];
+    short* dst = a.coef + ((size_t)blockIdx.y * a.blocks + blk) * 64;
+    pf_f32x4 z = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) reinterpret_cast<pf_f32x4*>(dst)[i] = z;
+    if (start == 0xFFFFFFFFu) return;
+    const short* rec = reinterpret_cast<const short*>(region + (size_t)a.blocks * 4) + start;
+    const int len = rec[0];
+    for (int k = 0; k < len && k < 64; ++k) {
+        const short v = rec[1 + k];
+        if (v) dst[pf_jpeg_zigzag(k)] = v;
+    }
+}
 
 struct JpegIdctArgs {
     const short* coef;            // [block][64] natural (row-major) order, NOT yet dequantised
