@@ -5,6 +5,7 @@
 // Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), greyscale or YCbCr with luma sampling 1x1, 2x1 or 2x2
 // over 1x1 chroma (4:4:4, 4:2:2, 4:2:0), interleaved or one scan per component, restart markers.  Anything else -- progressive,
 // arithmetic coding, 12-bit, CMYK / Adobe RGB, other sampling grids -- is refused with a message, never decoded approximately.
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -21,6 +22,7 @@ struct JpegHuff {
     int maxcode[18];      // largest code of each length, -1 if none (maxcode[17] = sentinel)
     int valoff[17];       // vals index of the first code of a length minus that code
     unsigned short look[512];   // 9-bit prefix -> (length << 8) | symbol, 0 = longer code
+    short fast_ac[512];         // AC tables: 9-bit prefix holds code AND magnitude bits -> (value << 8) | (run << 4) | total bits, else 0
     bool build() {
         int code = 0, k = 0;
         for (int i = 0; i < 512; ++i) look[i] = 0;
@@ -42,6 +44,16 @@ struct JpegHuff {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        for (int i = 0; i < 512; ++i) {
+            fast_ac[i] = 0;
+            const int lk = look[i];
+            if (!lk) continue;
+            const int len = lk >> 8, rs = lk & 0xFF, run = rs >> 4, sz = rs & 15;
+            if (sz == 0 || len + sz > 9) continue;
+            int v = (i >> (9 - len - sz)) & ((1 << sz) - 1);          // the magnitude bits that follow the code
+            if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+            if (v >= -128 && v <= 127) fast_ac[i] = (short)((v * 256) | (run << 4) | (len + sz));
+        }
         return true;
     }
 };
@@ -87,6 +99,7 @@ struct JpegBits {
         }
     }
     int peek(int k) { if (n < k) fill(); return (int)((acc >> (n - k)) & ((1u << k) - 1)); }
+    int peek_nofill(int k) const { return (int)((acc >> (n - k)) & ((1u << k) - 1)); }   // caller keeps n >= 32
     void skip(int k) { n -= k; }
     int get(int k) { if (k == 0) return 0; const int v = peek(k); n -= k; return v; }
     void align_reset() { acc = 0; n = 0; hit_marker = false; }
@@ -214,17 +227,29 @@ inline int jpeg_decode_block(JpegBits& br, const JpegHuff& dct, const JpegHuff& 
     rec[1] = (short)pred;
     int last = 0;
     for (int k = 1; k < 64;) {
-        const int rs = jpeg_huff_decode(br, act);
-        const int r = rs >> 4, sz = rs & 15;
-        if (sz == 0) {
-            if (r != 15) break;                  // EOB
-            k += 16;
-            continue;
+        if (br.n < 32) br.fill();                // one refill covers a code (<= 16 bits) and its magnitude (<= 15)
+        const int fa = act.fast_ac[br.peek_nofill(9)];
+        int r, val;
+        if (fa) {                                // code and magnitude inside the 9-bit window: one lookup
+            br.skip(fa & 15);
+            r = (fa >> 4) & 15;
+            val = fa >> 8;
+        } else {
+            const int rs = jpeg_huff_decode(br, act);
+            const int sz = rs & 15;
+            r = rs >> 4;
+            if (sz == 0) {
+                if (r != 15) break;              // EOB
+                k += 16;
+                continue;
+            }
+            val = jpeg_extend(br.peek_nofill(sz), sz);
+            br.skip(sz);
         }
         k += r;
         if (k > 63) break;
         for (int z = last + 1; z < k; ++z) rec[1 + z] = 0;
-        rec[1 + k] = (short)jpeg_extend(br.get(sz), sz);
+        rec[1 + k] = (short)val;
         last = k;
         ++k;
     }
@@ -428,6 +453,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
                                         reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &used[f]);
         }
     };
+    const auto t_start = std::chrono::steady_clock::now();
     const int T = std::max(1, std::min(threads, n));
     if (T == 1) {
         work(0, 1);
@@ -439,6 +465,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     for (int f = 0; f < n; ++f)
         if (errs[f]) PF_FAIL(h, "pf_decode_jpeg: image %d: %s", f, errs[f]);
+    const auto t_entropy = std::chrono::steady_clock::now();
     for (int f = 0; f < n; ++f)      // only what the decoder wrote crosses PCIe: the block table and the records
         PF_HIP(h, hipMemcpyAsync(s.d_pack + (size_t)f * frame_pack, s.h_pack + (size_t)f * frame_pack,
                                  (size_t)hd.total_blocks * 4 + used[f] * sizeof(short), hipMemcpyHostToDevice, h->stream));
@@ -481,6 +508,14 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, s.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (getenv("PEPPA_JPEG_TIMING")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        size_t up = 0;
+        for (int f = 0; f < n; ++f) up += (size_t)hd.total_blocks * 4 + used[f] * sizeof(short);
+        fprintf(stderr, "[peppa-hip] jpeg batch of %d: entropy decode %.3f ms on %d thread(s), upload (%.2f MB) + device stages %.3f ms\n", n,
+                std::chrono::duration<double, std::milli>(t_entropy - t_start).count(), T, up / 1e6,
+                std::chrono::duration<double, std::milli>(t_end - t_entropy).count());
+    }
     if (height) *height = hd.H;
     if (width) *width = hd.W;
     if (d_bgr) *d_bgr = s.d_bgr;

@@ -21,10 +21,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quality", type=int, default=90)
     ap.add_argument("--n", type=int, default=50)
+    ap.add_argument("--content", default="photo", choices=["photo", "noise"])
     args = ap.parse_args()
-    frame, _ = make_frame(1080, 1920, 8, seed=1)
     rng = np.random.default_rng(0)
-    frame = np.clip(frame.astype(np.int16) + rng.integers(-6, 7, frame.shape), 0, 255).astype(np.uint8)
+    if args.content == "noise":      # worst case for the entropy stage: every block carries ~35 non-zero coefficients
+        frame, _ = make_frame(1080, 1920, 8, seed=1)
+        frame = np.clip(frame.astype(np.int16) + rng.integers(-6, 7, frame.shape), 0, 255).astype(np.uint8)
+    else:                            # photo-like statistics: smooth large-scale structure + faint sensor noise (~0.1 byte per pixel at q90)
+        low = rng.integers(0, 256, (68, 120, 3), dtype=np.uint8)
+        frame = np.asarray(Image.fromarray(low).resize((1920, 1080), Image.BICUBIC)).astype(np.int16)
+        frame = np.clip(frame + rng.integers(-2, 3, frame.shape), 0, 255).astype(np.uint8)
     buf = io.BytesIO()
     Image.fromarray(frame[..., ::-1]).save(buf, format="JPEG", quality=args.quality, subsampling=2)
     data = buf.getvalue()
@@ -58,7 +64,7 @@ def main():
             eng.decode_jpeg_batch(files, threads=T)
         dt = (time.perf_counter() - t0) / reps
         batch[str(T)] = {"ms_per_32_frames": round(dt * 1e3, 2), "frames_per_s": round(32 / dt, 1)}
-    print(json.dumps({"jpeg_bytes": len(data), "quality": args.quality, "frame": "1920x1080 4:2:0", "batch_by_host_threads": batch,
+    print(json.dumps({"jpeg_bytes": len(data), "quality": args.quality, "frame": "1920x1080 4:2:0", "content": args.content, "batch_by_host_threads": batch,
                       "host_cores": os.cpu_count(),
                       "pf_decode_jpeg_ms": round(t_dev * 1e3, 3), "frames_per_s_one_stream": round(1.0 / t_dev, 1),
                       "libjpeg_host_decode_ms": round(t_pil * 1e3, 3), "host_frame_upload_and_gate_ms": round(t_up * 1e3, 3),
