@@ -427,8 +427,8 @@ class Engine:
         """n JPEG byte strings of one size -> (device pointer of [n][H][W][3] BGR, n, H, W) for run_frames_device: Huffman
         decoding of the files on `threads` host threads, the device stages once over the batch."""
         n = len(files)
-        bufs = [(C.c_ubyte * len(d)).from_buffer_copy(d) for d in files]
-        ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+        files = [bytes(d) for d in files]            # immutable: the pointers below stay valid for the call, no copies
+        ptrs = (C.c_void_p * n)(*[C.cast(C.c_char_p(d), C.c_void_p) for d in files])
         sizes = (C.c_size_t * n)(*[len(d) for d in files])
         hh, ww, d = C.c_int(0), C.c_int(0), C.c_void_p(0)
         self._check(self.lib.pf_decode_jpeg_batch(self.h, n, ptrs, sizes, int(threads), C.byref(hh), C.byref(ww), C.byref(d)),

@@ -6,6 +6,7 @@
 // over 1x1 chroma (4:4:4, 4:2:2, 4:2:0), interleaved or one scan per component, restart markers.  Anything else -- progressive,
 // arithmetic coding, 12-bit, CMYK / Adobe RGB, other sampling grids -- is refused with a message, never decoded approximately.
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -446,11 +447,20 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     // ---- entropy decoding: one file per task ------------------------------------------------------------------------------------
     std::vector<const char*> errs((size_t)n, nullptr);
     std::vector<size_t> used((size_t)n, 0);
+    std::mutex enqueue;
+    std::vector<hipError_t> copy_rc((size_t)n, hipSuccess);
     auto work = [&](int first, int step) {
+        (void)hipSetDevice(h->device);
         for (int f = first; f < n; f += step) {
             unsigned char* region = s.h_pack + (size_t)f * frame_pack;
             errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], reinterpret_cast<unsigned*>(region),
                                         reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &used[f]);
+            if (errs[f]) continue;
+            // only what the decoder wrote crosses PCIe -- the block table and the records --, and it leaves as soon as this file
+            // is done, while the other threads are still decoding theirs
+            std::lock_guard<std::mutex> lock(enqueue);
+            copy_rc[f] = hipMemcpyAsync(s.d_pack + (size_t)f * frame_pack, region, (size_t)hd.total_blocks * 4 + used[f] * sizeof(short),
+                                        hipMemcpyHostToDevice, h->stream);
         }
     };
     const auto t_start = std::chrono::steady_clock::now();
@@ -466,9 +476,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     for (int f = 0; f < n; ++f)
         if (errs[f]) PF_FAIL(h, "pf_decode_jpeg: image %d: %s", f, errs[f]);
     const auto t_entropy = std::chrono::steady_clock::now();
-    for (int f = 0; f < n; ++f)      // only what the decoder wrote crosses PCIe: the block table and the records
-        PF_HIP(h, hipMemcpyAsync(s.d_pack + (size_t)f * frame_pack, s.h_pack + (size_t)f * frame_pack,
-                                 (size_t)hd.total_blocks * 4 + used[f] * sizeof(short), hipMemcpyHostToDevice, h->stream));
+    for (int f = 0; f < n; ++f) PF_HIP(h, copy_rc[f]);
     {
         JpegUnpackArgs ua{};
         ua.pack = s.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks;
