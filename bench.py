@@ -462,6 +462,32 @@ def main():
                 "h2d_GBps": round(args.frames * hs * args.frame_hw[0] * args.frame_hw[1] * 3 / dt / 1e9, 2), "steps": hs,
                 "note": "frames handed over in pf_host_alloc (page-locked) host memory, copied inside the call on each lane's "
                         "stream; results stay on the device (9.5 KB/frame)"}
+    # ---- JPEG-file ingest (never the headline): the same step starting from baseline JPEG files in host memory --------
+    jpeg = None
+    if workload == "pipeline" and rank == 0 and world == 1 and hasattr(state, "enable_jpeg_frames") and not args.no_probes:
+        try:
+            import PIL  # noqa: F401  (only to WRITE the test files; the decoder is the engine's)
+            have_pil = True
+        except ImportError:
+            have_pil = False
+        if have_pil:
+            total_bytes = state.enable_jpeg_frames(90)
+            thr = max(1, min(32, (os.cpu_count() or 8) // max(1, lanes)))
+            state.step_jpeg(thr)
+            state.sync()
+            js = max(2, min(args.steps, 6))
+            t1 = time.perf_counter()
+            for _ in range(js):
+                state.step_jpeg(thr)
+            state.sync()
+            dt = time.perf_counter() - t1
+            state.check()
+            jpeg = {"faces_per_s": round(faces_per_step * js / dt, 1), "frames_per_s": round(args.frames * js / dt, 1),
+                    "jpeg_MB_per_s": round(total_bytes * js / dt / 1e6, 1), "mean_file_KB": round(total_bytes / args.frames / 1e3, 1),
+                    "host_threads_per_lane": thr, "steps": js,
+                    "note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
+                            "(Huffman decoding on host threads, dequantisation / IDCT / upsampling / colour conversion on the device, "
+                            "bit-identical with libjpeg) feeds pf_run_frames; one host thread per lane drives decode + pipeline"}
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
@@ -489,7 +515,7 @@ def main():
                   "dense_kernels": dense_kernel_table(prof, PROF_STEPS, faces_per_launch, args.dtype) if args.model == "student" else None,
                   "sustained": sustained,
                   "latency": latency,
-                  "pcie_inclusive": pcie,
+                  "pcie_inclusive": pcie, "jpeg_ingest": jpeg,
                   "weight_broadcast": bcast,
                   "setup_s": round(setup_s, 2),
                   "kernel_ms_per_lane_step": {k: round(v[0] / PROF_STEPS, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},

@@ -245,6 +245,29 @@ class PipelineWorkload:
                                        self.counts.data_ptr(), self.boxes.data_ptr(), self.kps.data_ptr(),
                                        self.scores.data_ptr())
 
+    def enable_jpeg_frames(self, quality: int = 90):
+        """Frame ingest seam (next-row N2), file side: this lane's frames as baseline 4:2:0 JPEG files (PIL / libjpeg encodes
+        them once, outside any timed region).  Returns the total size of the files."""
+        import io
+        from PIL import Image
+        fr = self.frames.cpu().numpy()
+        self.jpegs = []
+        for i in range(self.F):
+            buf = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(fr[i][..., ::-1])).save(buf, format="JPEG", quality=quality, subsampling=2)
+            self.jpegs.append(buf.getvalue())
+        return sum(len(j) for j in self.jpegs)
+
+    def step_jpeg(self, threads: int):
+        """One step from JPEG FILES: pf_decode_jpeg_batch (Huffman on `threads` host threads, the rest on this lane's stream)
+        straight into pf_run_frames on the decoded device frames."""
+        d, n, h, w = self.eng.decode_jpeg_batch(self.jpegs, threads)
+        assert (n, h, w) == (self.F, self.H, self.W)
+        self.eng.run_frames_device(d, self.F, h, w, 0.5, 0.3, 1600.0, self.K, d_planted=self.rows.data_ptr(), rows=self.ROWS,
+                                   d_counts=self.h_counts.ctypes.data, d_boxes=self.h_boxes.ctypes.data,
+                                   d_kps=self.h_kps.ctypes.data, d_scores=self.h_scores.ctypes.data,
+                                   out_mem=_native.PF_MEM_HOST_PINNED)
+
     def latency_p50(self, frames: int, reps: int = 40):
         """p50 / p99 wall time (ms) of one synchronous call on `frames` frames (submit -> results complete)."""
         import time
@@ -311,6 +334,17 @@ class MultiLanePipeline:
     def step_host(self):
         for wl in self.lanes:
             wl.step_host()
+
+    def enable_jpeg_frames(self, quality: int = 90):
+        return sum(wl.enable_jpeg_frames(quality) for wl in self.lanes)
+
+    def step_jpeg(self, threads: int):
+        """Every lane decodes and runs its files from its own host thread (the decode call blocks on the Huffman stage; ctypes
+        releases the GIL), so one lane's host work overlaps the others' kernels."""
+        from concurrent.futures import ThreadPoolExecutor
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(len(self.lanes))
+        list(self._pool.map(lambda wl: wl.step_jpeg(threads), self.lanes))
 
     def profile(self, steps: int):
         """Per-kernel HIP-event times of lane 0 running ALONE (profiling serialises its launches);
