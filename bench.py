@@ -470,7 +470,9 @@ def main():
             have_pil = True
         except ImportError:
             have_pil = False
-        if have_pil:
+        try:
+            if not have_pil:
+                raise ImportError("PIL not installed: no way to write the JPEG test files")
             total_bytes = state.enable_jpeg_frames(90)
             thr = max(1, min(32, (os.cpu_count() or 8) // max(1, lanes)))
             state.step_jpeg(thr)
@@ -488,6 +490,8 @@ def main():
                     "note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
                             "(Huffman decoding on host threads, dequantisation / IDCT / upsampling / colour conversion on the device, "
                             "bit-identical with libjpeg) feeds pf_run_frames; one host thread per lane drives decode + pipeline"}
+        except Exception as e:          # a probe must never take the headline measurement down with it
+            jpeg = {"skipped": "%s: %s" % (type(e).__name__, e)}
     ms_per_step = elapsed / args.steps * 1e3
     faces_total = faces_per_step * world * args.steps
     value = faces_total / elapsed
