@@ -151,7 +151,7 @@ int pf_forget_frames(pf_handle* h);
  * 16-bit coefficient blocks go to the device through page-locked memory and dequantisation, inverse DCT, chroma upsampling
  * and YCbCr->BGR run as kernels, bit-identical with libjpeg(-turbo)'s default decoder (JDCT_ISLOW, fancy upsampling), i.e.
  * with what cv2.imread returns.  The frame (packed BGR, 3*width bytes per row) stays in device memory owned by the handle until
- * the next pf_decode_jpeg; *d_bgr is that pointer -- hand it to pf_set_frame / pf_detect / pf_landmarks / pf_run_frames /
+ * the decode after the next one; *d_bgr is that pointer -- hand it to pf_set_frame / pf_detect / pf_landmarks / pf_run_frames /
  * pf_track_frame with mem = PF_MEM_DEVICE.  bgr_host (may be NULL): host copy for drawing, height*width*3 bytes (sizes from
  * pf_jpeg_info).  Supported: 8-bit baseline / extended-sequential Huffman JPEG, greyscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
  * restart markers; progressive, arithmetic-coded, 12-bit, CMYK / Adobe-RGB files and other sampling grids are refused with an
@@ -161,7 +161,10 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
                    uint8_t* bgr_host);
 /* n files of one size and sampling -> [n][height][width][3] in device memory (*d_frames, same ownership), ready for
  * pf_run_frames(mem = PF_MEM_DEVICE): the files' Huffman streams are decoded on `threads` host threads (one file per task), the
- * device stages run once over the whole batch. */
+ * device stages run once over the whole batch.  Asynchronous like pf_run_frames: the frames are valid in the order of the
+ * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets
+ * alternate, so the pointer of call k stays valid until call k + 2 and the host work of call k + 1 overlaps the pipeline still
+ * running on the frames of call k. */
 int pf_decode_jpeg_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads, int* height,
                          int* width, const uint8_t** d_frames);
 

@@ -5,8 +5,8 @@
 // Supported: 8-bit baseline / extended-sequential Huffman (SOF0 / SOF1), greyscale or YCbCr with luma sampling 1x1, 2x1 or 2x2
 // over 1x1 chroma (4:4:4, 4:2:2, 4:2:0), interleaved or one scan per component, restart markers.  Anything else -- progressive,
 // arithmetic coding, 12-bit, CMYK / Adobe RGB, other sampling grids -- is refused with a message, never decoded approximately.
+#include <atomic>
 #include <chrono>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -361,11 +361,16 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
 }  // namespace
 
 void JpegState::release() {
-    if (h_pack) (void)hipHostFree(h_pack);
-    if (d_pack) (void)hipFree(d_pack);
+    for (Slot& sl : slot) {
+        if (sl.h_pack) (void)hipHostFree(sl.h_pack);
+        if (sl.d_pack) (void)hipFree(sl.d_pack);
+        if (sl.d_bgr) (void)hipFree(sl.d_bgr);
+        if (sl.uploaded) (void)hipEventDestroy(sl.uploaded);
+        if (sl.consumed) (void)hipEventDestroy(sl.consumed);
+    }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (d_coef) (void)hipFree(d_coef);
     if (d_planes) (void)hipFree(d_planes);
-    if (d_bgr) (void)hipFree(d_bgr);
     if (d_quant) (void)hipFree(d_quant);
     *this = JpegState{};
 }
@@ -386,7 +391,7 @@ int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int
 
 // n equally shaped JPEGs -> [n][H][W][3] in device memory; the entropy decoding of the files runs on `threads` host threads
 static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads,
-                             int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
+                             int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host, bool final_sync) {
     if (n < 1 || !jpegs || !sizes) PF_FAIL(h, "pf_decode_jpeg: bad arguments");
     PF_HIP(h, hipSetDevice(h->device));
     std::vector<JpegHeader> hds((size_t)n);
@@ -400,89 +405,92 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     const JpegHeader& hd = hds[0];
     JpegState& s = h->jpeg;
+    s.cur ^= 1;
+    JpegState::Slot& sl = s.slot[s.cur];
+    if (!s.copy_stream) PF_HIP(h, hipStreamCreateWithFlags(&s.copy_stream, hipStreamNonBlocking));
+    if (!sl.uploaded) {
+        PF_HIP(h, hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+        PF_HIP(h, hipEventCreateWithFlags(&sl.consumed, hipEventDisableTiming));
+    }
+    if (sl.in_flight) PF_HIP(h, hipEventSynchronize(sl.consumed));   // two decodes ago: long done; the slot's buffers are free
+    sl.in_flight = false;
     const size_t coef_bytes = (size_t)hd.total_blocks * 64 * sizeof(short) * n;
-    if (s.coef_cap < coef_bytes) {
-        PF_HIP(h, hipStreamSynchronize(h->stream));
+    const size_t plane_bytes = (size_t)hd.total_blocks * 64;
+    if (s.coef_cap < coef_bytes || s.planes_cap < plane_bytes * n || s.quant_cap < (size_t)n) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));                  // intermediates are shared by both slots: drain before growing
         if (s.d_coef) (void)hipFree(s.d_coef);
-        s.d_coef = nullptr; s.coef_cap = 0;
+        if (s.d_planes) (void)hipFree(s.d_planes);
+        if (s.d_quant) (void)hipFree(s.d_quant);
+        s.d_coef = nullptr; s.d_planes = nullptr; s.d_quant = nullptr; s.coef_cap = s.planes_cap = s.quant_cap = 0;
         PF_HIP(h, hipMalloc((void**)&s.d_coef, coef_bytes));
-        s.coef_cap = coef_bytes;
+        PF_HIP(h, hipMalloc((void**)&s.d_planes, plane_bytes * n));
+        PF_HIP(h, hipMalloc((void**)&s.d_quant, (size_t)n * 3 * 64 * sizeof(unsigned short)));
+        s.coef_cap = coef_bytes; s.planes_cap = plane_bytes * n; s.quant_cap = (size_t)n;
     }
     // packed records: worst case 65 values per block (every block is written by exactly one scan: decode_scans refuses a component that appears twice)
     const size_t frame_pack = ((size_t)hd.total_blocks * (4 + 65 * sizeof(short)) + 255) / 256 * 256;
-    if (s.pack_cap < frame_pack * n) {
+    if (sl.pack_cap < frame_pack * n) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
-        if (s.h_pack) (void)hipHostFree(s.h_pack);
-        if (s.d_pack) (void)hipFree(s.d_pack);
-        s.h_pack = nullptr; s.d_pack = nullptr; s.pack_cap = 0;
-        PF_HIP(h, hipHostMalloc((void**)&s.h_pack, frame_pack * n, hipHostMallocPortable));
-        PF_HIP(h, hipMalloc((void**)&s.d_pack, frame_pack * n));
-        s.pack_cap = frame_pack * n;
-    }
-    const size_t plane_bytes = (size_t)hd.total_blocks * 64;
-    if (s.planes_cap < plane_bytes * n) {
-        PF_HIP(h, hipStreamSynchronize(h->stream));
-        if (s.d_planes) (void)hipFree(s.d_planes);
-        s.d_planes = nullptr; s.planes_cap = 0;
-        PF_HIP(h, hipMalloc((void**)&s.d_planes, plane_bytes * n));
-        s.planes_cap = plane_bytes * n;
+        if (sl.h_pack) (void)hipHostFree(sl.h_pack);
+        if (sl.d_pack) (void)hipFree(sl.d_pack);
+        sl.h_pack = nullptr; sl.d_pack = nullptr; sl.pack_cap = 0;
+        PF_HIP(h, hipHostMalloc((void**)&sl.h_pack, frame_pack * n, hipHostMallocPortable));
+        PF_HIP(h, hipMalloc((void**)&sl.d_pack, frame_pack * n));
+        sl.pack_cap = frame_pack * n;
     }
     const size_t out_bytes = (size_t)hd.H * hd.W * 3 * n;
-    if (s.bgr_cap < out_bytes) {
+    if (sl.bgr_cap < out_bytes) {
         PF_HIP(h, hipStreamSynchronize(h->stream));
-        if (s.d_bgr) (void)hipFree(s.d_bgr);
-        s.d_bgr = nullptr; s.bgr_cap = 0;
+        if (sl.d_bgr) (void)hipFree(sl.d_bgr);
+        sl.d_bgr = nullptr; sl.bgr_cap = 0;
         h->alloc_epoch++;                          // a captured graph may hold the old frame pointer
-        PF_HIP(h, hipMalloc((void**)&s.d_bgr, out_bytes));
-        s.bgr_cap = out_bytes;
+        PF_HIP(h, hipMalloc((void**)&sl.d_bgr, out_bytes));
+        sl.bgr_cap = out_bytes;
     }
-    if (s.quant_cap < (size_t)n) {
-        PF_HIP(h, hipStreamSynchronize(h->stream));
-        if (s.d_quant) (void)hipFree(s.d_quant);
-        s.d_quant = nullptr; s.quant_cap = 0;
-        PF_HIP(h, hipMalloc((void**)&s.d_quant, (size_t)n * 3 * 64 * sizeof(unsigned short)));
-        s.quant_cap = (size_t)n;
-    }
-    PF_HIP(h, hipStreamSynchronize(h->stream));     // the previous decode's upload has left the pinned buffer
     // ---- entropy decoding: one file per task ------------------------------------------------------------------------------------
     std::vector<const char*> errs((size_t)n, nullptr);
     std::vector<size_t> used((size_t)n, 0);
-    std::mutex enqueue;
-    std::vector<hipError_t> copy_rc((size_t)n, hipSuccess);
+    std::vector<std::atomic<int>> done((size_t)n);
+    for (auto& d : done) d.store(0, std::memory_order_relaxed);
+    // workers are pure CPU (a HIP call from a fresh thread pays the runtime's per-thread set-up under its global lock: 60 ms
+    // stalls with three lanes decoding at once); the calling thread uploads each file's records as soon as that file is done
     auto work = [&](int first, int step) {
-        (void)hipSetDevice(h->device);
         for (int f = first; f < n; f += step) {
-            unsigned char* region = s.h_pack + (size_t)f * frame_pack;
+            unsigned char* region = sl.h_pack + (size_t)f * frame_pack;
             errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], reinterpret_cast<unsigned*>(region),
                                         reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &used[f]);
-            if (errs[f]) continue;
-            // only what the decoder wrote crosses PCIe -- the block table and the records --, and it leaves as soon as this file
-            // is done, while the other threads are still decoding theirs
-            std::lock_guard<std::mutex> lock(enqueue);
-            copy_rc[f] = hipMemcpyAsync(s.d_pack + (size_t)f * frame_pack, region, (size_t)hd.total_blocks * 4 + used[f] * sizeof(short),
-                                        hipMemcpyHostToDevice, h->stream);
+            done[f].store(1, std::memory_order_release);
         }
     };
     const auto t_start = std::chrono::steady_clock::now();
     const int T = std::max(1, std::min(threads, n));
-    if (T == 1) {
+    std::vector<std::thread> pool;
+    if (T > 1)
+        for (int t = 0; t < T; ++t) pool.emplace_back(work, t, T);
+    else
         work(0, 1);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t) pool.emplace_back(work, t, T);
-        work(0, T);
-        for (auto& th : pool) th.join();
+    hipError_t copy_rc = hipSuccess;
+    for (int f = 0; f < n; ++f) {        // only what the decoder wrote crosses PCIe: the block table and the records
+        while (!done[f].load(std::memory_order_acquire)) std::this_thread::yield();
+        if (errs[f] || copy_rc != hipSuccess) continue;
+        copy_rc = hipMemcpyAsync(sl.d_pack + (size_t)f * frame_pack, sl.h_pack + (size_t)f * frame_pack,
+                                 (size_t)hd.total_blocks * 4 + used[f] * sizeof(short), hipMemcpyHostToDevice, s.copy_stream);
     }
+    for (auto& th : pool) th.join();
     for (int f = 0; f < n; ++f)
         if (errs[f]) PF_FAIL(h, "pf_decode_jpeg: image %d: %s", f, errs[f]);
+    PF_HIP(h, copy_rc);
     const auto t_entropy = std::chrono::steady_clock::now();
-    for (int f = 0; f < n; ++f) PF_HIP(h, copy_rc[f]);
+    PF_HIP(h, hipEventRecord(sl.uploaded, s.copy_stream));
+    PF_HIP(h, hipStreamWaitEvent(h->stream, sl.uploaded, 0));        // the engine's stream expands them once they are all there
     {
         JpegUnpackArgs ua{};
-        ua.pack = s.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks;
+        ua.pack = sl.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks;
         ProfScope ps(h, "jpeg_unpack");
         PF_LAUNCH(jpeg_unpack_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ua);
     }
+    PF_HIP(h, hipEventRecord(sl.consumed, h->stream));
+    sl.in_flight = true;
     std::vector<unsigned short> qt((size_t)n * 3 * 64, 0);
     for (int f = 0; f < n; ++f)
         for (int c = 0; c < hd.ncomp; ++c)
@@ -501,7 +509,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     JpegColorArgs ca{};
     ca.y = ia.plane[0]; ca.ys = hd.c[0].bw * 8;
-    ca.W = hd.W; ca.H = hd.H; ca.out = s.d_bgr; ca.frame_plane_bytes = plane_bytes;
+    ca.W = hd.W; ca.H = hd.H; ca.out = sl.d_bgr; ca.frame_plane_bytes = plane_bytes;
     if (hd.ncomp == 1) {
         ca.mode = 0;
     } else {
@@ -514,8 +522,8 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         ProfScope ps(h, "jpeg_color");
         PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
     }
-    if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, s.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, sl.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
+    if (final_sync || bgr_host) PF_HIP(h, hipStreamSynchronize(h->stream));
     if (getenv("PEPPA_JPEG_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
         size_t up = 0;
@@ -526,19 +534,19 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     if (height) *height = hd.H;
     if (width) *width = hd.W;
-    if (d_bgr) *d_bgr = s.d_bgr;
+    if (d_bgr) *d_bgr = sl.d_bgr;
     return 0;
 }
 
 int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host) {
     if (!h) return 1;
-    return jpeg_decode_batch(h, 1, &jpeg, &bytes, 1, height, width, d_bgr, bgr_host);
+    return jpeg_decode_batch(h, 1, &jpeg, &bytes, 1, height, width, d_bgr, bgr_host, true);
 }
 
 int pf_decode_jpeg_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads, int* height, int* width,
                          const uint8_t** d_frames) {
     if (!h) return 1;
-    return jpeg_decode_batch(h, n, jpegs, sizes, threads, height, width, d_frames, nullptr);
+    return jpeg_decode_batch(h, n, jpegs, sizes, threads, height, width, d_frames, nullptr, false);
 }
 
 }  // extern "C"

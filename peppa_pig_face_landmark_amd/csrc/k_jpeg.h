@@ -12,15 +12,24 @@
 
 // per-handle buffers of the decoder (jpeg.inl)
 struct JpegState {
-    unsigned char* h_pack = nullptr;  // page-locked: per frame [block table u32 x blocks][records: length, coefficients in zigzag
-    unsigned char* d_pack = nullptr;  //   order up to the last non-zero one] -- what the entropy decoder writes and PCIe carries
-    size_t pack_cap = 0;
+    // two alternating slots: a batch decode of step k + 1 (host Huffman loop, uploads on the copy stream) overlaps the pipeline
+    // that is still reading the frames of step k on the engine's stream
+    struct Slot {
+        unsigned char* h_pack = nullptr;  // page-locked: per frame [block table u32 x blocks][records: length, coefficients in zigzag
+        unsigned char* d_pack = nullptr;  //   order up to the last non-zero one] -- what the entropy decoder writes and PCIe carries
+        size_t pack_cap = 0;
+        unsigned char* d_bgr = nullptr;   // the decoded frames, packed BGR
+        size_t bgr_cap = 0;
+        hipEvent_t uploaded = nullptr;    // this slot's records have arrived (copy stream)
+        hipEvent_t consumed = nullptr;    // ... and have been expanded (engine stream): the slot may be refilled
+        bool in_flight = false;
+    } slot[2];
+    int cur = 0;
+    hipStream_t copy_stream = nullptr;
     short* d_coef = nullptr;          // dense [block][64] natural-order blocks, expanded on the device
     size_t coef_cap = 0;
     unsigned char* d_planes = nullptr;    // component planes after the inverse DCT
     size_t planes_cap = 0;
-    unsigned char* d_bgr = nullptr;       // the decoded frame, packed BGR
-    size_t bgr_cap = 0;
     unsigned short* d_quant = nullptr;    // [frames][3][64]
     size_t quant_cap = 0;
     void release();

@@ -238,9 +238,12 @@ inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorInvalidValue; }
 double pf_emu_now_ms();
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new pf_emu_event{0}; return hipSuccess; }
+#define hipEventDisableTiming 0x2u
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new pf_emu_event{0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = pf_emu_now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }   // the emulator's streams are synchronous
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 template <typename... KArgs, typename... Args>
