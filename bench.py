@@ -340,8 +340,16 @@ def main():
             rank, world, bcast["rccl_version"], world, bcast["bytes"], bcast["ms"]), file=sys.stderr, flush=True)
     except Exception as e:   # noqa: BLE001
         if use_dist:
-            raise                                  # N > 1 cannot run without the broadcast
-        bcast["via"] = "single GPU: local pf_load_program (RCCL self-test failed: %s)" % e
+            # N > 1 cannot run without the weights on every rank.  The engine's own communicator failed on this rank (and, being
+            # a symmetric set-up step, on the others): distribute the blobs through torch.distributed's RCCL communicator
+            # instead and say so in the JSON -- a scaling line with a documented detour beats no line.
+            print("[bench] rank %d: pf_broadcast_weights failed (%s); falling back to torch.distributed broadcast" % (rank, e),
+                  file=sys.stderr, flush=True)
+            blobs, ms = bs.broadcast_blobs(blobs, dev, rank)
+            bcast.update({"ms": ms, "bytes": sum(len(b) for b in blobs.values()),
+                          "via": "torch.distributed broadcast over RCCL (pf_broadcast_weights failed: %s)" % e})
+        else:
+            bcast["via"] = "single GPU: local pf_load_program (RCCL self-test failed: %s)" % e
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
     lanes = args.lanes if workload == "pipeline" else 1
     if lanes == 1:
