@@ -481,24 +481,27 @@ def main():
         try:
             if not have_pil:
                 raise ImportError("PIL not installed: no way to write the JPEG test files")
-            total_bytes = state.enable_jpeg_frames(90)
             thr = max(1, min(32, (os.cpu_count() or 8) // max(1, lanes)))
-            for _ in range(2):          # the decoder alternates two frame buffers: both get their captured graph before the clock starts
-                state.step_jpeg(thr)
-            state.sync()
-            js = max(2, min(args.steps, 6))
-            t1 = time.perf_counter()
-            for _ in range(js):
-                state.step_jpeg(thr)
-            state.sync()
-            dt = time.perf_counter() - t1
-            state.check()
-            jpeg = {"faces_per_s": round(faces_per_step * js / dt, 1), "frames_per_s": round(args.frames * js / dt, 1),
-                    "jpeg_MB_per_s": round(total_bytes * js / dt / 1e6, 1), "mean_file_KB": round(total_bytes / args.frames / 1e3, 1),
-                    "host_threads_per_lane": thr, "steps": js,
-                    "note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
-                            "(Huffman decoding on host threads, dequantisation / IDCT / upsampling / colour conversion on the device, "
-                            "bit-identical with libjpeg) feeds pf_run_frames; one host thread per lane drives decode + pipeline"}
+            jpeg = {"note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
+                            "feeds pf_run_frames, one host thread per lane drives decode + pipeline; output bit-identical with libjpeg. "
+                            "'restart_markers': files with a restart marker per MCU row -- the Huffman stream is decoded on the device, one thread "
+                            "per restart interval; 'no_restart_markers': the Huffman stream is decoded on host threads",
+                    "host_threads_per_lane": thr}
+            for key, rows in (("restart_markers", 1), ("no_restart_markers", 0)):
+                total_bytes = state.enable_jpeg_frames(90, rows)
+                for _ in range(2):      # the decoder alternates two frame buffers: both get their captured graph before the clock starts
+                    state.step_jpeg(thr)
+                state.sync()
+                js = max(2, min(args.steps, 6))
+                t1 = time.perf_counter()
+                for _ in range(js):
+                    state.step_jpeg(thr)
+                state.sync()
+                dt = time.perf_counter() - t1
+                state.check()
+                jpeg[key] = {"faces_per_s": round(faces_per_step * js / dt, 1), "frames_per_s": round(args.frames * js / dt, 1),
+                             "jpeg_MB_per_s": round(total_bytes * js / dt / 1e6, 1), "mean_file_KB": round(total_bytes / args.frames / 1e3, 1),
+                             "steps": js}
         except Exception as e:          # a probe must never take the headline measurement down with it
             jpeg = {"skipped": "%s: %s" % (type(e).__name__, e)}
     ms_per_step = elapsed / args.steps * 1e3

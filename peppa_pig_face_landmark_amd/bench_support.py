@@ -245,16 +245,18 @@ class PipelineWorkload:
                                        self.counts.data_ptr(), self.boxes.data_ptr(), self.kps.data_ptr(),
                                        self.scores.data_ptr())
 
-    def enable_jpeg_frames(self, quality: int = 90):
+    def enable_jpeg_frames(self, quality: int = 90, restart_rows: int = 0):
         """Frame ingest seam (next-row N2), file side: this lane's frames as baseline 4:2:0 JPEG files (PIL / libjpeg encodes
-        them once, outside any timed region).  Returns the total size of the files."""
+        them once, outside any timed region), optionally with a restart marker every `restart_rows` MCU rows (such files have
+        their Huffman stream decoded on the device).  Returns the total size of the files."""
         import io
         from PIL import Image
         fr = self.frames.cpu().numpy()
         self.jpegs = []
         for i in range(self.F):
             buf = io.BytesIO()
-            Image.fromarray(np.ascontiguousarray(fr[i][..., ::-1])).save(buf, format="JPEG", quality=quality, subsampling=2)
+            Image.fromarray(np.ascontiguousarray(fr[i][..., ::-1])).save(buf, format="JPEG", quality=quality, subsampling=2,
+                                                                        **(dict(restart_marker_rows=restart_rows) if restart_rows else {}))
             self.jpegs.append(buf.getvalue())
         return sum(len(j) for j in self.jpegs)
 
@@ -335,8 +337,8 @@ class MultiLanePipeline:
         for wl in self.lanes:
             wl.step_host()
 
-    def enable_jpeg_frames(self, quality: int = 90):
-        return sum(wl.enable_jpeg_frames(quality) for wl in self.lanes)
+    def enable_jpeg_frames(self, quality: int = 90, restart_rows: int = 0):
+        return sum(wl.enable_jpeg_frames(quality, restart_rows) for wl in self.lanes)
 
     def step_jpeg(self, threads: int):
         """Every lane decodes and runs its files from its own host thread (the decode call blocks on the Huffman stage; ctypes

@@ -358,6 +358,68 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
     return nullptr;
 }
 
+// Device entropy decoding applies when the file has restart markers, ONE interleaved scan in frame component order and table ids
+// 0 / 1: copies the scan, the interval offsets and the lookup tables into the frame's pinned region.  Returns false (file untouched)
+// when the file does not qualify or its markers do not add up -- the host decoder then takes it.
+bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHeader& hd, unsigned char* region, size_t region_cap,
+                           JpegFrameDesc* desc, size_t* used_bytes) {
+    if (hd.restart <= 0 || sos + 4 > n || d[sos] != 0xFF || d[sos + 1] != 0xDA) return false;
+    const size_t len = jpeg_be16(d + sos + 2);
+    if (len < 2 || sos + 2 + len > n) return false;
+    const unsigned char* s = d + sos + 4;
+    const size_t sl = len - 2;
+    if (sl < 1 || s[0] != hd.ncomp || sl < (size_t)1 + 2 * hd.ncomp + 3) return false;
+    for (int i = 0; i < hd.ncomp; ++i) {
+        if (s[1 + 2 * i] != hd.c[i].id) return false;
+        hd.c[i].td = s[2 + 2 * i] >> 4; hd.c[i].ta = s[2 + 2 * i] & 15;
+        if (hd.c[i].td > 1 || hd.c[i].ta > 1 || !hd.dc[hd.c[i].td].present || !hd.ac[hd.c[i].ta].present) return false;
+    }
+    if (s[1 + 2 * hd.ncomp] != 0 || s[2 + 2 * hd.ncomp] != 63 || s[3 + 2 * hd.ncomp] != 0) return false;
+    const size_t begin = sos + 2 + len;
+    const int total_mcus = hd.mcux * hd.mcuy;
+    const int want = (total_mcus + hd.restart - 1) / hd.restart;
+    std::vector<unsigned> offs;
+    offs.reserve((size_t)want);
+    offs.push_back(0);
+    size_t q = begin, end = n;
+    while (q < n) {
+        const unsigned char* ff = static_cast<const unsigned char*>(memchr(d + q, 0xFF, n - q));
+        if (!ff) break;
+        q = (size_t)(ff - d);
+        if (q + 1 >= n) break;
+        const int m = d[q + 1];
+        if (m == 0x00) { q += 2; continue; }
+        if (m == 0xFF) { q += 1; continue; }
+        if (m >= 0xD0 && m <= 0xD7) { offs.push_back((unsigned)(q + 2 - begin)); q += 2; continue; }
+        end = q;                                   // any other marker ends the scan
+        if (m != 0xD9) return false;               // more scans / tables follow: not the single-scan case
+        break;
+    }
+    if ((int)offs.size() != want) return false;
+    const size_t scan_len = end - begin;
+    const size_t offs_off = (scan_len + 15) / 16 * 16;
+    const size_t tables_off = (offs_off + offs.size() * 4 + 15) / 16 * 16;
+    if (tables_off + sizeof(JpegGpuTables) > region_cap) return false;
+    memcpy(region, d + begin, scan_len);
+    memcpy(region + offs_off, offs.data(), offs.size() * 4);
+    JpegGpuTables* t = reinterpret_cast<JpegGpuTables*>(region + tables_off);
+    for (int i = 0; i < 4; ++i) {
+        const JpegHuff& src = i < 2 ? hd.dc[i] : hd.ac[i - 2];
+        memcpy(t->look[i], src.look, sizeof(src.look));
+        memcpy(t->fast_ac[i], src.fast_ac, sizeof(src.fast_ac));
+        memcpy(t->maxcode[i], src.maxcode, sizeof(src.maxcode));
+        memcpy(t->valoff[i], src.valoff, sizeof(src.valoff));
+        memcpy(t->vals[i], src.vals, sizeof(src.vals));
+    }
+    desc->scan_off = 0; desc->scan_len = (unsigned)scan_len;
+    desc->offs_off = (unsigned)offs_off; desc->n_intervals = (unsigned)offs.size();
+    desc->tables_off = (unsigned)tables_off; desc->restart = (unsigned)hd.restart; desc->pad = 0;
+    desc->tdta = 0;
+    for (int i = 0; i < hd.ncomp; ++i) desc->tdta |= ((unsigned)hd.c[i].td << i) | ((unsigned)hd.c[i].ta << (4 + i));
+    *used_bytes = tables_off + sizeof(JpegGpuTables);
+    return true;
+}
+
 }  // namespace
 
 void JpegState::release() {
@@ -372,6 +434,7 @@ void JpegState::release() {
     if (d_coef) (void)hipFree(d_coef);
     if (d_planes) (void)hipFree(d_planes);
     if (d_quant) (void)hipFree(d_quant);
+    if (d_desc) (void)hipFree(d_desc);
     *this = JpegState{};
 }
 
@@ -449,7 +512,9 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     // ---- entropy decoding: one file per task ------------------------------------------------------------------------------------
     std::vector<const char*> errs((size_t)n, nullptr);
-    std::vector<size_t> used((size_t)n, 0);
+    std::vector<size_t> used((size_t)n, 0);          // bytes of each frame's region that cross PCIe
+    std::vector<JpegFrameDesc> descs((size_t)n);
+    const bool device_entropy = getenv("PEPPA_JPEG_HOST_ENTROPY") == nullptr;   // A/B switch: force the host Huffman loop
     std::vector<std::atomic<int>> done((size_t)n);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     // workers are pure CPU (a HIP call from a fresh thread pays the runtime's per-thread set-up under its global lock: 60 ms
@@ -457,8 +522,15 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     auto work = [&](int first, int step) {
         for (int f = first; f < n; f += step) {
             unsigned char* region = sl.h_pack + (size_t)f * frame_pack;
-            errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], reinterpret_cast<unsigned*>(region),
-                                        reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &used[f]);
+            descs[f] = JpegFrameDesc{};
+            if (device_entropy && jpeg_stage_for_device(jpegs[f], sizes[f], sos[f], hds[f], region, frame_pack, &descs[f], &used[f])) {
+                // nothing else to do on the host: the scan is decoded by jpeg_huffman_kernel
+            } else {
+                size_t values = 0;
+                errs[f] = jpeg_decode_scans(jpegs[f], sizes[f], sos[f], hds[f], reinterpret_cast<unsigned*>(region),
+                                            reinterpret_cast<short*>(region + (size_t)hd.total_blocks * 4), &values);
+                used[f] = (size_t)hd.total_blocks * 4 + values * sizeof(short);
+            }
             done[f].store(1, std::memory_order_release);
         }
     };
@@ -473,8 +545,8 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     for (int f = 0; f < n; ++f) {        // only what the decoder wrote crosses PCIe: the block table and the records
         while (!done[f].load(std::memory_order_acquire)) std::this_thread::yield();
         if (errs[f] || copy_rc != hipSuccess) continue;
-        copy_rc = hipMemcpyAsync(sl.d_pack + (size_t)f * frame_pack, sl.h_pack + (size_t)f * frame_pack,
-                                 (size_t)hd.total_blocks * 4 + used[f] * sizeof(short), hipMemcpyHostToDevice, s.copy_stream);
+        copy_rc = hipMemcpyAsync(sl.d_pack + (size_t)f * frame_pack, sl.h_pack + (size_t)f * frame_pack, used[f],
+                                 hipMemcpyHostToDevice, s.copy_stream);
     }
     for (auto& th : pool) th.join();
     for (int f = 0; f < n; ++f)
@@ -483,11 +555,34 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     const auto t_entropy = std::chrono::steady_clock::now();
     PF_HIP(h, hipEventRecord(sl.uploaded, s.copy_stream));
     PF_HIP(h, hipStreamWaitEvent(h->stream, sl.uploaded, 0));        // the engine's stream expands them once they are all there
-    {
+    int on_device = 0, max_iv = 0;
+    for (int f = 0; f < n; ++f) { on_device += descs[f].n_intervals ? 1 : 0; max_iv = std::max(max_iv, (int)descs[f].n_intervals); }
+    if (s.desc_cap < (size_t)n) {
+        if (s.d_desc) (void)hipFree(s.d_desc);
+        s.d_desc = nullptr; s.desc_cap = 0;
+        PF_HIP(h, hipMalloc((void**)&s.d_desc, (size_t)n * sizeof(JpegFrameDesc)));
+        s.desc_cap = (size_t)n;
+    }
+    PF_HIP(h, hipMemcpyAsync(s.d_desc, descs.data(), (size_t)n * sizeof(JpegFrameDesc), hipMemcpyHostToDevice, h->stream));
+    if (on_device < n) {
         JpegUnpackArgs ua{};
-        ua.pack = sl.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks;
+        ua.pack = sl.d_pack; ua.frame_pack_bytes = frame_pack; ua.coef = s.d_coef; ua.blocks = hd.total_blocks; ua.desc = s.d_desc;
         ProfScope ps(h, "jpeg_unpack");
         PF_LAUNCH(jpeg_unpack_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ua);
+    }
+    if (on_device) {
+        // frames decoded here start from zeroed blocks (host-decoded frames of the same batch were just written by the unpack kernel)
+        for (int f = 0; f < n; ++f)
+            if (descs[f].n_intervals)
+                PF_HIP(h, hipMemsetAsync(s.d_coef + (size_t)f * hd.total_blocks * 64, 0, (size_t)hd.total_blocks * 64 * sizeof(short), h->stream));
+        JpegHuffArgs ha{};
+        ha.pack = sl.d_pack; ha.frame_pack_bytes = frame_pack; ha.desc = s.d_desc; ha.coef = s.d_coef; ha.blocks = hd.total_blocks;
+        ha.ncomp = hd.ncomp; ha.mcux = hd.mcux; ha.total_mcus = hd.mcux * hd.mcuy;
+        for (int c = 0; c < hd.ncomp; ++c) {
+            ha.ch[c] = hd.c[c].h; ha.cv[c] = hd.c[c].v; ha.cblock0[c] = hd.c[c].block0; ha.cbw[c] = hd.c[c].bw;
+        }
+        ProfScope ps(h, "jpeg_huffman");
+        PF_LAUNCH(jpeg_huffman_kernel, dim3((unsigned)pf_div_up(max_iv, 64), (unsigned)n), dim3(64), h->stream, ha);
     }
     PF_HIP(h, hipEventRecord(sl.consumed, h->stream));
     sl.in_flight = true;
@@ -527,7 +622,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     if (getenv("PEPPA_JPEG_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
         size_t up = 0;
-        for (int f = 0; f < n; ++f) up += (size_t)hd.total_blocks * 4 + used[f] * sizeof(short);
+        for (int f = 0; f < n; ++f) up += used[f];
         fprintf(stderr, "[peppa-hip] jpeg batch of %d: entropy decode %.3f ms on %d thread(s), upload (%.2f MB) + device stages %.3f ms\n", n,
                 std::chrono::duration<double, std::milli>(t_entropy - t_start).count(), T, up / 1e6,
                 std::chrono::duration<double, std::milli>(t_end - t_entropy).count());

@@ -32,7 +32,18 @@ struct JpegState {
     size_t planes_cap = 0;
     unsigned short* d_quant = nullptr;    // [frames][3][64]
     size_t quant_cap = 0;
+    struct JpegFrameDesc* d_desc = nullptr;   // [frames]
+    size_t desc_cap = 0;
     void release();
+};
+
+struct JpegFrameDesc {                    // per file of the batch, in the frame's region of the pack buffer (16-byte aligned fields)
+    unsigned scan_off, scan_len;          // the entropy-coded segment inside the region
+    unsigned offs_off, n_intervals;       // u32 offsets (relative to scan_off) of each interval's first byte
+    unsigned tables_off;
+    unsigned restart;                     // MCUs per interval
+    unsigned tdta;                        // bit c: component c uses DC table 1; bit 4 + c: AC table 1
+    unsigned pad;
 };
 
 struct JpegUnpackArgs {
@@ -40,6 +51,7 @@ struct JpegUnpackArgs {
     size_t frame_pack_bytes;
     short* coef;                  // [frame][blocks][64]
     int blocks;
+    const JpegFrameDesc* desc;   // frames with n_intervals != 0 are decoded by jpeg_huffman_kernel, not expanded here
 };
 
 __device__ __forceinline__ int pf_jpeg_zigzag(int k) {      // zigzag position -> natural (row-major) index
@@ -52,7 +64,7 @@ __device__ __forceinline__ int pf_jpeg_zigzag(int k) {      // zigzag position -
 // packed records -> dense natural-order blocks (zeros where the record ends or no scan reached the block)
 __global__ __launch_bounds__(64) void jpeg_unpack_kernel(JpegUnpackArgs a) {
     const int blk = blockIdx.x * 64 + threadIdx.x;
-    if (blk >= a.blocks) return;
+    if (blk >= a.blocks || a.desc[blockIdx.y].n_intervals != 0) return;
     const unsigned char* region = a.pack + (size_t)blockIdx.y * a.frame_pack_bytes;
     const unsigned start = reinterpret_cast<const unsigned*>(region)[blk];
     short* dst = a.coef + ((size_t)blockIdx.y * a.blocks + blk) * 64;
@@ -65,6 +77,128 @@ __global__ __launch_bounds__(64) void jpeg_unpack_kernel(JpegUnpackArgs a) {
     for (int k = 0; k < len && k < 64; ++k) {
         const short v = rec[1 + k];
         if (v) dst[pf_jpeg_zigzag(k)] = v;
+    }
+}
+
+// ---- entropy decoding on the device, for files that carry restart markers ---------------------------------------------------------
+// A restart interval is an independent, byte-aligned piece of the scan (DC predictions reset, ITU T.81 E.1.4): one thread per
+// interval walks its bit stream exactly as the host decoder does (9-bit lookahead tables, combined code + magnitude lookup for
+// short AC codes, canonical-code search beyond) and writes the coefficients into the dense, pre-zeroed block buffer.  Only the
+// compressed scan, the interval offsets and the tables cross PCIe.
+struct JpegGpuTables {                    // index 0, 1: DC tables 0 / 1; 2, 3: AC tables 0 / 1
+    unsigned short look[4][512];
+    short fast_ac[4][512];                // rows 2, 3 used
+    int maxcode[4][18];
+    int valoff[4][17];
+    unsigned char vals[4][256];
+};
+
+
+struct JpegHuffArgs {
+    const unsigned char* pack;            // [frame] regions of frame_pack_bytes
+    size_t frame_pack_bytes;
+    const JpegFrameDesc* desc;            // [frame]
+    short* coef;                          // [frame][blocks][64], zeroed
+    int blocks;                           // per frame
+    int ncomp, mcux, total_mcus;
+    int ch[3], cv[3], cblock0[3], cbw[3];
+};
+
+struct PfJpegBits {
+    const unsigned char* p;
+    const unsigned char* end;
+    unsigned long long acc;
+    int n;
+};
+
+__device__ __forceinline__ void pf_jpeg_fill(PfJpegBits& br) {
+    while (br.n <= 48) {
+        unsigned b = 0;
+        if (br.p < br.end) {
+            b = *br.p++;
+            if (b == 0xFF && br.p < br.end) ++br.p;       // the stuffed zero (markers cannot occur inside an interval)
+        }
+        br.acc = (br.acc << 8) | b;
+        br.n += 8;
+    }
+}
+__device__ __forceinline__ int pf_jpeg_peek(const PfJpegBits& br, int k) { return (int)((br.acc >> (br.n - k)) & ((1u << k) - 1)); }
+
+__device__ __forceinline__ int pf_jpeg_huff(PfJpegBits& br, const JpegGpuTables* t, int ti) {
+    const int lk = t->look[ti][pf_jpeg_peek(br, 9)];
+    if (lk) { br.n -= lk >> 8; return lk & 0xFF; }
+    int code = pf_jpeg_peek(br, 9), l = 9;
+    br.n -= 9;
+    for (;;) {
+        code = (code << 1) | pf_jpeg_peek(br, 1);
+        br.n -= 1;
+        ++l;
+        if (l > 16) return 0;
+        if (t->maxcode[ti][l] >= 0 && code <= t->maxcode[ti][l]) return t->vals[ti][(code + t->valoff[ti][l]) & 0xFF];
+    }
+}
+
+__device__ __forceinline__ int pf_jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
+
+__global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
+    const unsigned char* region = a.pack + (size_t)blockIdx.y * a.frame_pack_bytes;
+    const JpegFrameDesc d = a.desc[blockIdx.y];
+    const int iv = blockIdx.x * 64 + threadIdx.x;
+    if (iv >= (int)d.n_intervals) return;
+    const unsigned* offs = reinterpret_cast<const unsigned*>(region + d.offs_off);
+    const JpegGpuTables* t = reinterpret_cast<const JpegGpuTables*>(region + d.tables_off);
+    const unsigned char* scan = region + d.scan_off;
+    PfJpegBits br;
+    br.p = scan + offs[iv];
+    br.end = scan + (iv + 1 < (int)d.n_intervals ? offs[iv + 1] - 2 : d.scan_len);     // the RSTn marker is not data
+    br.acc = 0; br.n = 0;
+    short* coef = a.coef + (size_t)blockIdx.y * a.blocks * 64;
+    int pred[3] = {0, 0, 0};
+    const int m0 = iv * (int)d.restart;
+    const int m1 = min(m0 + (int)d.restart, a.total_mcus);
+    for (int m = m0; m < m1; ++m) {
+        const int my = m / a.mcux, mx = m - my * a.mcux;
+        for (int c = 0; c < a.ncomp; ++c) {
+            const int nb = a.ch[c] * a.cv[c];
+            for (int bi = 0; bi < nb; ++bi) {
+                const int v = bi / a.ch[c], hh = bi - v * a.ch[c];
+                short* blk = coef + ((size_t)a.cblock0[c] + (size_t)(my * a.cv[c] + v) * a.cbw[c] + (mx * a.ch[c] + hh)) * 64;
+                pf_jpeg_fill(br);
+                const int s = pf_jpeg_huff(br, t, (d.tdta >> c) & 1);
+                const int sb = s > 15 ? 15 : s;
+                pf_jpeg_fill(br);
+                const int diff = sb ? pf_jpeg_extend(pf_jpeg_peek(br, sb), sb) : 0;
+                br.n -= sb;
+                pred[c] += diff;
+                blk[0] = (short)pred[c];
+                const int ta = 2 + ((d.tdta >> (4 + c)) & 1);
+                for (int k = 1; k < 64;) {
+                    pf_jpeg_fill(br);
+                    const int fa = t->fast_ac[ta][pf_jpeg_peek(br, 9)];
+                    int r, val;
+                    if (fa) {
+                        br.n -= fa & 15;
+                        r = (fa >> 4) & 15;
+                        val = fa >> 8;
+                    } else {
+                        const int rs = pf_jpeg_huff(br, t, ta);
+                        const int sz = rs & 15;
+                        r = rs >> 4;
+                        if (sz == 0) {
+                            if (r != 15) break;
+                            k += 16;
+                            continue;
+                        }
+                        val = pf_jpeg_extend(pf_jpeg_peek(br, sz), sz);
+                        br.n -= sz;
+                    }
+                    k += r;
+                    if (k > 63) break;
+                    blk[pf_jpeg_zigzag(k)] = (short)val;
+                    ++k;
+                }
+            }
+        }
     }
 }
 

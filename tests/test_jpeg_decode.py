@@ -85,6 +85,30 @@ def _check_cases(eng):
         assert np.array_equal(got[0], ref[0]), i
     with pytest.raises(_native.PeppaHipError, match="differs in size"):
         eng.decode_jpeg_batch([files[0], _encode(_image(48, 56, seed=1), quality=80, subsampling=2)])
+    # files with restart markers: the Huffman stream itself is decoded on the device (one thread per restart interval)
+    eng.profile_enable(True)
+    for (h, w), kw in (((67, 101), dict(subsampling=2, restart_marker_blocks=2)), ((64, 96), dict(subsampling=0, restart_marker_rows=1)),
+                       ((35, 53), dict(subsampling=1, restart_marker_blocks=5)), ((50, 70), dict(subsampling=2, restart_marker_blocks=1, optimize=True)),
+                       ((120, 160), dict(subsampling=2, restart_marker_rows=2, quality=35))):
+        img = _image(h, w, seed=h + w)
+        data = _encode(img, **dict(dict(quality=88), **kw))
+        assert b"\xff\xdd" in data
+        _, _, _, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data)), (h, w, kw)
+    grey = _image(40, 72, seed=19)[..., 1]
+    data = _encode(grey, quality=80, restart_marker_blocks=3)
+    assert np.array_equal(eng.decode_jpeg(data)[3], _pil_decode(data))
+    names = list(eng.profile_fetch())
+    assert "jpeg_huffman" in names, names
+    eng.profile_enable(False)
+    # a batch that mixes both kinds: each file takes its own route
+    imgs = [_image(48, 80, seed=60 + i) for i in range(4)]
+    files = [_encode(im, quality=85, subsampling=2, **(dict(restart_marker_rows=1) if i % 2 else {})) for i, im in enumerate(imgs)]
+    refs = [_pil_decode(f) for f in files]
+    d, n, hh, ww = eng.decode_jpeg_batch(files, threads=2)
+    for i, ref in enumerate(refs):
+        got = eng.letterbox(_native.DeviceFrame(d + i * hh * ww * 3, hh, ww), (48, 80))
+        assert np.array_equal(got[0], eng.letterbox(ref, (48, 80))[0]), i
     # refused, not approximated
     with pytest.raises(_native.PeppaHipError, match="progressive"):
         eng.decode_jpeg(_encode(img, quality=85, progressive=True))

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--quality", type=int, default=90)
     ap.add_argument("--n", type=int, default=50)
     ap.add_argument("--content", default="photo", choices=["photo", "noise"])
+    ap.add_argument("--restart-rows", type=int, default=0,
+                    help="write a restart marker every N MCU rows: such files have their Huffman stream decoded on the device")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     if args.content == "noise":      # worst case for the entropy stage: every block carries ~35 non-zero coefficients
@@ -32,7 +34,8 @@ def main():
         frame = np.asarray(Image.fromarray(low).resize((1920, 1080), Image.BICUBIC)).astype(np.int16)
         frame = np.clip(frame + rng.integers(-2, 3, frame.shape), 0, 255).astype(np.uint8)
     buf = io.BytesIO()
-    Image.fromarray(frame[..., ::-1]).save(buf, format="JPEG", quality=args.quality, subsampling=2)
+    kw = dict(restart_marker_rows=args.restart_rows) if args.restart_rows else {}
+    Image.fromarray(frame[..., ::-1]).save(buf, format="JPEG", quality=args.quality, subsampling=2, **kw)
     data = buf.getvalue()
     eng = _native.Engine(0)
     ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[..., ::-1]
@@ -65,7 +68,8 @@ def main():
             eng.decode_jpeg_batch(files, threads=T)
         dt = (time.perf_counter() - t0) / reps
         batch[str(T)] = {"ms_per_96_frames": round(dt * 1e3, 2), "frames_per_s": round(96 / dt, 1)}
-    print(json.dumps({"jpeg_bytes": len(data), "quality": args.quality, "frame": "1920x1080 4:2:0", "content": args.content, "batch_by_host_threads": batch,
+    print(json.dumps({"jpeg_bytes": len(data), "quality": args.quality, "frame": "1920x1080 4:2:0", "content": args.content, "restart_marker_rows": args.restart_rows,
+                      "entropy_decoding": "device (one thread per restart interval)" if args.restart_rows else "host threads", "batch_by_host_threads": batch,
                       "host_cores": os.cpu_count(),
                       "pf_decode_jpeg_ms": round(t_dev * 1e3, 3), "frames_per_s_one_stream": round(1.0 / t_dev, 1),
                       "libjpeg_host_decode_ms": round(t_pil * 1e3, 3), "host_frame_upload_and_gate_ms": round(t_up * 1e3, 3),
