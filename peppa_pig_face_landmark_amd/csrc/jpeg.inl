@@ -514,7 +514,15 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     std::vector<const char*> errs((size_t)n, nullptr);
     std::vector<size_t> used((size_t)n, 0);          // bytes of each frame's region that cross PCIe
     std::vector<JpegFrameDesc> descs((size_t)n);
-    const bool device_entropy = getenv("PEPPA_JPEG_HOST_ENTROPY") == nullptr;   // A/B switch: force the host Huffman loop
+    // Where the Huffman stream is decoded.  A restart interval is one GPU thread, and a GPU thread is slow (a 120-MCU interval of a
+    // 1080p file takes ~7 ms): the device wins when the batch offers thousands of intervals (96 files x 68: 11.8 k files/s against
+    // 3.6-5.2 k on 16-96 host threads), a single file is faster on one host core (4 ms).  PEPPA_JPEG_ENTROPY=host|device overrides.
+    bool device_entropy = false;
+    if (hd.restart > 0) {
+        const long long intervals = (long long)n * ((hd.mcux * hd.mcuy + hd.restart - 1) / hd.restart);
+        device_entropy = intervals >= 4096;
+    }
+    if (const char* e = getenv("PEPPA_JPEG_ENTROPY")) device_entropy = e[0] == 'd';
     std::vector<std::atomic<int>> done((size_t)n);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     // workers are pure CPU (a HIP call from a fresh thread pays the runtime's per-thread set-up under its global lock: 60 ms

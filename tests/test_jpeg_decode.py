@@ -85,7 +85,9 @@ def _check_cases(eng):
         assert np.array_equal(got[0], ref[0]), i
     with pytest.raises(_native.PeppaHipError, match="differs in size"):
         eng.decode_jpeg_batch([files[0], _encode(_image(48, 56, seed=1), quality=80, subsampling=2)])
-    # files with restart markers: the Huffman stream itself is decoded on the device (one thread per restart interval)
+    # files with restart markers: the Huffman stream itself can be decoded on the device (one thread per restart interval; chosen
+    # automatically for big batches, forced here)
+    os.environ["PEPPA_JPEG_ENTROPY"] = "device"
     eng.profile_enable(True)
     for (h, w), kw in (((67, 101), dict(subsampling=2, restart_marker_blocks=2)), ((64, 96), dict(subsampling=0, restart_marker_rows=1)),
                        ((35, 53), dict(subsampling=1, restart_marker_blocks=5)), ((50, 70), dict(subsampling=2, restart_marker_blocks=1, optimize=True)),
@@ -109,6 +111,7 @@ def _check_cases(eng):
     for i, ref in enumerate(refs):
         got = eng.letterbox(_native.DeviceFrame(d + i * hh * ww * 3, hh, ww), (48, 80))
         assert np.array_equal(got[0], eng.letterbox(ref, (48, 80))[0]), i
+    os.environ.pop("PEPPA_JPEG_ENTROPY", None)
     # refused, not approximated
     with pytest.raises(_native.PeppaHipError, match="progressive"):
         eng.decode_jpeg(_encode(img, quality=85, progressive=True))

@@ -69,7 +69,7 @@ def main():
         dt = (time.perf_counter() - t0) / reps
         batch[str(T)] = {"ms_per_96_frames": round(dt * 1e3, 2), "frames_per_s": round(96 / dt, 1)}
     print(json.dumps({"jpeg_bytes": len(data), "quality": args.quality, "frame": "1920x1080 4:2:0", "content": args.content, "restart_marker_rows": args.restart_rows,
-                      "entropy_decoding": "device (one thread per restart interval)" if args.restart_rows else "host threads", "batch_by_host_threads": batch,
+                      "entropy_decoding": "device (one thread per restart interval) for the batches, host for the single file" if args.restart_rows else "host threads", "batch_by_host_threads": batch,
                       "host_cores": os.cpu_count(),
                       "pf_decode_jpeg_ms": round(t_dev * 1e3, 3), "frames_per_s_one_stream": round(1.0 / t_dev, 1),
                       "libjpeg_host_decode_ms": round(t_pil * 1e3, 3), "host_frame_upload_and_gate_ms": round(t_up * 1e3, 3),
