@@ -483,11 +483,11 @@ def main():
                 raise ImportError("PIL not installed: no way to write the JPEG test files")
             thr = max(1, min(32, (os.cpu_count() or 8) // max(1, lanes)))
             jpeg = {"note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
-                            "feeds pf_run_frames, one host thread per lane drives decode + pipeline; output bit-identical with libjpeg. "
-                            "'restart_markers': files with a restart marker per MCU row -- the Huffman stream is decoded on the device, one thread "
-                            "per restart interval; 'no_restart_markers': the Huffman stream is decoded on host threads",
+                            "feeds pf_run_frames, one host thread per lane drives decode + pipeline; output bit-identical with libjpeg.  The "
+                            "files carry no restart markers, so their Huffman streams are decoded on host threads (files WITH restart markers "
+                            "in batches of >= 4096 intervals are entropy-decoded on the device: tools/bench_jpeg.py --restart-rows 1)",
                     "host_threads_per_lane": thr}
-            for key, rows in (("restart_markers", 1), ("no_restart_markers", 0)):
+            for key, rows in (("no_restart_markers", 0),):
                 total_bytes = state.enable_jpeg_frames(90, rows)
                 for _ in range(2):      # the decoder alternates two frame buffers: both get their captured graph before the clock starts
                     state.step_jpeg(thr)

@@ -161,7 +161,9 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
                    uint8_t* bgr_host);
 /* n files of one size and sampling -> [n][height][width][3] in device memory (*d_frames, same ownership), ready for
  * pf_run_frames(mem = PF_MEM_DEVICE): the files' Huffman streams are decoded on `threads` host threads (one file per task), the
- * device stages run once over the whole batch.  Asynchronous like pf_run_frames: the frames are valid in the order of the
+ * device stages run once over the whole batch.  Files that carry restart markers (one interleaved scan, table ids 0 / 1) in batches
+ * of >= 4096 restart intervals skip the host Huffman loop: one device thread per interval decodes the stream, and only the
+ * compressed scan crosses PCIe (PEPPA_JPEG_ENTROPY=host|device overrides the choice).  Asynchronous like pf_run_frames: the frames are valid in the order of the
  * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets
  * alternate, so the pointer of call k stays valid until call k + 2 and the host work of call k + 1 overlaps the pipeline still
  * running on the frames of call k. */
