@@ -378,29 +378,36 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
     const size_t begin = sos + 2 + len;
     const int total_mcus = hd.mcux * hd.mcuy;
     const int want = (total_mcus + hd.restart - 1) / hd.restart;
+    if (n - begin + 64 + (size_t)want * 4 + sizeof(JpegGpuTables) + 64 > region_cap) return false;
+    // The scan is copied WITHOUT its byte stuffing and without the RSTn markers (offsets in the copied stream): the device threads
+    // then refill their bit buffers four bytes at a time, branch-free -- with stuffing in place the 64 lanes of a wave each looped
+    // over single bytes and the wave paid the longest loop on every symbol.
     std::vector<unsigned> offs;
     offs.reserve((size_t)want);
     offs.push_back(0);
-    size_t q = begin, end = n;
+    size_t q = begin, out = 0;
+    bool ended = false;
     while (q < n) {
         const unsigned char* ff = static_cast<const unsigned char*>(memchr(d + q, 0xFF, n - q));
-        if (!ff) break;
-        q = (size_t)(ff - d);
-        if (q + 1 >= n) break;
+        const size_t run = ff ? (size_t)(ff - (d + q)) : n - q;
+        memcpy(region + out, d + q, run);
+        out += run; q += run;
+        if (!ff || q + 1 >= n) break;
         const int m = d[q + 1];
-        if (m == 0x00) { q += 2; continue; }
+        if (m == 0x00) { region[out++] = 0xFF; q += 2; continue; }
         if (m == 0xFF) { q += 1; continue; }
-        if (m >= 0xD0 && m <= 0xD7) { offs.push_back((unsigned)(q + 2 - begin)); q += 2; continue; }
-        end = q;                                   // any other marker ends the scan
+        if (m >= 0xD0 && m <= 0xD7) { offs.push_back((unsigned)out); q += 2; continue; }
         if (m != 0xD9) return false;               // more scans / tables follow: not the single-scan case
+        ended = true;
         break;
     }
+    (void)ended;
     if ((int)offs.size() != want) return false;
-    const size_t scan_len = end - begin;
-    const size_t offs_off = (scan_len + 15) / 16 * 16;
+    const size_t scan_len = out;
+    memset(region + out, 0, 32);                   // the bit readers run a few bytes past the end of the last interval
+    const size_t offs_off = (scan_len + 32 + 15) / 16 * 16;
     const size_t tables_off = (offs_off + offs.size() * 4 + 15) / 16 * 16;
     if (tables_off + sizeof(JpegGpuTables) > region_cap) return false;
-    memcpy(region, d + begin, scan_len);
     memcpy(region + offs_off, offs.data(), offs.size() * 4);
     JpegGpuTables* t = reinterpret_cast<JpegGpuTables*>(region + tables_off);
     for (int i = 0; i < 4; ++i) {
@@ -579,10 +586,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         PF_LAUNCH(jpeg_unpack_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ua);
     }
     if (on_device) {
-        // frames decoded here start from zeroed blocks (host-decoded frames of the same batch were just written by the unpack kernel)
-        for (int f = 0; f < n; ++f)
-            if (descs[f].n_intervals)
-                PF_HIP(h, hipMemsetAsync(s.d_coef + (size_t)f * hd.total_blocks * 64, 0, (size_t)hd.total_blocks * 64 * sizeof(short), h->stream));
+        // (every block of such a frame is written whole by the kernel: an interleaved scan covers the MCU-padded planes)
         JpegHuffArgs ha{};
         ha.pack = sl.d_pack; ha.frame_pack_bytes = frame_pack; ha.desc = s.d_desc; ha.coef = s.d_coef; ha.blocks = hd.total_blocks;
         ha.ncomp = hd.ncomp; ha.mcux = hd.mcux; ha.total_mcus = hd.mcux * hd.mcuy;

@@ -105,36 +105,29 @@ struct JpegHuffArgs {
 };
 
 struct PfJpegBits {
-    const unsigned char* base;            // 8-byte aligned start of the frame's region
-    unsigned pos, end;                    // byte offsets from base
+    const unsigned char* base;            // 8-byte aligned start of the frame's region (the scan in it has no byte stuffing)
+    unsigned pos;                         // byte offset from base
     unsigned long long chunk, ahead;      // the aligned 8 bytes that contain pos, and the 8 after them, requested one chunk early
-    unsigned chunk_at;                    //   (a dependent global load per BYTE would cost a full L2 round trip each)
+    unsigned chunk_at;                    //   (a dependent global load per refill would cost a full L2 round trip each)
     unsigned long long acc;
     int n;
 };
 
-__device__ __forceinline__ unsigned pf_jpeg_byte(PfJpegBits& br) {
+// Branch-light refill: four bytes at a time out of the (chunk, ahead) window.  (With the stuffed stream each lane looped over
+// single bytes and the wave paid the longest loop on every symbol: ~0.8 us per symbol.)
+__device__ __forceinline__ void pf_jpeg_fill(PfJpegBits& br) {
+    if (br.n > 32) return;
     const unsigned at = br.pos & ~7u;
     if (at != br.chunk_at) {
         br.chunk = at == br.chunk_at + 8 ? br.ahead : *reinterpret_cast<const unsigned long long*>(br.base + at);
         br.ahead = *reinterpret_cast<const unsigned long long*>(br.base + at + 8);     // in flight while this chunk is consumed
         br.chunk_at = at;
     }
-    const unsigned b = (unsigned)(br.chunk >> (8 * (br.pos & 7u))) & 0xFFu;
-    ++br.pos;
-    return b;
-}
-
-__device__ __forceinline__ void pf_jpeg_fill(PfJpegBits& br) {
-    while (br.n <= 48) {
-        unsigned b = 0;
-        if (br.pos < br.end) {
-            b = pf_jpeg_byte(br);
-            if (b == 0xFF && br.pos < br.end) ++br.pos;   // the stuffed zero (markers cannot occur inside an interval)
-        }
-        br.acc = (br.acc << 8) | b;
-        br.n += 8;
-    }
+    const unsigned sh = 8u * (br.pos & 7u);
+    const unsigned long long w = sh ? (br.chunk >> sh) | (br.ahead << (64u - sh)) : br.chunk;
+    br.acc = (br.acc << 32) | __builtin_bswap32((unsigned)w);             // bytes pos .. pos + 3, stream order
+    br.n += 32;
+    br.pos += 4;
 }
 __device__ __forceinline__ int pf_jpeg_peek(const PfJpegBits& br, int k) { return (int)((br.acc >> (br.n - k)) & ((1u << k) - 1)); }
 
@@ -163,6 +156,12 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
     // memory each would be an L2 round trip per symbol (8.5 -> 6.8 ms for the 120-MCU intervals of a 1080p file)
     __shared__ JpegGpuTables tables;
     __shared__ unsigned char zz[64];
+    // the block being decoded lives in LDS and leaves as eight 16-byte stores when it is complete: on this ISA stores share the
+    // loads' counter, so every wait for the next stream chunk is also a wait for ALL outstanding stores -- one 2-byte global store
+    // per coefficient made that a full store round trip every few symbols
+    constexpr int BLK_STRIDE = 72;                        // shorts per thread: 144 bytes, 16-byte aligned, rows on staggered banks
+    __shared__ __attribute__((aligned(16))) short blkbuf[64 * BLK_STRIDE];
+    short* mine = blkbuf + threadIdx.x * BLK_STRIDE;
     zz[threadIdx.x] = (unsigned char)pf_jpeg_zigzag(threadIdx.x);
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(region + d.tables_off);
@@ -175,7 +174,6 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
     PfJpegBits br;
     br.base = region;
     br.pos = d.scan_off + offs[iv];
-    br.end = d.scan_off + (iv + 1 < (int)d.n_intervals ? offs[iv + 1] - 2 : d.scan_len);     // the RSTn marker is not data
     br.chunk = 0; br.ahead = 0; br.chunk_at = 0xFFFFFFF0u;
     br.acc = 0; br.n = 0;
     short* coef = a.coef + (size_t)blockIdx.y * a.blocks * 64;
@@ -189,6 +187,8 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
             for (int bi = 0; bi < nb; ++bi) {
                 const int v = bi / a.ch[c], hh = bi - v * a.ch[c];
                 short* blk = coef + ((size_t)a.cblock0[c] + (size_t)(my * a.cv[c] + v) * a.cbw[c] + (mx * a.ch[c] + hh)) * 64;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reinterpret_cast<pf_f32x4*>(mine)[i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
                 pf_jpeg_fill(br);
                 const int s = pf_jpeg_huff(br, t, (d.tdta >> c) & 1);
                 const int sb = s > 15 ? 15 : s;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
                 const int diff = sb ? pf_jpeg_extend(pf_jpeg_peek(br, sb), sb) : 0;
                 br.n -= sb;
                 pred[c] += diff;
-                blk[0] = (short)pred[c];
+                mine[0] = (short)pred[c];
                 const int ta = 2 + ((d.tdta >> (4 + c)) & 1);
                 for (int k = 1; k < 64;) {
                     pf_jpeg_fill(br);
@@ -220,9 +220,11 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
                     }
                     k += r;
                     if (k > 63) break;
-                    blk[zz[k]] = (short)val;
+                    mine[zz[k]] = (short)val;
                     ++k;
                 }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reinterpret_cast<pf_f32x4*>(blk)[i] = reinterpret_cast<const pf_f32x4*>(mine)[i];
             }
         }
     }
