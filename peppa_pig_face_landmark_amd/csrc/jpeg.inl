@@ -386,7 +386,6 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
     offs.reserve((size_t)want);
     offs.push_back(0);
     size_t q = begin, out = 0;
-    bool ended = false;
     while (q < n) {
         const unsigned char* ff = static_cast<const unsigned char*>(memchr(d + q, 0xFF, n - q));
         const size_t run = ff ? (size_t)(ff - (d + q)) : n - q;
@@ -398,10 +397,8 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
         if (m == 0xFF) { q += 1; continue; }
         if (m >= 0xD0 && m <= 0xD7) { offs.push_back((unsigned)out); q += 2; continue; }
         if (m != 0xD9) return false;               // more scans / tables follow: not the single-scan case
-        ended = true;
         break;
     }
-    (void)ended;
     if ((int)offs.size() != want) return false;
     const size_t scan_len = out;
     memset(region + out, 0, 32);                   // the bit readers run a few bytes past the end of the last interval
