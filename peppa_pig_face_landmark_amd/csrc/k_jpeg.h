@@ -106,7 +106,7 @@ struct JpegHuffArgs {
 
 struct PfJpegBits {
     const unsigned char* base;            // 8-byte aligned start of the frame's region (the scan in it has no byte stuffing)
-    unsigned pos;                         // byte offset from base
+    unsigned pos, limit;                  // byte offset from base; the stream ends at limit (a corrupt stream must not walk off)
     unsigned long long chunk, ahead;      // the aligned 8 bytes that contain pos, and the 8 after them, requested one chunk early
     unsigned chunk_at;                    //   (a dependent global load per refill would cost a full L2 round trip each)
     unsigned long long acc;
@@ -117,6 +117,7 @@ struct PfJpegBits {
 // single bytes and the wave paid the longest loop on every symbol: ~0.8 us per symbol.)
 __device__ __forceinline__ void pf_jpeg_fill(PfJpegBits& br) {
     if (br.n > 32) return;
+    if (br.pos >= br.limit) { br.acc <<= 32; br.n += 32; return; }       // past the end: zeros, like the host decoder
     const unsigned at = br.pos & ~7u;
     if (at != br.chunk_at) {
         br.chunk = at == br.chunk_at + 8 ? br.ahead : *reinterpret_cast<const unsigned long long*>(br.base + at);
@@ -174,6 +175,7 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
     PfJpegBits br;
     br.base = region;
     br.pos = d.scan_off + offs[iv];
+    br.limit = d.scan_off + d.scan_len + 8;              // (staged with 32 zero bytes behind the scan)
     br.chunk = 0; br.ahead = 0; br.chunk_at = 0xFFFFFFF0u;
     br.acc = 0; br.n = 0;
     short* coef = a.coef + (size_t)blockIdx.y * a.blocks * 64;

@@ -193,3 +193,48 @@ def test_faceana_runs_on_decoded_device_frame_emulator(emu_library, student_weig
 @pytest.mark.gpu
 def test_faceana_runs_on_decoded_device_frame_gpu(hip_library, student_weights, detector_weights):
     _facade_case(hip_library, student_weights, detector_weights)
+
+
+def _malformed(library, trials):
+    rng = np.random.default_rng(2024)
+    base = [_encode(_image(40, 56, seed=70), quality=85, subsampling=2),
+            _encode(_image(33, 47, seed=71), quality=60, subsampling=0, optimize=True),
+            _encode(_image(48, 64, seed=72), quality=85, subsampling=2, restart_marker_blocks=2),
+            _encode(_image(24, 40, seed=73)[..., 0], quality=80)]
+    eng = _native.Engine(0, library)
+    outcomes = {"ok": 0, "error": 0}
+    try:
+        for trial in range(trials):
+            data = bytearray(base[trial % len(base)])
+            kind = trial % 3
+            if kind == 0:                              # truncation
+                data = data[:int(rng.integers(2, len(data)))]
+            elif kind == 1:                            # a few flipped bytes anywhere (headers, tables, scan, markers)
+                for _ in range(int(rng.integers(1, 6))):
+                    data[int(rng.integers(2, len(data)))] = int(rng.integers(0, 256))
+            else:                                      # corrupted segment lengths / marker codes in the header region
+                i = int(rng.integers(2, min(len(data), 600)))
+                data[i] = int(rng.integers(0, 256))
+                data = data[:int(rng.integers(len(data) // 2, len(data) + 1))]
+            os.environ["PEPPA_JPEG_ENTROPY"] = "device" if trial % 2 else "host"
+            try:
+                _, h, w, got = eng.decode_jpeg(bytes(data))
+                assert got.shape == (h, w, 3)
+                outcomes["ok"] += 1
+            except _native.PeppaHipError:
+                outcomes["error"] += 1
+    finally:
+        os.environ.pop("PEPPA_JPEG_ENTROPY", None)
+        eng.close()
+    assert outcomes["ok"] > trials // 12 and outcomes["error"] > trials // 12, outcomes
+
+
+def test_malformed_files_fail_cleanly_emulator(emu_library):
+    """Ingest reads untrusted bytes: truncated, bit-flipped and length-corrupted files must end in a decoded frame or a
+    PeppaHipError -- never in a crash or a hang (host parser / Huffman decoder bounds; both entropy routes)."""
+    _malformed(emu_library, 240)
+
+
+@pytest.mark.gpu
+def test_malformed_files_fail_cleanly_gpu(hip_library):
+    _malformed(hip_library, 120)
