@@ -218,8 +218,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(h->dbg & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
-            if (a.Npad == 128 && (h->dbg & 4096)) PF_LAUNCH(conv3x3_halo3_split_kernel, grid, dim3(512), h->stream, a);
-            else if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
+            if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
             else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 80) PF_LAUNCH((conv3x3_halo_split_kernel<80, 8, 1>), grid, dim3(512), h->stream, a);

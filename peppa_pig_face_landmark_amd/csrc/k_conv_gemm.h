@@ -1180,171 +1180,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }
 
-// ---- the 128-output halo conv with a THREE-stage weight ring (experiment, PEPPA_DBG bit 4096) --------------------------------
-// Same tiling as conv3x3_halo_split_kernel<128, 4, 2> (128 pixels = whole rows, 4 x 2 waves, patch of the current 32-channel
-// chunk resident as hi / lo planes).  Differences: the planes hold only real columns (the zero ring columns are gone: the two
-// border taps mask their fragments instead), which frees exactly the LDS a third 16 KB weight stage needs at two workgroups per
-// CU (2 x 16 KB + 3 x 16 KB = 81 920 B); weights are requested TWO taps ahead by asm-issued LDS-DMA and retired by a partial
-// vmcnt wait, so a tap never waits for a request issued one short MFMA phase earlier.
-__global__ __launch_bounds__(512, 4) void conv3x3_halo3_split_kernel(ConvGemmArgs a) {
-    constexpr int BM = 128, BN = 128, WARPS_M = 4, WARPS_N = 2;
-    constexpr int NTHR = 512;
-    constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
-    constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int MAXHP = 256;                           // (2 + 2) x 64 at W = 64, 6 x 32 at 32, 10 x 16 at 16
-    constexpr int XU = (MAXHP * 4 + NTHR - 1) / NTHR;
-    constexpr int PLANE_X = MAXHP * 64;
-    constexpr int WCHUNKS = BN * 8 / NTHR;               // LDS-DMA requests per thread and stage
-    constexpr int W_BYTES = BN * 128;
-    constexpr int NSTG = 3;
-    static_assert(2 * PLANE_X + NSTG * W_BYTES == 81920 && MT == 2, "LDS budget of two workgroups per CU");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + NSTG * W_BYTES];
-    unsigned char* xh = smem;
-    unsigned char* xl = smem + PLANE_X;
-    unsigned char* wbase = smem + 2 * PLANE_X;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave % WARPS_M, wn = wave / WARPS_M;
-    int mtile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-aware tile order
-    const int m0 = mtile * BM;
-    const int n0 = blockIdx.y * BN;
-    const int W = a.outW, H = a.outH, OHW = H * W;
-    const int M = a.B * OHW;
-    const int TR = BM / W;
-    const int HP = (TR + 2) * W;
-    const int face = m0 / OHW;
-    const int y0 = (m0 - face * OHW) / W;
-    const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)face * OHW * a.inLd;
-    const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
-    const int cblocks = a.Cpad / 32;
-    const size_t wrow_bytes = (size_t)9 * cblocks * 128;
-
-    int xoff[XU], xhp[XU];
-    const int xc = t & 3;
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-        const int hp = (t >> 2) + (NTHR / 4) * u;
-        xhp[u] = hp < HP ? hp : -1;
-        const int hy = hp / W, hx = hp - hy * W;
-        const int iy = y0 - 1 + hy;
-        const bool ok = hp < HP && m0 < M && (unsigned)iy < (unsigned)H;
-        xoff[u] = ok ? (iy * W + hx) * a.inLd + xc * 8 : -1;
-    }
-    pf_f32x4 xreg[XU][2];
-    auto load_x = [&](int cb) {
-#pragma unroll
-        for (int u = 0; u < XU; ++u)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                if (xoff[u] >= 0 && cb * 32 + xc * 8 + 4 * h < a.inC) v = *reinterpret_cast<const pf_f32x4*>(in + xoff[u] + cb * 32 + 4 * h);
-                xreg[u][h] = v;
-            }
-    };
-    auto store_x = [&]() {
-#pragma unroll
-        for (int u = 0; u < XU; ++u) {
-            if (xhp[u] < 0) continue;
-            pf_half8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = xreg[u][e >> 2][e & 3];
-                const pf_half hv = (pf_half)v;
-                hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
-            }
-            const int off = pf_lds_chunk_off(xhp[u], xc);
-            *reinterpret_cast<pf_half8*>(xh + off) = hi;
-            *reinterpret_cast<pf_half8*>(xl + off) = lo;
-        }
-    };
-    const int nk = 9 * cblocks;
-    auto dma_w = [&](int kt) {                            // K step kt = cb * 9 + tap -> ring slot kt % 3
-        if (kt >= nk) return;
-        const int cb = kt / 9, tap = kt - cb * 9;
-        unsigned char* wdst = wbase + (kt % NSTG) * W_BYTES;
-#pragma unroll
-        for (int c = 0; c < WCHUNKS; ++c) {
-            const int sl = t + NTHR * c;
-            const int plane = sl >= BN * 4 ? 1 : 0;
-            const int row = (sl - plane * BN * 4) >> 2;
-            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-            const int n = min(n0 + row, a.Npad - 1);
-            pf_glds16_raw(wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
-        }
-    };
-
-    pf_f32x4 acc[NT][MT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fchunk = lane >> 4;
-    int hp0[MT];
-    bool edge_l[MT], edge_r[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int p = wm * WM + i * 16 + frow;
-        const int ty = p / W, tx = p - ty * W;
-        hp0[i] = ty * W + tx;
-        edge_l[i] = tx == 0;
-        edge_r[i] = tx == W - 1;
-    }
-
-    load_x(0);
-    store_x();                                            // (the compiler drains the patch loads here, before any DMA is in flight)
-    dma_w(0);
-    dma_w(1);
-    int tap = 0, cb = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed (everything but the younger stage's requests is complete); everybody has left step kt - 1, so its
-        // ring slot is free, and a freshly stored patch is visible
-        if (kt + 1 < nk) pf_wait_vm_barrier<WCHUNKS>(); else pf_wait_vm_barrier<0>();
-        dma_w(kt + 2);
-        const bool last_tap = tap == 8;
-        if (tap == 0 && cb + 1 < cblocks) load_x(cb + 1);
-        const unsigned char* wh = wbase + (kt % NSTG) * W_BYTES;
-        const unsigned char* wl = wh + BN * 64;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int shift = ky * W + kx - 1;
-        {
-            pf_half8 xhf[MT], xlf[MT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int hp = min(max(hp0[i] + shift, 0), HP - 1);
-                const int off = pf_lds_chunk_off(hp, fchunk);
-                xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
-                xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
-                if ((kx == 0 && edge_l[i]) || (kx == 2 && edge_r[i])) {          // the column outside the image
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { xhf[i][e] = (pf_half)0.f; xlf[i][e] = (pf_half)0.f; }
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-                const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wh + off);
-                const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wl + off);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
-#pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
-            }
-        }
-        if (last_tap && kt + 1 < nk) {
-            pf_wait_vm_barrier<63>();            // every wave is done with this chunk's patch (weights stay in flight)
-            store_x();
-        }
-        if (last_tap) { tap = 0; ++cb; } else ++tap;
-    }
-    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
-}
-
 // ---- fused DecoderBlock front end with the low-res patch and its filters resident in LDS ------------------------
 // Same operator as conv_gemm_split_kernel<..., STAGE = 1> (bilinear x2 upsample + concat + depthwise 3x3 + BN as
 // the producer of a pointwise split-precision GEMM).  There every (pixel, 8-channel) unit issues 36 16-byte
