@@ -31,7 +31,9 @@ struct JpegHuff {
             valoff[l] = k - code;
             if (bits[l]) {
                 for (int i = 0; i < bits[l]; ++i, ++k, ++code) {
-                    if (k >= 256) return false;
+                    // an over-subscribed table (more codes of length l than 2^l code points are left) must be refused BEFORE
+                    // its codes index the lookahead table: code << (9 - l) would run past look[] into the neighbouring members
+                    if (k >= 256 || code >= (1 << l)) return false;
                     if (l <= 9) {
                         const int lo = code << (9 - l), n = 1 << (9 - l);
                         for (int j = 0; j < n; ++j) look[lo + j] = (unsigned short)((l << 8) | vals[k]);

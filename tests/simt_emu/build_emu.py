@@ -21,18 +21,22 @@ def available() -> bool:
     return os.path.exists(CLANG)
 
 
-def build_emu(force: bool = False) -> str:
+def build_emu(force: bool = False, flavour: str = "") -> str:
+    """``flavour="asan"``: the same sources under AddressSanitizer (tests/test_jpeg_decode.py runs the host-side JPEG parser of
+    that build on hostile files in a subprocess with the sanitizer runtime preloaded)."""
     os.makedirs(OUT_DIR, exist_ok=True)
+    out = OUT if not flavour else os.path.join(OUT_DIR, "libpeppa_emu_%s.so" % flavour)
+    extra = {"": [], "asan": ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan", "-O1"]}[flavour]
     srcs = [os.path.join(CSRC, "engine.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
         os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "include", "pf_intrinsics.h"),
         os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "peppa_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps):
-        return OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
     cmd = [CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-pthread",
-           "-I", os.path.join(HERE, "include"), "-I", CSRC] + os.environ.get("PEPPA_EMU_CFLAGS", "").split() + srcs + ["-o", OUT]
+           "-I", os.path.join(HERE, "include"), "-I", CSRC] + os.environ.get("PEPPA_EMU_CFLAGS", "").split() + extra + srcs + ["-o", out]
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

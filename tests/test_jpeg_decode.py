@@ -238,3 +238,74 @@ def test_malformed_files_fail_cleanly_emulator(emu_library):
 @pytest.mark.gpu
 def test_malformed_files_fail_cleanly_gpu(hip_library):
     _malformed(hip_library, 120)
+
+
+# ---- over-subscribed Huffman tables (DHT) ----------------------------------------------------------------------------------
+def _dht_file(counts, tc_th=0x00):
+    """SOI + one DHT segment whose 16 code-length counts are `counts` (+ that many symbol bytes) + EOI."""
+    nsym = min(sum(counts), 256)
+    body = bytes([tc_th]) + bytes(counts) + bytes(i & 0xFF for i in range(nsym))
+    return b"\xff\xd8" + b"\xff\xc4" + (len(body) + 2).to_bytes(2, "big") + body + b"\xff\xd9"
+
+
+def _oversubscribed_dhts():
+    files = []
+    one = [0] * 16
+    one[0] = 255                                   # 255 codes of length 1 (two exist): the advisor's 130 KB overrun
+    files.append(_dht_file(one))
+    for l in range(1, 10):                         # lengths 1..9 index the 9-bit lookahead table
+        for extra in (1, 3):
+            c = [0] * 16
+            c[l - 1] = min((1 << l) + extra, 255)
+            files.append(_dht_file(c))
+            files.append(_dht_file(c, tc_th=0x10))  # the same counts as an AC table
+    c = [0] * 16
+    c[0], c[1] = 2, 1                              # length 1 full, then one more code of length 2
+    files.append(_dht_file(c))
+    return files
+
+
+def test_oversubscribed_huffman_tables_are_refused_emulator(emu_library):
+    """A DHT whose counts exceed the code space of a length used to index look[] past its end before the check ran
+    (round-2 advisor finding, jpeg.inl JpegHuff::build): every such table must be refused, through every entry point that
+    parses headers."""
+    eng = _native.Engine(0, emu_library)
+    try:
+        for data in _oversubscribed_dhts():
+            with pytest.raises(_native.PeppaHipError):
+                eng.jpeg_info(data)
+            with pytest.raises(_native.PeppaHipError):
+                eng.decode_jpeg(data)
+    finally:
+        eng.close()
+
+
+def test_oversubscribed_huffman_tables_under_asan(tmp_path):
+    """The same files through an AddressSanitizer build of the emulator flavour, in a subprocess (the sanitizer runtime has to be
+    preloaded): a write past look[] aborts the child with an ASan report instead of silently landing in fast_ac / the heap."""
+    import subprocess
+    import sys
+    from tests.simt_emu import build_emu
+    rt = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+    if not (build_emu.available() and os.path.exists(rt)):
+        pytest.skip("no host clang / ASan runtime")
+    lib = build_emu.build_emu(flavour="asan")
+    blob = tmp_path / "dhts.bin"
+    files = _oversubscribed_dhts()
+    with open(blob, "wb") as f:
+        for d in files:
+            f.write(len(d).to_bytes(4, "little") + d)
+    child = (
+        "import ctypes as C, sys\n"
+        "lib = C.CDLL(sys.argv[1])\n"
+        "lib.pf_jpeg_info.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 4\n"
+        "raw = open(sys.argv[2], 'rb').read(); i = 0; n = 0\n"
+        "while i < len(raw):\n"
+        "    ln = int.from_bytes(raw[i:i + 4], 'little'); d = raw[i + 4:i + 4 + ln]; i += 4 + ln\n"
+        "    buf = (C.c_ubyte * ln).from_buffer_copy(d); v = [C.c_int() for _ in range(4)]\n"
+        "    assert lib.pf_jpeg_info(buf, ln, *[C.byref(x) for x in v]) != 0\n"
+        "    n += 1\n"
+        "print('refused', n)\n")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:verify_asan_link_order=0")
+    r = subprocess.run([sys.executable, "-c", child, lib, str(blob)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and ("refused %d" % len(files)) in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
