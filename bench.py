@@ -38,6 +38,7 @@ GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstre
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
+PMC_SQ_PROFILE = "r02_run5_pmc_sq_hero_and_expdw.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel
 HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
 # algorithmic FLOPs per face of the other dense kernels of the Student (MACs x 2, model.py line ranges in DESIGN.md 5)
@@ -52,6 +53,41 @@ DENSE_FLOP_PER_FACE = {
     "expdw3x3d1_c112_n672_16x16": 2.0 * 256 * 672 * (112 + 9),
     "conv3x3_c160_n64_16x16": 2.0 * 256 * 160 * 64 * 9,
 }
+
+
+def tag_flops_per_face(tag: str):
+    """Algorithmic FLOPs (MACs x 2) per face of ONE launch of the dense kernel behind a profile tag, from the shapes the
+    engine writes into the tag (csrc/engine.cpp ProfScope names); None for tags that are not dense-conv launches."""
+    import re
+    if tag in DENSE_FLOP_PER_FACE:
+        return DENSE_FLOP_PER_FACE[tag]
+    m = re.fullmatch(r"conv(\d)x\d(?:_argmax)?_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)
+    if m:
+        k, c, n, h, w = map(int, m.groups())
+        return 2.0 * k * k * c * n * h * w
+    m = re.fullmatch(r"block_c(\d+)_(\d+)x(\d+)", tag)          # BasicBlock: two 3x3 convs C -> C
+    if m:
+        c, h, w = map(int, m.groups())
+        return 2 * 2.0 * 9 * c * c * h * w
+    m = re.fullmatch(r"chain(\d+)_c(\d+)_(\d+)x(\d+)", tag)    # n 3x3 convs C -> C resident in LDS
+    if m:
+        n, c, h, w = map(int, m.groups())
+        return n * 2.0 * 9 * c * c * h * w
+    m = re.fullmatch(r"sepup_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)  # depthwise 3x3 on C channels + pointwise C -> N
+    if m:
+        c, n, h, w = map(int, m.groups())
+        return 2.0 * h * w * c * (n + 9)
+    m = re.fullmatch(r"expdw(\d)x\d[ds]\d_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # expand C -> N + depthwise KxK on N
+    if m:
+        k, c, n, h, w = map(int, m.groups())
+        return 2.0 * h * w * n * (c + k * k)
+    return None
+
+
+KERNEL_OF_TAG_F32S = (   # profile tag prefix -> the HIP kernel that runs it in an f32s program (csrc/engine.cpp dispatch)
+    ("conv3x3_c128_n128_64x64", "conv3x3_halo_split_kernel<128,4,2>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
+    ("sepup_", "sepup_patch_kernel"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
+    ("conv", "conv_gemm_split_kernel"))
 
 
 def parse_args():
@@ -79,6 +115,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=24)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
+    ap.add_argument("--allow-torch-broadcast", action="store_true",
+                    help="N > 1 only: if the engine's own RCCL broadcast (pf_broadcast_weights) fails, distribute the weights "
+                         "through torch.distributed instead of exiting non-zero (the JSON then says so in weight_broadcast.via)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="plumbing check without a GPU: launch / rendezvous (gloo) / weight-blob broadcast / frame sharding "
                          "only, no compute, value = null (used by the CPU test tier; never a measurement)")
@@ -211,7 +250,7 @@ def dry_run_cpu(args):
     """Launch / rendezvous / broadcast / sharding plumbing on CPU (gloo); no engine, no compute, no measurement."""
     import torch
     import torch.distributed as dist
-    from peppa_pig_face_landmark_amd import bench_support as bs
+    import bench_support as bs
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -257,7 +296,7 @@ def main():
             if have < args.gpus:
                 raise SystemExit("bench.py: --gpus %d requested but only %d GPU(s) visible on this node (no CPU fallback, "
                                  "no oversubscription)" % (args.gpus, have))
-        from peppa_pig_face_landmark_amd import bench_support as bs
+        import bench_support as bs
         sys.exit(bs.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.dry_run_cpu:
         return dry_run_cpu(args)
@@ -304,7 +343,7 @@ def main():
 
     from peppa_pig_face_landmark_amd import build as pbuild
     from peppa_pig_face_landmark_amd._native import Engine, PF_NET_DETECTOR, PF_NET_LANDMARK
-    from peppa_pig_face_landmark_amd import bench_support as bs
+    import bench_support as bs
 
     if rank == 0:
         pbuild.build_hip()
@@ -330,26 +369,37 @@ def main():
         dist.broadcast(t, 0)
         return bytes(t.cpu().numpy().tobytes())
 
-    bcast = {"ms": 0.0, "bytes": 0, "via": "pf_broadcast_weights (ncclBroadcast on the engine's stream)", "rccl_version": None}
+    bcast = {"ms": 0.0, "bytes": 0, "via": "pf_broadcast_weights (ncclBroadcast on the engine's stream)", "rccl_version": None,
+             "engine_rccl_ok": True}
+    fail = None
     try:
         with _StdoutToStderr():
             blobs_out, bcast["ms"], bcast["bytes"] = bs.broadcast_programs_rccl(eng, blobs, slots, rank, world, exchange_id)
             bcast["rccl_version"] = eng.rccl_version()
-        blobs = blobs_out
         print("[bench] rank %d/%d: RCCL %s communicator of %d rank(s); %d weight bytes in %.3f ms" % (
             rank, world, bcast["rccl_version"], world, bcast["bytes"], bcast["ms"]), file=sys.stderr, flush=True)
     except Exception as e:   # noqa: BLE001
-        if use_dist:
-            # N > 1 cannot run without the weights on every rank.  The engine's own communicator failed on this rank (and, being
-            # a symmetric set-up step, on the others): distribute the blobs through torch.distributed's RCCL communicator
-            # instead and say so in the JSON -- a scaling line with a documented detour beats no line.
-            print("[bench] rank %d: pf_broadcast_weights failed (%s); falling back to torch.distributed broadcast" % (rank, e),
-                  file=sys.stderr, flush=True)
+        fail = e
+    if use_dist:
+        # the ranks must AGREE on what happens next: a rank that alone entered the fallback broadcast would hang there
+        ok = torch.tensor([0.0 if fail is not None else 1.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            print("[bench] rank %d: pf_broadcast_weights failed on at least one rank (here: %s)" % (rank, fail), file=sys.stderr, flush=True)
+            if not args.allow_torch_broadcast:
+                # a scaling line must not exist unless the C-ABI RCCL path worked: no silent detour through torch.distributed
+                dist.destroy_process_group()
+                raise SystemExit("bench.py: the engine's RCCL weight broadcast (pf_broadcast_weights) failed; "
+                                 "re-run with --allow-torch-broadcast to distribute the weights through torch.distributed instead")
             blobs, ms = bs.broadcast_blobs(blobs, dev, rank)
-            bcast.update({"ms": ms, "bytes": sum(len(b) for b in blobs.values()),
-                          "via": "torch.distributed broadcast over RCCL (pf_broadcast_weights failed: %s)" % e})
+            bcast.update({"ms": ms, "bytes": sum(len(b) for b in blobs.values()), "engine_rccl_ok": False,
+                          "via": "torch.distributed broadcast over RCCL (--allow-torch-broadcast; pf_broadcast_weights failed: %s)" % fail})
         else:
-            bcast["via"] = "single GPU: local pf_load_program (RCCL self-test failed: %s)" % e
+            blobs = blobs_out
+    elif fail is not None:
+        bcast.update({"engine_rccl_ok": False, "via": "single GPU: local pf_load_program (RCCL self-test failed: %s)" % fail})
+    else:
+        blobs = blobs_out
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
     lanes = args.lanes if workload == "pipeline" else 1
     if lanes == 1:
@@ -406,40 +456,55 @@ def main():
     # ---- per-kernel device time (HIP events on the engine's own stream), dominant kernel roofline ---
     PROF_STEPS = 3
     prof = state.profile(PROF_STEPS)
-    hero_ms, hero_n = prof.get(HERO_TAG, (0.0, 0))
     faces_per_launch = faces_per_step // lanes      # the profiled lane processes 1/lanes of the step
     frames_per_launch = args.frames // lanes
+    # The dominant kernel = the dense-conv tag with the most device time per lane-step IN THIS RUN (the Student's hero conv
+    # up2.conv2; for --model teacher whichever HRNet / decoder kernel leads), not a name fixed in this file.
+    def _square(t):      # the landmark networks run on square maps; the detector's 3:5 maps are per FRAME, not per face
+        m = __import__("re").search(r"_(\d+)x(\d+)$", t)
+        return bool(m) and m.group(1) == m.group(2)
+    dense = {t: v for t, v in prof.items() if v[1] and _square(t) and tag_flops_per_face(t) is not None}
     roofline = None
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
-    if args.dtype in ("f32", "f32s") and os.path.exists(pmc_path):
-        # HBM bytes of the hero launch from the committed rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE in
-        # separate runs, gfx950 FETCH correction applied), scaled to this run's faces per launch
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        traffic = int(pmc["traffic_bytes_per_launch"] * faces_per_launch / pmc["faces_per_launch"])
-    if hero_n:
-        avg_ms = hero_ms / hero_n
-        achieved = HERO_FLOP_PER_FACE * faces_per_launch / (avg_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "%s %s" % ("conv3x3_halo_split_kernel<128,4,2>" if args.dtype == "f32s" else "conv_gemm_kernel<%s,128,128>" % args.dtype, HERO_TAG),
+    if dense:
+        dom = max(dense, key=lambda t: dense[t][0])
+        dom_ms, dom_n = dense[dom]
+        avg_ms = dom_ms / dom_n
+        flop = tag_flops_per_face(dom)
+        achieved = flop * faces_per_launch / (avg_ms * 1e-3) / 1e12
+        kern = "conv_gemm_kernel<%s>" % args.dtype
+        if args.dtype == "f32s":
+            kern = next(k for pre, k in KERNEL_OF_TAG_F32S if dom.startswith(pre))
+        m = __import__("re").search(r"_c(\d+)(?:_n(\d+))?_(\d+)x(\d+)$", dom)
+        cin, nout, hh, ww = int(m.group(1)), int(m.group(2) or m.group(1)), int(m.group(3)), int(m.group(4))
+        esz = 2 if args.dtype == "f16" else 4
+        roofline = {"bound": "mfma", "kernel": "%s %s" % (kern, dom),
                     "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": traffic,
-                    "algorithmic_bytes": int(2 * 64 * 64 * 128 * 4 * faces_per_launch) if args.dtype != "f16" else int(2 * 64 * 64 * 128 * 2 * faces_per_launch),
-                    "faces_per_launch": faces_per_launch,
-                    "avg_launch_ms": round(avg_ms, 4), "launches": hero_n,
+                    "frac": round(achieved / PEAK_TFLOPS[args.dtype], 4), "traffic": None,
+                    "algorithmic_bytes": int((cin + nout) * hh * ww * esz * faces_per_launch),      # the input map once + the output map once
+                    "algorithmic_flop_per_face": flop, "faces_per_launch": faces_per_launch,
+                    "avg_launch_ms": round(avg_ms, 4), "launches": dom_n, "launches_per_lane_step": dom_n / PROF_STEPS,
+                    "share_of_lane_step": round(dom_ms / max(1e-9, sum(v[0] for v in prof.values())), 4),
+                    "measured": "HIP events on the engine's stream around every launch of this tag, this process",
                     "executed_mfma_tflops": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype], 2),
                     "executed_mfma_frac": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype] / PEAK_TFLOPS[args.dtype], 4)}
-
-    sq_path = os.path.join(ROOT, "profiles", "r02_run5_pmc_sq_hero_and_expdw.json")
-    if roofline is not None and args.dtype == "f32s" and os.path.exists(sq_path):
-        # matrix-pipe busy fraction of the same kernel from the committed rocprofv3 --pmc SQ pass:
-        # SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) -- relative to the clock the chip actually ran at
-        with open(sq_path) as f:
-            sq = json.load(f)["derived"]
-        key = [k for k in sq if "conv3x3_halo_split_kernel<128" in k]
-        if key:
-            roofline["mfma_pipe_busy_pmc"] = sq[key[0]]["mfma_pipe_busy_frac"]
-            roofline["pmc_source"] = "profiles/r02_run5_pmc_sq_hero_and_expdw.json"
+        # PMC figures cannot be collected from inside this process (rocprofv3 owns the counters): they are attached from
+        # the COMMITTED profile of the same kernel and flagged as such -- they do not move when the kernel regresses.
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
+        if dom == HERO_TAG and args.dtype in ("f32", "f32s") and os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            roofline["traffic"] = int(pmc["traffic_bytes_per_launch"] * faces_per_launch / pmc["faces_per_launch"])
+            roofline["traffic_from_committed_profile"] = True
+            roofline["traffic_source"] = "profiles/pmc_hero_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled to this launch size)"
+        sq_path = os.path.join(ROOT, "profiles", PMC_SQ_PROFILE)
+        if dom == HERO_TAG and args.dtype == "f32s" and os.path.exists(sq_path):
+            with open(sq_path) as f:
+                sq = json.load(f)["derived"]
+            key = [k for k in sq if "conv3x3_halo_split_kernel<128" in k]
+            if key:
+                roofline["mfma_pipe_busy_pmc"] = sq[key[0]]["mfma_pipe_busy_frac"]
+                roofline["mfma_pipe_busy_from_committed_profile"] = True
+                roofline["pmc_source"] = "profiles/" + PMC_SQ_PROFILE
     if args.dump_profile and rank == 0:
         with open(args.dump_profile, "w") as f:
             json.dump({"steps": PROF_STEPS, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
@@ -519,9 +584,10 @@ def main():
                    "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
                    "unique_frames_per_gpu": getattr(state, "unique_frames", None),
                    "results": "counts/boxes/landmarks/scores copied to page-locked host memory inside every step" if workload == "pipeline" else "device resident",
-                   "weights": "synthetic (reference .onnx blobs absent), %s: %.1f MB in %.3f ms%s" % (
-                       bcast["via"], bcast["bytes"] / 1e6, bcast["ms"],
-                       (" = %.1f GB/s vs 153 GB/s per xGMI link" % (bcast["bytes"] / 1e9 / (bcast["ms"] * 1e-3))) if bcast["ms"] > 0 else "")},
+                   "weights": "synthetic (reference .onnx blobs absent), %s: %.1f MB%s" % (
+                       bcast["via"], bcast["bytes"] / 1e6,
+                       (" in %.3f ms = %.1f GB/s vs 153 GB/s per xGMI link" % (bcast["ms"], bcast["bytes"] / 1e9 / (bcast["ms"] * 1e-3)))
+                       if (world > 1 and bcast["ms"] > 0) else (" (one rank: the broadcast is a local no-op, no rate to report)" if world == 1 else ""))},
         "roofline": roofline,
         "cpu_baseline": None,
         "extra": {"ms_per_frame": round(ms_per_step / args.frames, 4) if workload == "pipeline" else None,
@@ -535,7 +601,9 @@ def main():
                   "weight_broadcast": bcast,
                   "setup_s": round(setup_s, 2),
                   "kernel_ms_per_lane_step": {k: round(v[0] / PROF_STEPS, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:12]},
-                  "lane_step_ms_serial": round(sum(v[0] for v in prof.values()) / PROF_STEPS, 4)},
+                  "lane_step_ms_serial": round(sum(v[0] for v in prof.values()) / PROF_STEPS, 4),
+                  # how much of the lanes' serial kernel time the concurrent streams hide: serial sum x lanes / measured step
+                  "lanes_overlap": round(sum(v[0] for v in prof.values()) / PROF_STEPS * lanes / ms_per_step, 4)},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_faces, tuple(args.frame_hw), args.faces_per_frame)

@@ -1,6 +1,7 @@
-"""Benchmark plumbing shared by bench.py: program packing, RCCL weight broadcast, device-resident
-synthetic workloads.  torch is used only for device memory and torch.distributed (plumbing); every
-kernel on the timed path is the HIP engine's."""
+"""Benchmark plumbing shared by bench.py and tools/: program packing, RCCL weight broadcast, device-resident
+synthetic workloads.  Lives beside bench.py, OUTSIDE the product package: it imports torch (device memory and
+torch.distributed -- plumbing), which the engine and its ctypes shim never do; every kernel on the timed path is
+the HIP engine's."""
 from __future__ import annotations
 
 import time
@@ -8,12 +9,12 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-from . import _native
-from .graph.random_init import random_student_weights
-from .graph.student import build_student_program
+from peppa_pig_face_landmark_amd import _native
+from peppa_pig_face_landmark_amd.graph.random_init import random_student_weights
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
 
 try:  # the detector program builder arrives with the full pipeline
-    from .graph.detector import build_detector_program, random_detector_weights
+    from peppa_pig_face_landmark_amd.graph.detector import build_detector_program, random_detector_weights
 except ImportError:  # pragma: no cover
     build_detector_program = None
     random_detector_weights = None
@@ -25,7 +26,7 @@ def pipeline_available() -> bool:
 
 def build_programs(workload: str, dtype: str, model: str = "student") -> Dict[int, bytes]:
     if model == "teacher":
-        from .graph.teacher import build_teacher_program, random_teacher_weights
+        from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program, random_teacher_weights
         blobs = {_native.PF_NET_LANDMARK: build_teacher_program(random_teacher_weights(2), 256, dtype)[0]}
     else:
         blobs = {_native.PF_NET_LANDMARK: build_student_program(random_student_weights(0), 256, dtype)[0]}
@@ -190,8 +191,9 @@ class PipelineWorkload:
     def __init__(self, eng, dev, frames: int, faces_per_frame: int, seed: int, graph: bool = True,
                  frame_hw: Tuple[int, int] = (1080, 1920)):
         import torch
-        from .synth import make_frame, make_frame_grid, plant_rows
+        from peppa_pig_face_landmark_amd.synth import make_frame, make_frame_grid, plant_rows
         self.eng, self.F, self.K = eng, frames, faces_per_frame
+        self.graph = bool(graph)
         self.H, self.W = frame_hw                            # (2160, 3840) x 32 faces = BASELINE config 5 / SURVEY C5
         eng.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)   # replay the step from a captured hipGraph
         base_frames, base_rows = [], []
@@ -292,6 +294,20 @@ class PipelineWorkload:
         assert bool((self.h_counts == self.K).all()), "NMS did not return the planted faces: %s" % self.h_counts.tolist()
         assert bool(np.isfinite(self.h_kps).all()) and bool(np.isfinite(self.h_scores).all()), "non-finite landmarks"
         assert float(np.abs(self.h_kps).max()) > 0.0, "results never reached the host buffers"
+        # the timed steps replay a captured hipGraph: the SAME inputs launched eagerly (graph off, results into the device-side
+        # buffers) must give bit-identical counts / boxes / landmarks / scores -- a stale or mis-captured graph cannot pass
+        if self.graph:
+            self.eng.set_option(_native.PF_OPT_HIP_GRAPH, 0)
+            try:
+                self.eng.run_frames_device(self.frames.data_ptr(), self.F, self.H, self.W, 0.5, 0.3, 1600.0, self.K,
+                                           d_planted=self.rows.data_ptr(), rows=self.ROWS, d_counts=self.counts.data_ptr(),
+                                           d_boxes=self.boxes.data_ptr(), d_kps=self.kps.data_ptr(), d_scores=self.scores.data_ptr())
+                self.eng.sync()
+            finally:
+                self.eng.set_option(_native.PF_OPT_HIP_GRAPH, 1)
+            for name, host, dev_t in (("counts", self.h_counts, self.counts), ("boxes", self.h_boxes, self.boxes),
+                                      ("landmarks", self.h_kps, self.kps), ("scores", self.h_scores, self.scores)):
+                assert np.array_equal(host, dev_t.cpu().numpy()), "graph replay and eager launch disagree on " + name
 
     profile = LandmarkWorkload.profile
     sync = LandmarkWorkload.sync

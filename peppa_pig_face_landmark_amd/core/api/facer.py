@@ -21,6 +21,7 @@ from ...logger.logger import logger
 from ..smoother.lk import EmaFilter, GroupTrack
 from .face_detector import FaceDetector
 from .face_landmark import FaceLandmark
+from .hip_model_base import run_guarded
 
 
 def get_cfg(path: Optional[str] = None):
@@ -96,8 +97,8 @@ class FaceAna:
         # landmark stage; the frame-difference gate (facer.py:98-118) is evaluated on the GPU against the
         # previous resident frame (exact integer sum, same decision as the numpy code in diff_frames()).
         if self.device_tracking:
-            boxes, kps, scores, _ = self.face_landmark.model.guarded(
-                self.engine.track_frame, image, float(self._det_cfg["score_thrs"]), float(self._det_cfg["iou_thrs"]),
+            boxes, kps, scores, _ = run_guarded(
+                [self.face_detector.model, self.face_landmark.model], self.engine.track_frame, image, float(self._det_cfg["score_thrs"]), float(self._det_cfg["iou_thrs"]),
                 float(self.min_face), int(self.top_k), float(self.iou_thres), float(self.alpha), float(self.diff_thres),
                 self._planted_rows() if self._planted_rows is not None else None)
             self.previous_image = image

@@ -3,13 +3,38 @@
 uint8 NHWC) array, get the list of output arrays back.  Execution happens in libpeppa_hip.so."""
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+import re
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
 from ... import _native
 from ...graph.detector import build_detector_program
 from ...graph.student import build_student_program
+
+
+_RANGE_ERR = re.compile(r"activation range check failed: input of op \d+ of program (\d+)")
+
+
+def run_guarded(models: Sequence["HIPEngine"], fn, *args):
+    """``fn(*args)`` with the f32s range-guard fallback for a call that spans several networks (``pf_track_frame`` runs the
+    detector AND the landmark regressor): the error names the program slot whose activations left the representable range,
+    and THAT network is rebuilt with exact-f32 convolutions before the call is repeated -- reloading the wrong one would fail
+    again on every later frame.  One retry per network at most."""
+    for _ in range(len(models) + 1):
+        try:
+            return fn(*args)
+        except _native.PeppaHipError as e:
+            m = _RANGE_ERR.search(str(e))
+            if not m:
+                raise
+            failed = [x for x in models if x.slot == int(m.group(1)) and x.dtype != "f32"]
+            if not failed:
+                raise
+            from ...logger.logger import logger
+            logger.warning("%s network: %s -- falling back to dtype f32", failed[0].kind, e)
+            failed[0]._load("f32")
+    raise _native.PeppaHipError("range guard fallback did not converge")
 
 
 class HIPEngine:
@@ -51,15 +76,7 @@ class HIPEngine:
         """Run ``fn(*args)``; if the engine's range guard reports activations the split-precision (f32s) convolutions
         cannot represent (PF_OPT_RANGE_CHECK: outputs NaN + error), reload this network with exact-f32 MFMA convolutions
         and run again -- slower, never wrong."""
-        try:
-            return fn(*args)
-        except _native.PeppaHipError as e:
-            if "activation range check failed" not in str(e) or self.dtype == "f32":
-                raise
-            from ...logger.logger import logger
-            logger.warning("%s network: %s -- falling back to dtype f32", self.kind, e)
-            self._load("f32")
-            return fn(*args)
+        return run_guarded([self], fn, *args)
 
     def __call__(self, data: np.ndarray) -> List[np.ndarray]:
         if data.shape[0] > self.max_batch:

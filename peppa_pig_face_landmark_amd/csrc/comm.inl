@@ -126,15 +126,19 @@ int pf_broadcast_weights(pf_handle* h, const void* rccl_unique_id, int rank, int
     PF_HIP(h, hipMemcpyAsync(&sz, h->d_stage, sizeof(sz), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
     if (sz < sizeof(PfHeader)) PF_FAIL(h, "pf_broadcast_weights: root announced %llu bytes", sz);
-    if (rank != 0 && sz > capacity) PF_FAIL(h, "pf_broadcast_weights: blob of %llu bytes exceeds the receive capacity %zu", sz, capacity);
+    // A rank whose receive buffer is too small must still take part in the payload broadcast (it lands in the engine's
+    // own staging buffer, not in `blob`): returning here would leave the root and the other ranks waiting in a collective
+    // this rank never enters.  The call fails on this rank AFTER the exchange; every other rank completes normally.
+    const bool too_small = rank != 0 && sz > capacity;
     // 2. payload: rank 0's packed program, HBM to HBM over xGMI, timed with HIP events on the engine's stream
     if (ensure_stage(h, (size_t)sz)) return 1;
     if (rank == 0) PF_HIP(h, hipMemcpyAsync(h->d_stage, blob, (size_t)sz, hipMemcpyHostToDevice, h->stream));
     PF_HIP(h, hipEventRecord(h->ev0, h->stream));
     PF_NCCL(h, api.Broadcast(h->d_stage, h->d_stage, (size_t)sz, kNcclUint8, 0, h->comm, h->stream));
     PF_HIP(h, hipEventRecord(h->ev1, h->stream));
-    if (rank != 0) PF_HIP(h, hipMemcpyAsync(blob, h->d_stage, (size_t)sz, hipMemcpyDeviceToHost, h->stream));
+    if (rank != 0 && !too_small) PF_HIP(h, hipMemcpyAsync(blob, h->d_stage, (size_t)sz, hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (too_small) PF_FAIL(h, "pf_broadcast_weights: blob of %llu bytes exceeds the receive capacity %zu", sz, capacity);
     float ms = 0.f;
     PF_HIP(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     if (bcast_ms) *bcast_ms = ms;

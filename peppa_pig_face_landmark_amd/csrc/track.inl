@@ -142,7 +142,16 @@ static int track_frame_impl(pf_handle* h, const uint8_t* bgr, int mem, int heigh
     int n = 0;
     PF_HIP(h, hipMemcpyAsync(&n, t.d_n_track, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     PF_HIP(h, hipStreamSynchronize(h->stream));
-    if (check_numerics(h)) return 1;
+    if (check_numerics(h)) {
+        // The range guard poisoned this frame's outputs with NaN, and steps 4-5 above have already folded them into the
+        // stream's state (track boxes, landmark sets, One-Euro filters).  Drop all of it: the caller reloads the network as
+        // exact f32 and sends the frame again, and that call must find a stream with no track and no previous frame -- so
+        // the detector runs -- instead of a zero frame difference over NaN track boxes.
+        const std::string why = h->err;
+        (void)pf_track_reset(h);
+        h->err = why;
+        return 1;
+    }
     n = std::min(n, top_k);
     *n_out = n;
     if (n > 0) {

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from peppa_pig_face_landmark_amd import bench_support as bs
+import bench_support as bs
 
 
 def _free_port():

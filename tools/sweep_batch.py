@@ -8,7 +8,7 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from peppa_pig_face_landmark_amd import bench_support as bs  # noqa: E402
+import bench_support as bs  # noqa: E402
 from peppa_pig_face_landmark_amd._native import Engine  # noqa: E402
 
 

@@ -3,7 +3,7 @@ import os, sys, threading, time
 import torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
-from peppa_pig_face_landmark_amd import bench_support as bs
+import bench_support as bs
 from peppa_pig_face_landmark_amd._native import Engine
 
 def run(nlanes, frames_total, steps=20):
