@@ -138,3 +138,52 @@ def test_fused_hrnet_ops_report_internal_overflow_emulator(emu_library):
 def test_fused_hrnet_ops_report_internal_overflow_gpu(hip_library):
     from peppa_pig_face_landmark_amd._native import Engine
     _fused_hrnet_guard(lambda: Engine(0, hip_library))
+
+
+def _tracking_fallback(library, student_weights, detector_weights):
+    """pf_track_frame under the range guard (round-2 advisor finding): the failing frame has already been folded into the
+    stream's device state (NaN track boxes, has_track) when the guard reports it; the engine must drop that state, so the
+    facade's retry -- landmark network reloaded as exact f32 -- runs the detector again and answers like an f32 engine does."""
+    from tests.test_tracking_parity import _make_facer
+    from tests.tracking_video import video
+    frames, rows = video()
+    w = _scaled(student_weights, 3.0e5)
+    state = {"i": 0}
+
+    def run(dtype):
+        from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+        from Skps import FaceAna
+        cfg = get_cfg()
+        cfg["Skps"]["Engine"]["device_tracking"] = True
+        cfg["Skps"]["Detect"]["input_shape"] = [384, 640, 3]
+        cfg["Skps"]["Keypoints"]["input_shape"] = [64, 64, 3]
+        cfg["Skps"]["Engine"]["dtype"] = dtype
+        f = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": w}, library=library)
+        f._planted_rows = lambda: rows[state["i"]]
+        out = []
+        try:
+            for i in range(3):
+                state["i"] = i
+                out.append(f.run(frames[i].copy()))
+            return out, f.face_landmark.model.dtype, f.face_detector.model.dtype
+        finally:
+            f.engine.close()
+
+    want, _, _ = run("f32")
+    got, lm_dtype, det_dtype = run("f32s")
+    assert lm_dtype == "f32" and det_dtype == "f32s"           # the network that failed was reloaded, the other one was not
+    for a, b in zip(want, got):
+        assert len(a) == len(b) >= 2
+        for x, y in zip(a, b):
+            assert np.isfinite(np.asarray(y["box"], np.float64)).all() and np.isfinite(np.asarray(y["kps"], np.float64)).all()
+            assert np.array_equal(np.asarray(x["box"], np.float64), np.asarray(y["box"], np.float64))
+            assert np.array_equal(np.asarray(x["kps"], np.float64), np.asarray(y["kps"], np.float64))
+
+
+def test_tracking_state_rolled_back_on_guard_failure_emulator(emu_library, student_weights, detector_weights):
+    _tracking_fallback(emu_library, student_weights, detector_weights)
+
+
+@pytest.mark.gpu
+def test_tracking_state_rolled_back_on_guard_failure_gpu(hip_library, student_weights, detector_weights):
+    _tracking_fallback(hip_library, student_weights, detector_weights)
