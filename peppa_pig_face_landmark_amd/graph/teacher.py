@@ -24,6 +24,12 @@ from .student import build_decoder_and_head
 
 BRANCH_CH = [18, 36, 72, 144]
 STAGES = [(2, 1, 2), (3, 4, 3), (4, 3, 4)]  # (stage index, modules, branches)
+# model.py:313 keeps features [stem, incre(branch 0), incre(branch 1), incre(branch 2)]: the fourth (144-channel) OUTPUT of
+# the last HighResolutionModule feeds nothing.  Its six fuse convolutions are dead code -- an ONNX export of the model does
+# not even contain them (the exporter drops nodes that reach no output) -- so the program skips them and the ONNX importer
+# does not expect them.
+DEAD_FUSE_OUTPUT = (4, 2, 3)                       # (stage, module, output branch)
+DEAD_FUSE_PREFIX = "encoder.stage4.2.fuse_layers.3."
 
 
 def _bn(w, prefix):
@@ -80,6 +86,8 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                         xs[br] = basic(xs[br], f"{p}.branches.{br}.{blk}")
             fused = []
             for i in range(nb):
+                if (si, m, i) == DEAD_FUSE_OUTPUT:
+                    continue           # nothing reads the 144-channel output of the very last module (see DEAD_FUSE_PREFIX)
                 last_stage_module = (m == modules - 1)
                 name = f"encoder.stage{si}.branch{i}" if last_stage_module else ""
                 down = [j for j in range(nb) if j < i]

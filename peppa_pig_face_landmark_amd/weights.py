@@ -77,7 +77,7 @@ def split_cotrain_state_dict(sd: Mapping[str, object]) -> Tuple[Dict[str, np.nda
 # in the order the convolutions execute, which is the order of the architecture inventories
 # (graph/random_init.py::student_param_shapes, graph/detector.py::detector_param_shapes).  Every node is checked against
 # the inventory's shape before it is accepted, so a different architecture fails here with the offending layer named.
-_BN_EPS = {"student": 1e-5, "detector": 1e-3}
+_BN_EPS = {"student": 1e-5, "teacher": 1e-5, "detector": 1e-3}
 
 
 def _conv_units(shapes):
@@ -98,25 +98,82 @@ def _conv_units(shapes):
     return units, lone_bn
 
 
-def weights_from_onnx(path: str, arch: str) -> Dict[str, np.ndarray]:
+def conv_topology(model) -> list:
+    """For every Conv node, in file order: the sorted indices of the Conv nodes whose outputs reach its DATA input through
+    non-Conv nodes only (-1 = the graph input).  This Conv-to-Conv adjacency is a property of the architecture -- BatchNorm
+    folded or kept, Clip/Mul or HardSwish, Resize or Upsample make no difference -- so it pins WHICH convolution a node
+    is, where the node order alone cannot: C3's cv1 / cv2 or a ShuffleNetV2 unit's two 1x1s have identical shapes and
+    differ only in what feeds them and what they feed."""
+    producer = {o: n for n in model.nodes for o in n.outputs}
+    index = {id(n): i for i, n in enumerate(x for x in model.nodes if x.op_type == "Conv")}
+    memo: Dict[str, frozenset] = {}
+
+    def sources(name: str) -> frozenset:
+        if name in memo:
+            return memo[name]
+        memo[name] = frozenset()                 # cycle guard (ONNX graphs are acyclic; a malformed file must not hang us)
+        n = producer.get(name)
+        if n is None:
+            r = frozenset([-1]) if (name in model.inputs and name not in model.initializers) else frozenset()
+        elif n.op_type == "Conv":
+            r = frozenset([index[id(n)]])
+        else:
+            r = frozenset().union(*[sources(i) for i in n.inputs if i]) if n.inputs else frozenset()
+        memo[name] = r
+        return r
+
+    import sys
+    limit = sys.getrecursionlimit()
+    sys.setrecursionlimit(max(limit, 20000))
+    try:
+        return [sorted(sources(n.inputs[0])) for n in model.nodes if n.op_type == "Conv"]
+    finally:
+        sys.setrecursionlimit(limit)
+
+
+def _check_topology(path: str, arch: str, model) -> None:
+    import json
+    ref = os.path.join(os.path.dirname(os.path.abspath(__file__)), "graph", "onnx_topology.json")
+    with open(ref) as f:
+        want = json.load(f)[arch]
+    got = conv_topology(model)
+    for i, (a, b) in enumerate(zip(got, want)):
+        if list(a) != list(b):
+            raise ValueError("%s: Conv node #%d is fed by convolutions %s where the %s architecture has %s there -- the file "
+                             "orders (or wires) its convolutions differently from the exporter the importer was written "
+                             "against; refusing to pair weights by position" % (path, i, a, arch, b))
+
+
+def weights_from_onnx(path: str, arch: str, check_topology: bool = True) -> Dict[str, np.ndarray]:
     """Weights of ``arch`` ('student' | 'detector') lifted out of an ONNX export, keyed by the reference's state_dict
     names -- i.e. exactly what ``build_student_program`` / ``build_detector_program`` consume.  Handles both export
     flavours: BatchNorm folded into the convolutions (the default; the fused bias is carried by an identity BatchNorm in
-    the result) and BatchNormalization nodes kept."""
+    the result) and BatchNormalization nodes kept.  Nodes are paired with the architecture by execution order, shape-checked
+    one by one, and the file's Conv-to-Conv wiring must equal the architecture's (``conv_topology``)."""
     from . import onnx_lite
     if arch == "student":
         from .graph.random_init import student_param_shapes as shapes_fn
+    elif arch == "teacher":          # convert_to_onnx.py:26-28 exports either model of COTRAIN
+        from .graph.teacher import teacher_param_shapes as shapes_fn
     elif arch == "detector":
         from .graph.detector import detector_param_shapes as shapes_fn
     else:
-        raise ValueError("arch must be 'student' or 'detector'")
+        raise ValueError("arch must be 'student', 'teacher' or 'detector'")
     eps = _BN_EPS[arch]
-    units, lone_bn = _conv_units(shapes_fn())
+    shapes = list(shapes_fn())
+    dead = []
+    if arch == "teacher":      # convolutions no output depends on are absent from an export (graph/teacher.py DEAD_FUSE_PREFIX)
+        from .graph.teacher import DEAD_FUSE_PREFIX
+        dead = [e for e in shapes if e[0].startswith(DEAD_FUSE_PREFIX)]
+        shapes = [e for e in shapes if not e[0].startswith(DEAD_FUSE_PREFIX)]
+    units, lone_bn = _conv_units(shapes)
     model = onnx_lite.read_model(path)
     convs = [n for n in model.nodes if n.op_type == "Conv"]
     bns = [n for n in model.nodes if n.op_type == "BatchNormalization"]
     if len(convs) != len(units):
         raise ValueError("%s: %d Conv nodes, the %s architecture has %d convolutions" % (path, len(convs), arch, len(units)))
+    if check_topology:       # off only for the hand-written single-chain files of tests/test_onnx_import.py
+        _check_topology(path, arch, model)
     producer = {o: n for n in model.nodes for o in n.outputs}
     conv_unit = {id(n): u for n, u in zip(convs, units)}
 
@@ -177,6 +234,12 @@ def weights_from_onnx(path: str, arch: str) -> Dict[str, np.ndarray]:
         out[bnp + ".bias"] = b
         out[bnp + ".running_mean"] = np.zeros(ch, np.float32)
         out[bnp + ".running_var"] = np.full(ch, 1.0 - eps, np.float32)
+    for name, shape, kind in dead:                # never executed: any finite value will do, the inventory stays complete
+        if kind == "bn":
+            out[name + ".weight"], out[name + ".bias"] = np.ones(shape, np.float32), np.zeros(shape, np.float32)
+            out[name + ".running_mean"], out[name + ".running_var"] = np.zeros(shape, np.float32), np.ones(shape, np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
     exp = _expected(shapes_fn())
     missing = sorted(set(exp) - set(out))
     if missing:
@@ -190,7 +253,7 @@ def load_weights(path: str, arch: str) -> Dict[str, np.ndarray]:
     ``weights_only=True``)."""
     ext = os.path.splitext(path)[1].lower()
     if ext == ".onnx":
-        return weights_from_onnx(path, "student" if arch == "keypoints" else arch)
+        return weights_from_onnx(path, "student" if arch == "keypoints" else arch)     # 'teacher' and 'detector' pass through
     if ext == ".npz":
         with np.load(path) as z:
             return {k: z[k] for k in z.files}
