@@ -46,18 +46,28 @@ def needs_build() -> bool:
         return f.read().strip() != source_hash()
 
 
-def build_hip(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return OUT
+ABLATE_OUT = os.path.join(HERE, "libpeppa_hip_ablate.so")
+
+
+def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
+    """``ablate=True`` builds the TOOL flavour (``libpeppa_hip_ablate.so``, -DPF_ABLATE=1): the same sources with the timing
+    ablations of the GEMM kernels compiled in and PEPPA_DBG honoured (tools/ab_env.py; wrong results by construction).  The
+    production library has neither."""
+    out, stamp = (ABLATE_OUT, ABLATE_OUT + ".srchash") if ablate else (OUT, STAMP)
+    if not force:
+        if ablate and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
+            return out
+        if not ablate and not needs_build():
+            return out
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", CSRC] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT]
+           "-I", CSRC] + (["-DPF_ABLATE=1"] if ablate else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print("[peppa-hip] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    with open(STAMP, "w") as f:
+    with open(stamp, "w") as f:
         f.write(source_hash() + "\n")
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv))
+    print(build_hip(force="--force" in sys.argv, ablate="--ablate" in sys.argv))

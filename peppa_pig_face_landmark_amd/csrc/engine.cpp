@@ -18,6 +18,7 @@
 #include "k_layers.h"
 #include "k_mbconv.h"
 #include "k_chain.h"
+#include "k_sepup.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
 #include "k_track.h"
@@ -25,6 +26,8 @@
 
 
 namespace {
+
+const int kNumCUs = 256;   // MI355X: 8 XCDs x 32 CUs; persistent kernels launch one workgroup per CU
 
 struct Program {
     bool loaded = false;
@@ -73,6 +76,7 @@ struct pf_handle {
     unsigned long long alloc_epoch = 0;
     // kernel-variant switches for A/B timing on the GPU (environment, read once at pf_create): PEPPA_SEPUP=patch
     // selects the previous LDS-class-filter decoder front end instead of the register-blocked one
+    unsigned long long* d_dbg = nullptr;   // PEPPA_DBG & 64: cycle accounting of sepup_pipe_kernel
     int dbg = 0;             // PEPPA_DBG: timing ablations of the GEMM kernels (ConvGemmArgs::dbg), never set in production
     // tracking state of the handle's video stream (pf_track_frame, k_track.h)
     TrackState track;
@@ -96,6 +100,8 @@ struct pf_handle {
 };
 
 static std::string g_create_error;
+
+static inline int host_dbg(const pf_handle* h) { return PF_ABLATE ? h->dbg : 0; }   // see pf_common.h: constant 0 in the production library
 
 namespace { void comm_release(pf_handle* h); }   // comm.inl
 
@@ -216,7 +222,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
         (a.Npad == 128 || (a.Npad == 64 && a.outW == 64) || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
         if constexpr (SPLIT) {
             grid = dim3(pf_div_up(M, 128), 1);
-            const bool big = ((a.outH * a.outW) % 256) == 0 && !(h->dbg & 1024);     // narrow variants: 256-pixel tiles
+            const bool big = ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
@@ -344,6 +350,33 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "sepup_c%d_n%d_%dx%d", a.inC, a.N, to.H, to.W);
                     ProfScope ps(h, tagbuf);
                     const bool patch_ok = (to.W == 16 || to.W == 32 || to.W == 64) && ((to.H * to.W) % 128) == 0 && (tl.C % 32) == 0 && a.Cpad <= 640;
+                    // producer / consumer pipelined kernel (k_sepup.h): persistent workgroups, one per CU
+                    const bool pipe_ok = patch_ok && (to.H * to.W) / 128 >= 2 && (tk.C % 8) == 0 && tk.C <= 64 && a.N == a.Npad && (a.Npad == 128 || a.Npad == 256) &&
+                                         f[13] > 0 && f[14] > 0 && !(host_dbg(h) & 2048);
+                    if (pipe_ok) {
+                        SepupArgs s{};
+                        s.lo = a.up_lo; s.skip = a.up_skip; s.out = (float*)a.out; s.dw_lo = (const float*)p.cptr(f[14]); s.dw_w2 = a.dw_w2;
+                        s.wt = (const unsigned char*)a.wt; s.bias = a.bias; s.skipx = (unsigned char*)p.buf_ptr(f[13]);
+                        s.B = B; s.H = to.H; s.C1 = tl.C; s.C2 = tk.C; s.loLd = tl.ld; s.skipLd = tk.ld; s.outLd = to.ld;
+                        s.N = a.N; s.Cpad = a.Cpad; s.act = a.act; s.acc_scale = a.acc_scale; s.dbg = h->dbg;
+                        if (host_dbg(h) & 64) {      // per-role cycle accounting of the pipelined kernel (printed at pf_destroy)
+                            if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
+                            s.prof = h->d_dbg + (a.Npad == 128 ? 0 : 16);
+                        }
+                        const int tpf = to.H * to.W / 128, nskip = a.Cpad / 32 - tl.C / 32;
+                        const int per_xcd = ((B + 7) / 8) * tpf;                  // tiles of the busiest XCD
+                        const int wgs = 8 * std::min(kNumCUs / 8, per_xcd);
+                        const dim3 sg(B * tpf);
+#define PF_SEPUP_CASE(WW)                                                                                          \
+    if (to.W == WW) {                                                                                              \
+        if (nskip > 0 && tk.C <= 32) PF_LAUNCH((sepup_skip_kernel<WW, 32>), sg, dim3(512), h->stream, s);          \
+        else if (nskip > 0) PF_LAUNCH((sepup_skip_kernel<WW, 64>), sg, dim3(512), h->stream, s);                   \
+        if (a.Npad == 128) PF_LAUNCH((sepup_pipe_kernel<128, WW, 3, false, true>), dim3(wgs), dim3(1024), h->stream, s);     \
+        else PF_LAUNCH((sepup_pipe_kernel<256, WW, 2, true, false>), dim3(wgs), dim3(1024), h->stream, s);                   \
+    }
+                        PF_SEPUP_CASE(64) PF_SEPUP_CASE(32) PF_SEPUP_CASE(16)
+#undef PF_SEPUP_CASE
+                    } else
                     if (patch_ok && a.Npad == 256) {
                         grid.y = 1;
                         PF_LAUNCH((sepup_patch_kernel<256, 4, 2>), grid, dim3(512), h->stream, a);
@@ -760,7 +793,9 @@ int pf_create(int device_id, pf_handle** out) {
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return 1; }
     pf_handle* h = new pf_handle();
     h->device = device_id;
-    if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) { h->range_every = 0; h->check_pending = false; } }   // ablated kernels compute garbage
+    if constexpr (PF_ABLATE != 0) {      // ablation build only (libpeppa_hip_ablate.so): ablated kernels compute garbage, so the guard is off
+        if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) { h->range_every = 0; h->check_pending = false; } }
+    }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         g_create_error = "stream/event creation failed";
@@ -789,6 +824,19 @@ void pf_destroy(pf_handle* h) {
     }
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_range) (void)hipFree(h->d_range);
+    if (h->d_dbg) {
+        unsigned long long v[32];
+        if (hipMemcpy(v, h->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < 2; ++k) {
+                const unsigned long long* q = v + 16 * k;
+                if (!q[2]) continue;
+                const double steps = (double)q[3] / (double)q[2];          // K steps per wave
+                fprintf(stderr, "[sepup_pipe BN=%d] per wave and K step (cycles): producer dma %.0f work %.0f wait %.0f | consumer dma %.0f mfma %.0f epilogue %.0f wait %.0f  (%.0f steps/wave)\n",
+                        k ? 256 : 128, q[9] / (double)q[2] / steps, q[0] / (double)q[2] / steps, q[1] / (double)q[2] / steps, q[4] / (double)q[8] / steps, q[5] / (double)q[8] / steps,
+                        q[6] / (double)q[8] / steps, q[7] / (double)q[8] / steps, steps);
+            }
+        (void)hipFree(h->d_dbg);
+    }
     if (h->h_status) (void)hipHostFree(h->h_status);
     h->pipe.release();
     h->track.release();

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void
             const unsigned char* xl = xh + PLANE;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int shift = ky * HW2 + kx;
-            if (!(a.dbg & 16)) {
+            if (!(pf_dbg(a) & 16)) {
                 pf_half8 xhf[MT], xlf[MT];
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void
     for (int j = 0; j < NT; ++j) {
         if (j >= njt) break;
         const int n = (jt0 + j) * 16 + crow;
-        if (n < C && !(a.dbg & 32)) {
+        if (n < C && !(pf_dbg(a) & 32)) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) *reinterpret_cast<pf_f32x4*>(out + (size_t)pix[i] * a.outLd + n) = resid[j][i];
         }
@@ -463,13 +463,13 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
         for (int i = 0; i < MT1; ++i) acc1[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     int buf = 0;
     if constexpr (NBUF == 1) {
-        if (!(a.dbg & 16)) mma_group(acc1, hp1, Tag1{}, nt1, 0, 0);
+        if (!(pf_dbg(a) & 16)) mma_group(acc1, hp1, Tag1{}, nt1, 0, 0);
         __syncthreads();                                  // everybody is done with x and with conv1's weights
         load_w(1, 0, 0);
     } else {
         for (int g = 0; g < K::NG; ++g) {
             if (g + 1 < K::NG) load_w(0, g + 1, buf ^ 1); else load_w(1, 0, buf ^ 1);
-            if (!(a.dbg & 16)) mma_group(acc1, hp1, Tag1{}, nt1, g, buf);
+            if (!(pf_dbg(a) & 16)) mma_group(acc1, hp1, Tag1{}, nt1, g, buf);
             __syncthreads();
             buf ^= 1;
         }
@@ -515,11 +515,11 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int i = 0; i < MT2; ++i) acc2[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (NBUF == 1) {
-        if (!(a.dbg & 16)) mma_group(acc2, hp2, Tag2{}, MT2, 0, 0);
+        if (!(pf_dbg(a) & 16)) mma_group(acc2, hp2, Tag2{}, MT2, 0, 0);
     } else {
         for (int g = 0; g < K::NG; ++g) {
             if (g + 1 < K::NG) load_w(1, g + 1, buf ^ 1);
-            if (!(a.dbg & 16)) mma_group(acc2, hp2, Tag2{}, MT2, g, buf);
+            if (!(pf_dbg(a) & 16)) mma_group(acc2, hp2, Tag2{}, MT2, g, buf);
             if (g + 1 < K::NG) __syncthreads();
             buf ^= 1;
         }
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int n = j * 16 + crow;
-            if (n >= a.Cs || (a.dbg & 32)) continue;
+            if (n >= a.Cs || (pf_dbg(a) & 32)) continue;
             const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(a.bias[1] + n);
 #pragma unroll
             for (int i = 0; i < MT2; ++i) {

@@ -131,7 +131,7 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
                 for (int r = 0; r < 4; ++r)
                     if (v[r] > best_v[r]) { best_v[r] = v[r]; best_i[r] = local; }
             }
-            if (a.store_out && mok && !(a.dbg & 32)) {
+            if (a.store_out && mok && !(pf_dbg(a) & 32)) {
                 T* o = out + (size_t)m * a.outLd;
                 if (a.outCs == 1 && n + 3 < a.N) {
                     if constexpr (sizeof(T) == 2) {
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         const bool more = kt + 1 < nk;
         if (more) {
             if (++tap == taps) { tap = 0; ++cb; }
-            if (!(a.dbg & 256)) load_tile(tap, cb, cur ^ 1);
+            if (!(pf_dbg(a) & 256)) load_tile(tap, cb, cur ^ 1);
         }
         const unsigned char* xh = smem + cur * STAGE_BYTES;
         const unsigned char* xl = xh + PLANE_X;
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             whf[j] = *reinterpret_cast<const pf_half8*>(wh + off);
             wlf[j] = *reinterpret_cast<const pf_half8*>(wl + off);
         }
-        if (!(a.dbg & 16))
+        if (!(pf_dbg(a) & 16))
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
         }
-        if (more && !(a.dbg & 512)) store_tile(cur ^ 1);
+        if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1);
         __syncthreads();
     }
     if constexpr (EPI_K < 0) {
@@ -1119,13 +1119,13 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
         const bool last_tap = tap == 8;
-        if (more && !(a.dbg & 1)) load_w(last_tap ? 0 : tap + 1, last_tap ? cb + 1 : cb, cur ^ 1);
-        if (tap == 0 && cb + 1 < cblocks && !(a.dbg & 64)) load_x(cb + 1);          // next chunk's patch: nine taps of latency cover
+        if (more && !(pf_dbg(a) & 1)) load_w(last_tap ? 0 : tap + 1, last_tap ? cb + 1 : cb, cur ^ 1);
+        if (tap == 0 && cb + 1 < cblocks && !(pf_dbg(a) & 64)) load_x(cb + 1);          // next chunk's patch: nine taps of latency cover
         const unsigned char* wh = wbase + cur * W_BYTES;
         const unsigned char* wl = wh + BN * 64;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int shift = ky * HW2 + kx;
-        if (!(a.dbg & 16)) {
+        if (!(pf_dbg(a) & 16)) {
             if constexpr (MT == 2) {
                 // pixel fragments of the (two) 16-pixel sub-tiles stay live, weight fragments come one 16-channel tile at a
                 // time: 24 fragment registers instead of 40, which is what keeps this kernel out of scratch at 128 VGPRs
@@ -1170,11 +1170,11 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
                 }
             }
         }
-        if (last_tap && more && !(a.dbg & 64)) {
+        if (last_tap && more && !(pf_dbg(a) & 64)) {
             __syncthreads();                 // every wave is done with this chunk's patch
             store_x();
         }
-        if (!(a.dbg & 128)) __syncthreads();
+        if (!(pf_dbg(a) & 128)) __syncthreads();
         if (last_tap) { tap = 0; ++cb; } else ++tap;
     }
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     if (lo_chunks > 1) load_patch(1);
     for (int cb = 0; cb < cblocks; ++cb) {
         // ---- phase 1: weights of this step || produce the pixel operand ----------------------------------------
-        if (!(a.dbg & 1) || cb == 0) dma_weights(cb);
+        if (!(pf_dbg(a) & 1) || cb == 0) dma_weights(cb);
         float o[8];
         const int kelem = cb * 32 + xc * 8;
 #pragma unroll
@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             for (int e = 0; e < 4; ++e) { o[e] = b0[e]; o[4 + e] = b1[e]; }
             if (cb < lo_chunks) {
 #pragma unroll 1
-                for (int j = 0; j < ((a.dbg & 256) ? 1 : 3); ++j)   // one patch row at a time keeps the live LDS reads (and VGPRs) bounded
+                for (int j = 0; j < ((pf_dbg(a) & 256) ? 1 : 3); ++j)   // one patch row at a time keeps the live LDS reads (and VGPRs) bounded
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const float* pp = ppix + (j * PC + i) * 32;
@@ -1371,7 +1371,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         }
         __syncthreads();
         // ---- phase 2: next chunk's patch and filters || MFMAs -------------------------------------------------------
-        if (cb + 1 < lo_chunks && !(a.dbg & 64)) {
+        if (cb + 1 < lo_chunks && !(pf_dbg(a) & 64)) {
             store_patch();
             dma_filters(cb + 1);
             if (cb + 2 < lo_chunks) load_patch(cb + 2);

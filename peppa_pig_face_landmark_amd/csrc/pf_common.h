@@ -7,6 +7,15 @@
 #pragma once
 #include <pf_intrinsics.h>  // resolved through -I (csrc/ for the product build)
 
+// Timing ablations (wave-uniform bit masks tested inside the GEMM kernels; results are WRONG when set) exist only in the
+// ablation build -- `python -m peppa_pig_face_landmark_amd.build --ablate` compiles the same sources with -DPF_ABLATE=1 into
+// libpeppa_hip_ablate.so for tools/ab_env.py.  In the production library pf_dbg() is the constant 0: every ablation branch
+// folds away, and no environment variable can make a kernel skip work or switch the range guard off.
+#ifndef PF_ABLATE
+#define PF_ABLATE 0
+#endif
+template <typename Args> __device__ __forceinline__ int pf_dbg(const Args& a) { return PF_ABLATE ? a.dbg : 0; }
+
 enum PfAct : int { PF_ACT_NONE = 0, PF_ACT_RELU = 1, PF_ACT_HSWISH = 2, PF_ACT_SILU = 3, PF_ACT_SIGMOID = 4,
                    PF_ACT_HSIGMOID = 5 };
 

@@ -12,6 +12,7 @@
 typedef _Float16 pf_half;
 typedef _Float16 pf_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pf_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf_half2 __attribute__((ext_vector_type(2)));
 typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -72,6 +73,9 @@ template <int N> __device__ __forceinline__ void pf_wait_vm_barrier() {
     // LDS / global accesses across it, lgkmcnt(0) retires this wave's own LDS writes before the rendezvous
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
 }
+
+// shader clock (s_memtime), for the per-wave time accounting of the ablation build
+__device__ __forceinline__ unsigned long long pf_clock() { return __builtin_amdgcn_s_memtime(); }
 
 #define PF_BUILD_TAG "gfx950"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 7
+#define PF_PROGRAM_VERSION 8
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -54,7 +54,7 @@ enum PfOpCode : int32_t {
                         //    convs + identity residual each), one face's map resident in LDS (k_chain.h); split programs only
     PF_OP_BLOCK = 17,   // f: in_t out_t C wt1 b1 s1 wt2 b2 s2 (s = acc_scale float bits): one BasicBlock, TR rows per workgroup, flat-K
                         //    weights (k_chain.h basic_block_kernel); split programs only
-    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip)
+    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };
 

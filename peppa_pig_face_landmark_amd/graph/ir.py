@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 7
+VERSION = 8
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
@@ -461,8 +461,12 @@ class ProgramBuilder:
         out = self.tensor(ts.H, ts.W, _round_up(n, self.ve), name=out_name)
         woff, npad, cpad, acc_scale, use_split = self.pack_conv_weight(pw_weight)
         assert use_split
+        # Only the affine BatchNorm sits between the depthwise and the pointwise conv (SeparableConv2d, model.py:21-30), so
+        # the depthwise bias is a constant vector in front of a linear map: it moves into the pointwise bias here
+        # (float64) and the kernels' producers start from zero -- no per-K-step bias traffic.
         b = np.zeros(npad, np.float64)
-        b[:n] = pw_bias
+        b[:n] = pw_bias.astype(np.float64) + pw_weight.astype(np.float64).reshape(n, c) @ dw_bias.astype(np.float64)
+        dw_bias = np.zeros(c, np.float64)
         wdw = dw_weight.astype(np.float64).reshape(c, 3, 3)
         c1 = tl.C
         assert ts.H >= 6 and ts.W >= 6
@@ -477,9 +481,14 @@ class ProgramBuilder:
                 E[cy, cx] = np.einsum("kj,li,ckl->jic", ay[cy], ax[cx], wdw[:c1])
         dwe = self.const_f32(E.reshape(16 * 9, c1))
         dws = self.const_f32(np.transpose(wdw[c1:].reshape(c - c1, 9), (1, 0)))
+        # scratch of the pipelined kernel (csrc/k_sepup.h): the skip channels' depthwise output, pre-split, one 16 KB pixel-operand
+        # stage per (128-pixel tile, 32-channel chunk); lives for this op only
+        n_skip_chunks = cpad // 32 - c1 // 32
+        skipx = self.buffer((ts.H * ts.W + 127) // 128 * n_skip_chunks * 4096, ELEM_F32, "sepup.skipx")
+        dwl = self.const_f32(np.transpose(wdw[:c1].reshape(c1, 9), (1, 0)))       # [9][C1]: the pipelined kernel upsamples, then filters
         self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
-                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws],
-                 [self._tb(lo), self._tb(skip)], [self._tb(out)])
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, skipx, dwl],
+                 [self._tb(lo), self._tb(skip)], [self._tb(out), skipx])
         return out
 
     def add_up(self, a: int, b: int, shift: int, act: str, out_name: str = "") -> int:

@@ -10,6 +10,7 @@
 typedef _Float16 pf_half;
 typedef _Float16 pf_half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pf_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 pf_half2 __attribute__((ext_vector_type(2)));
 typedef float pf_f32x4 __attribute__((ext_vector_type(4)));
 typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
 
@@ -83,6 +84,8 @@ inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_la
 inline void pf_glds16_raw(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
 
 template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous
+
+inline unsigned long long pf_clock() { return 0; }
 
 #define PF_BUILD_TAG "simt-emu"
 #define PF_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)

@@ -103,3 +103,25 @@ def test_production_f32s_program_with_fused_decoder_front_end(emu_library, stude
         assert np.abs(score - oscore)[safe].max() < 2e-3
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("batch", [3, 9])
+def test_pipelined_decoder_front_end_ragged_batches(emu_library, student_weights, batch):
+    """sepup_pipe_kernel (csrc/k_sepup.h) walks its tiles per XCD: workgroup b serves faces b & 7, (b & 7) + 8, ...  With 3
+    faces five of the eight lists are empty (those workgroups leave before the first barrier); with 9 faces list 0 holds two
+    faces, so its workgroups run their rings across a tile AND a face boundary.  Size 128: 32 x 32 / 128-channel and
+    16 x 16 / 256-channel variants, both against the oracle."""
+    from peppa_pig_face_landmark_amd._native import Engine
+    eng = Engine(0, emu_library)
+    try:
+        blob, _ = build_student_program(student_weights, 128, "f32s")
+        eng.load_program(0, blob, batch)
+        crops = sw.smooth_blob_images(batch, 128, seed=1900 + batch)
+        loc, score = eng.landmark_forward(crops)
+        oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+        safe = helpers.heat_margins(taps) > 1e-3
+        d = np.abs(loc - oloc).reshape(batch, 98, 2).max(2)
+        assert safe.mean() > 0.9 and d[safe].max() < 1e-4, d[safe].max()
+        assert np.abs(score - oscore)[safe].max() < 2e-3
+    finally:
+        eng.close()

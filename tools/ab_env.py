@@ -3,6 +3,10 @@ usage: python tools/ab_env.py "<tag substring,tag substring,...>" "NAME=VAL NAME
 Each remaining argument is one variant: a space-separated list of environment assignments ("-" = none).
 Prints whole-pipeline faces/s and the per-lane-step ms of every kernel tag containing one of the substrings."""
 import json, os, subprocess, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from peppa_pig_face_landmark_amd import build as _b  # noqa: E402
+# PEPPA_DBG exists in the ablation flavour of the library only (-DPF_ABLATE=1); build it in-tree BEFORE going to the GPU box
+os.environ["PEPPA_HIP_LIBRARY"] = _b.build_hip(ablate=True, verbose=False)
 subs = sys.argv[1].split(",")
 extra = os.environ.get("AB_BENCH_ARGS", "").split()
 os.makedirs("gpurun_out", exist_ok=True)
