@@ -120,6 +120,9 @@ def shard_frames(n_frames: int, rank: int, world: int):
 
 
 def load_programs(eng: "_native.Engine", blobs: Dict[int, bytes], workload: str, faces: int, frames: int):
+    import os
+    if os.environ.get("PEPPA_BENCH_NO_GUARD"):       # measurement aid only: what the always-on f32s range guard costs
+        eng.set_option(_native.PF_OPT_RANGE_CHECK, 0)
     eng.load_program(_native.PF_NET_LANDMARK, blobs[_native.PF_NET_LANDMARK], faces)
     if workload == "pipeline":
         eng.load_program(_native.PF_NET_DETECTOR, blobs[_native.PF_NET_DETECTOR], frames)

@@ -224,11 +224,12 @@ int pf_comm_destroy(pf_handle* h);
 enum { PF_OPT_HIP_GRAPH = 1,
        /* Range guard of the f32s (split-precision) programs.  Their convolutions write each f32 activation as f16 hi + f16 lo:
         * |x| >= 65504 overflows, and a tensor whose largest magnitude is below 2^-10 loses its low halves to f16 subnormals.
-        * Every value-th forward call (default 256; 0 = never) and the first one after a program load also measures max |x| of
-        * the input of every split-precision op.  A tensor outside [2^-10, 6e4] sets that call's outputs to NaN and makes the
-        * next synchronising entry point (pf_sync, any call with host outputs) fail with a message naming the op -- never
-        * silent inf or garbage.  The remedy is to load the program with PF_DTYPE_F32 (exact f32 MFMA), which the Python
-        * facade does on its own. */
+        * On EVERY forward call (value != 0, the default; 0 switches the guard off) each kernel that splits keeps max |x| of
+        * what it splits and a one-workgroup kernel at the end of the forward judges the maxima -- part of the captured graphs
+        * too.  A tensor outside [2^-10, 6e4] (or holding a NaN) sets that call's outputs to NaN and makes the next
+        * synchronising entry point (pf_sync, any call with host outputs) fail with a message naming the op -- never silent
+        * inf or garbage.  The remedy is to load the program with PF_DTYPE_F32 (exact f32 MFMA), which the Python facade does
+        * on its own. */
        PF_OPT_RANGE_CHECK = 2 };
 int pf_set_option(pf_handle* h, int option, int value);
 

@@ -37,6 +37,7 @@ struct Program {
     std::vector<PfOpRec> ops;
     char* d_const = nullptr;
     char* d_arena = nullptr;
+    unsigned* d_range = nullptr;     // f32s range guard: one slot per op (k_layers.h range_verdict_kernel)
     size_t arena_bytes = 0;
     int max_batch = 0;
     int esize = 2;
@@ -81,12 +82,10 @@ struct pf_handle {
     // tracking state of the handle's video stream (pf_track_frame, k_track.h)
     TrackState track;
     JpegState jpeg;          // pf_decode_jpeg (jpeg.inl)
-    // f32s range guard (k_layers.h: absmax_kernel / range_verdict_kernel): every `range_every`-th call, and the first call
-    // after a program load, measures max |x| of the input of every split-precision op
-    int range_every = 256;
+    // f32s range guard (pf_common.h pf_amax, k_layers.h range_verdict_kernel): on for every forward unless switched off with
+    // PF_OPT_RANGE_CHECK = 0; the slots live with each program
+    int range_every = 1;
     unsigned long long n_calls = 0;
-    bool check_pending = true, check_now = false;
-    unsigned* d_range = nullptr; size_t range_cap = 0;
     int* h_status = nullptr;            // page-locked, device-visible: {code, op, value bits, program slot}
     // RCCL communicator for pf_broadcast_weights (comm.inl); created lazily, one per handle
     void* comm = nullptr;
@@ -152,7 +151,7 @@ struct ProfScope {
 
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool SPLIT>
-static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B) {
+static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B, unsigned* range_slot) {
     const int32_t* f = op.f;
     const PfTensorRec& ti = p.tens[f[0]];
     const PfTensorRec& to = p.tens[f[1]];
@@ -174,6 +173,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     a.act = f[15]; a.amaxN = f[19]; a.store_out = f[20];
     memcpy(&a.acc_scale, &f[22], 4);
     a.dbg = h->dbg;
+    a.range_slot = range_slot;
     // tile configurations: index -> (BM pixels, BN channels).  The channel tile is chosen so that
     // q tiles of NT*16 channels cover Npad with the least padding (NT <= 8), ties -> fewer tiles.
     static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256, 128};
@@ -266,44 +266,15 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B)
     return 0;
 }
 
-// range guard: max |x| of activation tensor `t` of program `p` into slot `oi` (checked forwards of f32s programs only)
-static int measure_range(pf_handle* h, const Program& p, int t, size_t oi, int B) {
-    const PfTensorRec& tr = p.tens[t];
-    AbsMaxArgs a{};
-    a.in = (const float*)p.tensor_ptr(t);
-    a.slot = h->d_range + oi;
-    a.pixels = (long long)B * tr.H * tr.W;
-    a.C = tr.C; a.ld = tr.ld;
-    if (tr.C % 4) PF_FAIL(h, "range guard: tensor with %d channels", tr.C);
-    const long long work = a.pixels * (tr.C / 4);
-    PF_LAUNCH(absmax_kernel, dim3((unsigned)std::min<long long>(1024, (work + 255) / 256)), dim3(256), h->stream, a);
-    return 0;
-}
-
 template <typename T, bool SPLIT>
 static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_kind, int B) {
     Program& p = h->prog[slot];
     constexpr int VE = PfVec<T>::N;
-    const bool guard = SPLIT && h->check_now && !h->capturing;
-    if (guard) {
-        if (h->range_cap < p.ops.size()) {
-            if (h->d_range) (void)hipFree(h->d_range);
-            h->d_range = nullptr;
-            PF_HIP(h, hipMalloc((void**)&h->d_range, p.ops.size() * sizeof(unsigned)));
-            h->range_cap = p.ops.size();
-        }
-        PF_HIP(h, hipMemsetAsync(h->d_range, 0, p.ops.size() * sizeof(unsigned), h->stream));
-    }
+    const bool guard = SPLIT && h->range_every > 0 && p.d_range != nullptr;     // every call, graph-captured ones included
+    auto slot_of = [&](size_t oi) -> unsigned* { return guard ? p.d_range + oi * PF_RANGE_SUBSLOTS : nullptr; };
     for (size_t oi = 0; oi < p.ops.size(); ++oi) {
         const PfOpRec& op = p.ops[oi];
         const int32_t* f = op.f;
-        if (guard) {   // inputs of the ops that split activations into f16 hi / lo parts
-            const bool conv_split = op.code == PF_OP_CONV && f[23] != 0;
-            const bool mb_split = op.code == PF_OP_MBCONV && (f[21] == 0 || f[21] == 3);
-            if (conv_split || mb_split || op.code == PF_OP_EXPDW || op.code == PF_OP_SEPUP)
-                if (measure_range(h, p, f[0], oi, B)) return 1;
-            if (op.code == PF_OP_SEPUP && measure_range(h, p, f[1], oi, B)) return 1;
-        }
         switch (op.code) {
             case PF_OP_STEM: {
                 const PfTensorRec& to = p.tens[f[1]];
@@ -322,7 +293,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 break;
             }
             case PF_OP_CONV:
-                if (launch_conv<T, SPLIT>(h, p, op, B)) return 1;
+                if (launch_conv<T, SPLIT>(h, p, op, B, slot_of(oi))) return 1;
                 break;
             case PF_OP_SEPUP: {
                 if constexpr (!SPLIT) {
@@ -342,6 +313,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
                     a.dbg = h->dbg;
+                    a.range_slot = slot_of(oi);
                     if (to.H != 2 * tl.H || to.W != 2 * tl.W || tk.H != to.H || tk.W != to.W || (tl.C % 32) != 0 || to.H < 6 || to.W < 6)
                         PF_FAIL(h, "sepup: inconsistent tensor shapes");
                     dim3 grid(pf_div_up(B * to.H * to.W, 128), pf_div_up(a.Npad, 128));
@@ -358,7 +330,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         s.lo = a.up_lo; s.skip = a.up_skip; s.out = (float*)a.out; s.dw_lo = (const float*)p.cptr(f[14]); s.dw_w2 = a.dw_w2;
                         s.wt = (const unsigned char*)a.wt; s.bias = a.bias; s.skipx = (unsigned char*)p.buf_ptr(f[13]);
                         s.B = B; s.H = to.H; s.C1 = tl.C; s.C2 = tk.C; s.loLd = tl.ld; s.skipLd = tk.ld; s.outLd = to.ld;
-                        s.N = a.N; s.Cpad = a.Cpad; s.act = a.act; s.acc_scale = a.acc_scale; s.dbg = h->dbg;
+                        s.N = a.N; s.Cpad = a.Cpad; s.act = a.act; s.acc_scale = a.acc_scale; s.dbg = h->dbg; s.range_slot = a.range_slot;
                         if (host_dbg(h) & 64) {      // per-role cycle accounting of the pipelined kernel (printed at pf_destroy)
                             if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
                             s.prof = h->d_dbg + (a.Npad == 128 ? 0 : 16);
@@ -410,6 +382,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.B = B; a.inH = ti.H; a.inW = ti.W; a.Cin = ti.C; a.inLd = ti.ld;
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
                     a.act_dw = a.act; a.act_out = PF_ACT_NONE; a.outCs = 1;
+                    a.range_slot = slot_of(oi);
                     if (f[21] == 3) {   // ShuffleNetV2 unit: separate activations, channel-strided store, pass-through copy
                         a.act_dw = f[22]; a.act_out = f[23]; a.outCs = f[24];
                         if (f[25] >= 0) {
@@ -475,7 +448,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         a.wt[c] = p.cptr(f[4 + 3 * c]); a.bias[c] = (const float*)p.cptr(f[5 + 3 * c]);
                         memcpy(&a.acc_scale[c], &f[6 + 3 * c], 4);
                     }
-                    a.range_slot = guard ? h->d_range + oi : nullptr;
+                    a.range_slot = slot_of(oi);
                     a.dbg = h->dbg;
                     char tagbuf[96];
                     tagbuf[0] = 0;
@@ -504,7 +477,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         a.wt[c] = p.cptr(f[3 + 3 * c]); a.bias[c] = (const float*)p.cptr(f[4 + 3 * c]);
                         memcpy(&a.acc_scale[c], &f[5 + 3 * c], 4);
                     }
-                    a.range_slot = guard ? h->d_range + oi : nullptr;
+                    a.range_slot = slot_of(oi);
                     a.dbg = h->dbg;
                     char tagbuf[96];
                     tagbuf[0] = 0;
@@ -534,6 +507,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.outH = to.H; a.outW = to.W; a.outLd = to.ld; a.outCs = 1; a.outCpad = to.C;
                     a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.store_out = 1;
                     a.dbg = h->dbg;
+                    a.range_slot = slot_of(oi);
                     const int ohw = to.H * to.W;
                     const int dstride = f[15] > 0 ? f[15] : 1;
                     if (dstride == 2) {   // 64 x 64 -> 32 x 32, depthwise stride 2: whole image per workgroup, quadrant by quadrant
@@ -725,7 +699,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     }
     if (guard) {
         RangeVerdictArgs v{};
-        v.slots = h->d_range; v.n_ops = (int)p.ops.size();
+        v.slots = p.d_range; v.n_ops = (int)p.ops.size();
         v.lo = 0.0009765625f;            // 2^-10: below this a tensor's low halves sit in the f16 subnormal range
         v.hi = 6.0e4f;                   // f16 overflows at 65504
         v.status = h->h_status; v.prog_slot = slot;
@@ -738,12 +712,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     return 0;
 }
 
-// Start of every forward-running entry point: is this one of the range-checked calls?
-static void begin_call(pf_handle* h) {
-    h->check_now = h->range_every > 0 && (h->check_pending || (h->n_calls % (unsigned long long)h->range_every) == 0);
-    h->check_pending = false;
-    h->n_calls++;
-}
+// Start of every forward-running entry point
+static void begin_call(pf_handle* h) { h->n_calls++; }
 
 // After a stream synchronisation: did a range-checked forward find a tensor the f32s kernels cannot represent?
 static int check_numerics(pf_handle* h) {
@@ -752,7 +722,6 @@ static int check_numerics(pf_handle* h) {
     float v;
     memcpy(&v, &h->h_status[2], 4);
     h->h_status[0] = 0;
-    h->check_pending = true;             // keep checking until a clean forward has been seen
     PF_FAIL(h, "activation range check failed: input of op %d of program %d has max |x| = %g, %s the range [9.8e-4, 6e4] the "
                "split-precision (f32s) convolutions can represent (outputs were set to NaN); rebuild the program with dtype 'f32'",
             op, slot, (double)v, code == 1 ? "above" : "below");
@@ -794,7 +763,7 @@ int pf_create(int device_id, pf_handle** out) {
     pf_handle* h = new pf_handle();
     h->device = device_id;
     if constexpr (PF_ABLATE != 0) {      // ablation build only (libpeppa_hip_ablate.so): ablated kernels compute garbage, so the guard is off
-        if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) { h->range_every = 0; h->check_pending = false; } }
+        if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) h->range_every = 0; }
     }
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
@@ -821,9 +790,9 @@ void pf_destroy(pf_handle* h) {
     for (auto& p : h->prog) {
         if (p.d_const) (void)hipFree(p.d_const);
         if (p.d_arena) (void)hipFree(p.d_arena);
+        if (p.d_range) (void)hipFree(p.d_range);
     }
     if (h->d_stage) (void)hipFree(h->d_stage);
-    if (h->d_range) (void)hipFree(h->d_range);
     if (h->d_dbg) {
         unsigned long long v[32];
         if (hipMemcpy(v, h->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess)
@@ -874,6 +843,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipStreamSynchronize(h->stream));
     if (p.d_const) { (void)hipFree(p.d_const); p.d_const = nullptr; }
     if (p.d_arena) { (void)hipFree(p.d_arena); p.d_arena = nullptr; }
+    if (p.d_range) { (void)hipFree(p.d_range); p.d_range = nullptr; }
     h->alloc_epoch++;            // graphs captured over the old arena / constants must not be replayed
     p.loaded = false;
     p.hdr = hd;
@@ -900,8 +870,12 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     p.arena_bytes = (size_t)hd.arena_units_per_item * 256 * (size_t)max_batch;
     PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes));
     PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
+    if (hd.dtype == PF_DTYPE_F32_SPLIT) {
+        const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);
+        PF_HIP(h, hipMalloc((void**)&p.d_range, rb));
+        PF_HIP(h, hipMemset(p.d_range, 0, rb));
+    }
     p.loaded = true;
-    h->check_pending = true;             // the first forward of a new program is range-checked
     return 0;
 }
 

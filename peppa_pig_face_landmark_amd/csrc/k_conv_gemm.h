@@ -52,6 +52,7 @@ struct ConvGemmArgs {
     // fused "pointwise expand -> depthwise kxk" (EPI != 0 kernels): dw_w2 = [K*K][N] depthwise weights, dw_b = [N]
     // bias, both BN folded; the depthwise output goes to `out`, its per-face channel means (SE squeeze) to gap_out
     float* gap_out;       // [B][N] or nullptr
+    unsigned* range_slot; // f32s range guard: max |v| (raw bits) over everything this launch splits into f16 hi / lo, or nullptr
     // timing ablations of conv3x3_halo_split_kernel (PEPPA_DBG bit mask, 0 in production; results are WRONG when set):
     // 1 = weights fetched for the first K step only, 16 = no MFMAs, 32 = no output stores, 64 = input patch staged for the
     // first channel chunk only, 128 = no per-tap barrier; conv_gemm_split_kernel: 16 as above, 256 = operands (pixels AND weights)
@@ -568,6 +569,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     const size_t wrow_bytes = (size_t)taps * cblocks * 128;
 
     pf_f32x4 xreg[XUNITS][2];
+    unsigned amax = 0;                                 // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
 
     // Weights are pre-split bytes: they go global -> LDS directly (no VGPRs, no ds_write pass, which costs 13
     // LDS-path cycles per 16 bytes against 4 for a read).  LDS slot s (16 B, lane-linear as the DMA requires) is
@@ -688,6 +691,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
                 lo[e] = (pf_half)(v - (float)hv);
+                amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off(xrow0 + XROWSTEP * u, xc);
             *reinterpret_cast<pf_half8*>(xh + off) = hi;
@@ -741,6 +745,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1);
         __syncthreads();
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     if constexpr (EPI_K < 0) {
         conv_gemm_argmax_epilogue<BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, OHW, a.acc_scale);
     } else if constexpr (EPI_K != 0) {
@@ -761,6 +766,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 // lives in LDS and the depthwise conv reads it there, thread = (channel, image row), as in the 16 x 16 kernel.
 template <int K, int DIL>
 __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
+    unsigned amax = 0;                                 // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     constexpr int HW = 32, CB = 16;
     constexpr int RS = HW * CB + 16;            // floats per image row in LDS
     constexpr int PAD = DIL * (K - 1) / 2;
@@ -813,6 +820,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
                     const pf_half hv = (pf_half)v;
                     xh[e] = hv;
                     xl[e] = (pf_half)(v - (float)hv);
+                    amax = pf_amax(amax, v);
                 }
                 acc = pf_mfma_16x16x32_f16(wlf[ks], xh, acc);
                 acc = pf_mfma_16x16x32_f16(whf[ks], xl, acc);
@@ -869,6 +877,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
             rs += o[x];
         }
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     if (a.gap_out) {
         __syncthreads();                        // E is dead: its LDS becomes the row-sum scratch
         es[y * CB + c] = rs;
@@ -890,6 +899,8 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
 // visits all four quadrants.  Input channels <= 32 (one K step).
 template <int K>
 __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) {
+    unsigned amax = 0;                                 // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     constexpr int IN = 64, OUT = 32, Q = 16, CB = 16;    // input / output size, quadrant size, channels per workgroup
     constexpr int PAD = (K - 1) / 2;
     constexpr int R = (Q - 1) * 2 + K;                   // 35: input rows / columns a quadrant needs
@@ -940,6 +951,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
                 const pf_half hv = (pf_half)v;
                 xhf[e] = hv;
                 xlf[e] = (pf_half)(v - (float)hv);
+                amax = pf_amax(amax, v);
             }
             pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             acc = pf_mfma_16x16x32_f16(wlf, xhf, acc);
@@ -981,6 +993,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
         }
         __syncthreads();                        // the next quadrant overwrites the region
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     if (a.gap_out) {
         es[(t >> 4) * CB + c] = rs;             // 32 partial sums per channel
         __syncthreads();
@@ -1054,6 +1067,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         xoff[u] = ok ? (iy * W + ix) * a.inLd + xc * 8 : -1;
     }
     pf_f32x4 xreg[XU][2];
+    unsigned amax = 0;                                 // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     auto load_x = [&](int cb) {
 #pragma unroll
         for (int u = 0; u < XU; ++u)
@@ -1075,6 +1090,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
                 lo[e] = (pf_half)(v - (float)hv);
+                amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off(xhp[u], xc);
             *reinterpret_cast<pf_half8*>(xh + off) = hi;
@@ -1177,6 +1193,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         if (!(pf_dbg(a) & 128)) __syncthreads();
         if (last_tap) { tap = 0; ++cb; } else ++tap;
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }
 
@@ -1301,6 +1318,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fchunk = lane >> 4;
 
+    unsigned amax = 0;                                 // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     for (int i = t; i < MAXC; i += NTHR) sdwb[i] = i < a.inC ? a.dw_b[i] : 0.f;
     if (lo_chunks > 0) {
         load_patch(0);
@@ -1365,6 +1384,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                 const pf_half hv = (pf_half)o[e];
                 hi[e] = hv;
                 lo8[e] = (pf_half)(o[e] - (float)hv);
+                amax = pf_amax(amax, o[e]);
             }
             *reinterpret_cast<pf_half8*>(xh + xrow_off) = hi;
             *reinterpret_cast<pf_half8*>(xl + xrow_off) = lo8;
@@ -1397,5 +1417,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         }
         __syncthreads();
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }

@@ -634,41 +634,14 @@ __global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Range guard of the split-precision (f32s) convolutions.  Those kernels write every f32 activation as hi + lo with
-// hi = f16(v): |v| >= 65504 overflows to inf, and a tensor whose LARGEST magnitude is below ~1e-3 loses its low halves to
-// the f16 subnormal range.  Weights are pre-scaled per layer at pack time; activations depend on the data, so every N-th
-// forward (PF_OPT_RANGE_CHECK) the executor measures max |x| of the input of every split-precision op and, if a tensor is
-// outside [2^-10, 6e4], poisons the outputs with NaN and records (op, value): no silent inf, no silent garbage.
-struct AbsMaxArgs {
-    const float* in;       // [pixels][ld] f32 view
-    unsigned* slot;        // max |x| as float bits (non-negative floats order like unsigned integers)
-    long long pixels;
-    int C, ld;
-};
-
-__global__ __launch_bounds__(256) void absmax_kernel(AbsMaxArgs a) {
-    const int cv = a.C / 4;
-    const long long total = a.pixels * cv;
-    float m = 0.f;
-    bool bad = false;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const long long px = i / cv;
-        const int c = (int)(i - px * cv);
-        const pf_f32x4 v = *reinterpret_cast<const pf_f32x4*>(a.in + (size_t)px * a.ld + 4 * c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float av = fabsf(v[e]);
-            bad |= !(av == av);                 // NaN
-            m = fmaxf(m, av);
-        }
-    }
-    if (bad) m = __builtin_inff();              // a NaN input reports as out of range
-    for (int mask = 1; mask < 64; mask <<= 1) m = fmaxf(m, pf_shfl_xor_f32(m, mask));
-    if ((threadIdx.x & 63) == 0) atomicMax(a.slot, __float_as_uint(m));
-}
-
+// Range guard of the split-precision (f32s) convolutions, ALWAYS ON.  Those kernels write every f32 activation as hi + lo
+// with hi = f16(v): |v| >= 65504 overflows to inf, and a tensor whose LARGEST magnitude is below ~1e-3 loses its low halves to
+// the f16 subnormal range.  Weights are pre-scaled per layer at pack time; activations depend on the data, so every kernel that
+// splits keeps the maximum of |v| over what it splits and commits it to its op's slot (pf_amax / pf_amax_commit,
+// pf_common.h); at the end of EVERY forward this kernel compares the slots against [2^-10, 6e4], poisons the outputs with NaN
+// and records (op, value) on a violation -- no silent inf, no silent garbage, on any call -- and clears the slots for the next one.
 struct RangeVerdictArgs {
-    const unsigned* slots;   // [n_ops] float bits, 0 = op not measured
+    unsigned* slots;         // [n_ops][PF_RANGE_SUBSLOTS] raw bits of max |v|, 0 = not measured; cleared here
     int n_ops;
     float lo, hi;            // accepted range of a tensor's max |x|
     int* status;             // [4] = code (0 ok, 1 overflow, 2 underflow), op index, value bits, program slot (host-mapped)
@@ -679,19 +652,32 @@ struct RangeVerdictArgs {
 };
 
 __global__ __launch_bounds__(256) void range_verdict_kernel(RangeVerdictArgs a) {
+    static_assert(PF_RANGE_SUBSLOTS == 256, "one word per thread");
     __shared__ int s_code, s_op;
-    __shared__ unsigned s_val;
-    if (threadIdx.x == 0) {
-        s_code = 0; s_op = -1; s_val = 0;
-        for (int i = 0; i < a.n_ops; ++i) {
-            const unsigned bits = a.slots[i];
-            if (bits == 0) continue;                          // op not measured / all-zero tensor
-            const float v = __uint_as_float(bits);
-            if (!(v <= a.hi)) { s_code = 1; s_op = i; s_val = bits; break; }
-            if (v < a.lo && s_code == 0) { s_code = 2; s_op = i; s_val = bits; }
+    __shared__ unsigned s_val, s_part[4];
+    const int t = threadIdx.x;
+    if (t == 0) { s_code = 0; s_op = -1; s_val = 0; }
+    for (int i = 0; i < a.n_ops; ++i) {
+        unsigned m = a.slots[i * PF_RANGE_SUBSLOTS + t];
+        a.slots[i * PF_RANGE_SUBSLOTS + t] = 0;                     // cleared for the next forward
+        for (int mask = 1; mask < 64; mask <<= 1) {
+            const unsigned o = (unsigned)pf_shfl_xor_i32((int)m, mask);
+            m = o > m ? o : m;
         }
-        if (s_code != 0 && a.status[0] == 0) { a.status[1] = s_op; a.status[2] = (int)s_val; a.status[3] = a.prog_slot; a.status[0] = s_code; }
+        __syncthreads();
+        if ((t & 63) == 0) s_part[t >> 6] = m;
+        __syncthreads();
+        if (t == 0) {
+            unsigned bits = s_part[0];
+            for (int k = 1; k < 4; ++k) bits = s_part[k] > bits ? s_part[k] : bits;
+            if (bits != 0) {                                        // 0: op not measured / all-zero tensor
+                const float v = __uint_as_float(bits);
+                if (!(v <= a.hi) && s_code != 1) { s_code = 1; s_op = i; s_val = bits; }     // NaN bits land here too
+                if (v < a.lo && s_code == 0) { s_code = 2; s_op = i; s_val = bits; }
+            }
+        }
     }
+    if (t == 0 && s_code != 0 && a.status[0] == 0) { a.status[1] = s_op; a.status[2] = (int)s_val; a.status[3] = a.prog_slot; a.status[0] = s_code; }
     __syncthreads();
     if (s_code == 0) return;
     const float nan = __builtin_nanf("");

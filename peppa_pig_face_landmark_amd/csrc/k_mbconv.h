@@ -38,24 +38,28 @@ struct MbconvArgs {
     // output act = act_out; the result goes to every outCs-th channel of `out` (channel shuffle folded into the
     // store) and the pass-through half of the unit's input is copied to the channels in between.
     int act_dw, act_out, outCs;
+    unsigned* range_slot;   // f32s range guard: max |v| (raw bits) over the block input and the depthwise output it splits, or nullptr
     const float* pass_src;  // [B][outH][outW][passLd], passC channels -> pass_dst channel c*outCs, or nullptr
     float* pass_dst;
     int passLd, passC;
 };
 
-__device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1, pf_half8& hi, pf_half8& lo) {
+__device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1, pf_half8& hi, pf_half8& lo, unsigned& amax) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float v = e < 4 ? v0[e & 3] : v1[e & 3];
         const pf_half hv = (pf_half)v;
         hi[e] = hv;
         lo[e] = (pf_half)(v - (float)hv);
+        amax = pf_amax(amax, v);                 // range guard (pf_common.h)
     }
 }
 
 // S: stride, KS: input channels / 32 (rounded up), PH x PW: patch, MAXNT: output channels / 16 (rounded up)
 template <int S, int KS, int PH, int PW, int MAXNT, int MSPLIT>
 __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(MbconvArgs a) {
+    unsigned amax = 0;                         // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     constexpr int PP = PH * PW, MPW = PP / 16;
     constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
     constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
                 v0 = *reinterpret_cast<const pf_f32x4*>(px + ks * 32 + k8);
                 v1 = *reinterpret_cast<const pf_f32x4*>(px + ks * 32 + k8 + 4);
             }
-            pf_split8(v0, v1, xh[mt][ks], xl[mt][ks]);
+            pf_split8(v0, v1, xh[mt][ks], xl[mt][ks], amax);
         }
     }
     pf_f32x4 acc[MPW][MAXNT];
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 #pragma unroll
         for (int mt = 0; mt < MPW; ++mt) {
             const float* dp = ds + (mt * 16 + frow) * DS + k8;
-            pf_split8(*reinterpret_cast<const pf_f32x4*>(dp), *reinterpret_cast<const pf_f32x4*>(dp + 4), dh[mt], dl[mt]);
+            pf_split8(*reinterpret_cast<const pf_f32x4*>(dp), *reinterpret_cast<const pf_f32x4*>(dp + 4), dh[mt], dl[mt], amax);
         }
 #pragma unroll
         for (int nt = 0; nt < MAXNT; ++nt)
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
             for (int r = 0; r < 4; ++r) a.pass_dst[pix * a.outLd + (size_t)(c + r) * a.outCs] = v[r];
         }
     };
+    pf_amax_commit(a.range_slot, amax, amax_seen);
     if constexpr (MSPLIT == 1) {
 #pragma unroll
         for (int mt = 0; mt < MPW; ++mt)

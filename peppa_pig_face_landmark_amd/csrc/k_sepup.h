@@ -45,6 +45,7 @@ struct SepupArgs {
     int B, H, C1, C2, loLd, skipLd, outLd;
     int N, Cpad, act;
     float acc_scale;
+    unsigned* range_slot;       // f32s range guard: max |v| (raw bits) over the depthwise outputs both kernels split, or nullptr
     unsigned long long* prof;   // dbg & 64: per-role cycle totals {producer: work, barrier wait | consumer: dma issue, mfma, epilogue, barrier wait} + wave counts
     int dbg;                    // timing ablations (1 no weight refresh, 2 no patch/filter refresh, 4 no producer taps, 8 no MFMAs, 16 no stores)
 };
@@ -87,6 +88,8 @@ __global__ __launch_bounds__(512) void sepup_skip_kernel(SepupArgs a) {
     const int xc = t & 3, prow = t >> 2;
     const int ty = prow / W, px = prow - ty * W;
     const int nskip = (C2 + 31) >> 5;
+    unsigned amax = 0;                                               // range guard (pf_common.h)
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
     for (int sc = 0; sc < nskip; ++sc) {
         const int c0 = sc * 32 + xc * 8;
         float o[8];
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(512) void sepup_skip_kernel(SepupArgs a) {
             const pf_half hv = (pf_half)o[e];
             hi[e] = hv;
             lo8[e] = (pf_half)(o[e] - (float)hv);
+            amax = pf_amax(amax, o[e]);
         }
         unsigned char* dst = a.skipx + ((size_t)tb * nskip + sc) * 16384 + pf_lds_chunk_off(prow, xc);
         *reinterpret_cast<pf_half8*>(dst) = hi;
         *reinterpret_cast<pf_half8*>(dst + 8192) = lo8;
     }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
 }
 
 // position class of a row / column: 0 first, 1 last, 2 even, 3 odd (ir.py::sepconv_up builds the filters in this order)
@@ -271,6 +276,8 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             mb = (y0 + 2 * brow + 2 >= H) ? 0.f : 1.f;
         };
         prod_tile(0);
+        unsigned amax = 0;                                           // range guard (pf_common.h)
+        const unsigned amax_seen = pf_amax_seen(a.range_slot);
         unsigned long long t_dma = 0, t_work = 0, t_wait = 0;
         for (int g = 0; g <= S; ++g) {
             const unsigned long long c0 = prof ? pf_clock() : 0;
@@ -339,6 +346,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
                                 const pf_half hv = (pf_half)o[dy][dx][e];
                                 hi[e] = hv;
                                 lo2[e] = (pf_half)(o[dy][dx][e] - (float)hv);
+                                amax = pf_amax(amax, o[dy][dx][e]);
                             }
                             *reinterpret_cast<pf_half2*>(xdst + xoff[dy][dx]) = hi;
                             *reinterpret_cast<pf_half2*>(xdst + 8192 + xoff[dy][dx]) = lo2;
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             else pf_wait_vm_barrier<0>();
             if (prof) { t_dma += c1 - c0; t_work += c2 - c1; t_wait += pf_clock() - c2; }
         }
+        pf_amax_commit(a.range_slot, amax, amax_seen);
         if (prof && lane == 0) {
             atomicAdd(a.prof + 0, t_work); atomicAdd(a.prof + 1, t_wait); atomicAdd(a.prof + 2, 1ull);
             atomicAdd(a.prof + 3, (unsigned long long)S); atomicAdd(a.prof + 9, t_dma);

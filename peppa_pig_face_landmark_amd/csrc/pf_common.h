@@ -16,6 +16,40 @@
 #endif
 template <typename Args> __device__ __forceinline__ int pf_dbg(const Args& a) { return PF_ABLATE ? a.dbg : 0; }
 
+// ---- range guard of the split-precision (f32s) kernels, always on ---------------------------------------------------------------
+// Every kernel that writes f32 values as f16 hi + lo keeps a running maximum of |v| over EVERYTHING it splits, as raw bits
+// (NaN > inf > every finite value in that order, so a NaN is reported as well), and commits it with one atomicMax per wave
+// into its op's slot; range_verdict_kernel (k_layers.h) judges and clears the slots at the end of every forward.  Cost: an AND
+// and an unsigned max per split element, next to the four conversions of the split itself.
+__device__ __forceinline__ unsigned pf_amax(unsigned m, float v) {
+    const unsigned b = __float_as_uint(v) & 0x7fffffffu;
+    return b > m ? b : m;
+}
+// One op owns PF_RANGE_SUBSLOTS consecutive words; a wave commits to the word its (workgroup, wave) index selects, and only if
+// its maximum beats what is already there (a plain load first).  atomicMax of tens of thousands of waves on ONE address
+// serialises in the L2 at ~80 ns apiece (measured: +0.5 ms on an 8192-workgroup launch, +20 us on a 960-workgroup one even
+// with 16 words); spread over 256 words the first round of a launch puts ~16 on each and every later wave only loads.
+#define PF_RANGE_SUBSLOTS 256
+__device__ __forceinline__ unsigned* pf_amax_word(unsigned* slot) {
+    return slot + ((((blockIdx.x + 5 * blockIdx.y) << 4) + (threadIdx.x >> 6)) & (PF_RANGE_SUBSLOTS - 1));
+}
+// at kernel entry: what the wave's word holds now (the load's latency hides behind the kernel body; a stale value only means an
+// atomic that was not needed)
+__device__ __forceinline__ unsigned pf_amax_seen(unsigned* slot) { return slot ? __atomic_load_n(pf_amax_word(slot), __ATOMIC_RELAXED) : 0u; }
+__device__ __forceinline__ void pf_amax_commit(unsigned* slot, unsigned m, unsigned seen) {
+    if (!slot) return;
+    // wave maximum: four DPP exchanges inside each 16-lane row, then the four row results through SGPRs
+    { const unsigned o = (unsigned)pf_row_xchg_i32<0>((int)m); m = o > m ? o : m; }
+    { const unsigned o = (unsigned)pf_row_xchg_i32<1>((int)m); m = o > m ? o : m; }
+    { const unsigned o = (unsigned)pf_row_xchg_i32<2>((int)m); m = o > m ? o : m; }
+    { const unsigned o = (unsigned)pf_row_xchg_i32<3>((int)m); m = o > m ? o : m; }
+    const unsigned r0 = (unsigned)pf_readlane_i32((int)m, 0), r1 = (unsigned)pf_readlane_i32((int)m, 16);
+    const unsigned r2 = (unsigned)pf_readlane_i32((int)m, 32), r3 = (unsigned)pf_readlane_i32((int)m, 48);
+    const unsigned a01 = r0 > r1 ? r0 : r1, a23 = r2 > r3 ? r2 : r3;
+    m = a01 > a23 ? a01 : a23;
+    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(pf_amax_word(slot), m);
+}
+
 enum PfAct : int { PF_ACT_NONE = 0, PF_ACT_RELU = 1, PF_ACT_HSWISH = 2, PF_ACT_SILU = 3, PF_ACT_SIGMOID = 4,
                    PF_ACT_HSIGMOID = 5 };
 

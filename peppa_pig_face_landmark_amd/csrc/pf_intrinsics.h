@@ -36,6 +36,8 @@ template <int STEP> __device__ __forceinline__ float pf_row_xchg_f32(float v) {
     return __int_as_float(pf_row_xchg_i32<STEP>(__float_as_int(v)));
 }
 
+__device__ __forceinline__ int pf_readlane_i32(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }   // lane: compile-time constant
+
 // Orders LDS traffic between the lanes of ONE wave (producer lanes write, other lanes read) without a
 // workgroup barrier: the wave issues its LDS instructions in order, so only the compiler has to be fenced.
 __device__ __forceinline__ void pf_wave_sync() {

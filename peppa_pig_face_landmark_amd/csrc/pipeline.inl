@@ -310,9 +310,7 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     if (out_mem != PF_MEM_HOST && out_mem != PF_MEM_DEVICE && out_mem != PF_MEM_HOST_PINNED) PF_FAIL(h, "pf_run_frames: bad out_mem %d", out_mem);
     // results into page-locked host memory are plain asynchronous copies on the stream: they capture into the graph too
     begin_call(h);
-    // a range-checked call (every PF_OPT_RANGE_CHECK-th, and the first after a program load) runs eagerly: the
-    // measurement kernels are not part of the captured graphs
-    const bool graphable = h->use_graphs && !h->profiling && !h->check_now && mem == PF_MEM_DEVICE &&
+    const bool graphable = h->use_graphs && !h->profiling && mem == PF_MEM_DEVICE &&
                            (out_mem == PF_MEM_DEVICE || out_mem == PF_MEM_HOST_PINNED);
     if (!graphable) {
         if (enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
@@ -387,9 +385,9 @@ int pf_set_option(pf_handle* h, int option, int value) {
     if (!h) return 1;
     if (option == PF_OPT_HIP_GRAPH) { h->use_graphs = value != 0; return 0; }
     if (option == PF_OPT_RANGE_CHECK) {
-        if (value < 0) PF_FAIL(h, "PF_OPT_RANGE_CHECK: period must be >= 0");
-        h->range_every = value;
-        h->check_pending = value > 0;
+        if (value < 0) PF_FAIL(h, "PF_OPT_RANGE_CHECK: value must be >= 0");
+        if ((value > 0) != (h->range_every > 0)) h->alloc_epoch++;      // captured graphs carry the slot pointers: recapture
+        h->range_every = value;                                        // 0 = off, anything else = every forward
         return 0;
     }
     PF_FAIL(h, "unknown option %d", option);

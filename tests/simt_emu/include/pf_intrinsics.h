@@ -78,6 +78,8 @@ template <int STEP> inline float pf_row_xchg_f32(float v) {
     return __shfl(v, src, 64);
 }
 
+inline int pf_readlane_i32(int v, int lane) { return __shfl(v, lane, 64); }
+
 inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
 inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }

@@ -187,3 +187,34 @@ def test_tracking_state_rolled_back_on_guard_failure_emulator(emu_library, stude
 @pytest.mark.gpu
 def test_tracking_state_rolled_back_on_guard_failure_gpu(hip_library, student_weights, detector_weights):
     _tracking_fallback(hip_library, student_weights, detector_weights)
+
+
+def _guard_fires_on_any_call(make_engine, student_weights, size):
+    """Always-on guard (round-2 verdict: the every-256th-call schedule left 255 calls unguarded): the SECOND call of a healthy
+    program is fed an input that drives the activations past f16's range -- it must fail like a first call would, and the
+    third call, healthy again, must answer exactly like the first."""
+    eng = make_engine()
+    try:
+        blob, _ = build_student_program(student_weights, size, "f32s")
+        eng.load_program(0, blob, 2)
+        crops = sw.smooth_blob_images(2, size, seed=608)
+        x = np.ascontiguousarray(crops.astype(np.float32).transpose(0, 3, 1, 2) / np.float32(255.0))
+        a = eng.landmark_forward(x)
+        assert np.isfinite(a[0]).all()
+        with pytest.raises(_native.PeppaHipError, match="activation range check failed.*above"):
+            eng.landmark_forward(x * np.float32(3.0e6))
+        b = eng.landmark_forward(x)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    finally:
+        eng.close()
+
+
+def test_guard_fires_on_any_call_emulator(emu_library, student_weights):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _guard_fires_on_any_call(lambda: Engine(0, emu_library), student_weights, 64)
+
+
+@pytest.mark.gpu
+def test_guard_fires_on_any_call_gpu(hip_library, student_weights):
+    from peppa_pig_face_landmark_amd._native import Engine
+    _guard_fires_on_any_call(lambda: Engine(0, hip_library), student_weights, 256)
