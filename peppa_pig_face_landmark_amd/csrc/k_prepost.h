@@ -331,6 +331,7 @@ struct CropParamArgs {
     int n, per_frame, H, W;
     float min_face;       // 20 (face_landmark.py:26)
     double width_factor;  // 1 + 2*extend[0]  (face_landmark.py:83)
+    const int* boxes64_f32;   // device flag: the rows of boxes64 hold float32 values and numpy would compute in float32 (k_track.h)
 };
 
 __global__ __launch_bounds__(64) void crop_params_kernel(CropParamArgs a) {
@@ -341,7 +342,10 @@ __global__ __launch_bounds__(64) void crop_params_kernel(CropParamArgs a) {
     for (int k = 0; k < 8; ++k) p[k] = 0;
     for (int k = 0; k < 5; ++k) cf[k] = 0.f;
     if (a.counts && (i % a.per_frame) >= a.counts[i / a.per_frame]) return;
-    if (a.boxes64) {
+    float bf[4];
+    const bool as_f32 = a.boxes64 && a.boxes64_f32 && *a.boxes64_f32 != 0;
+    if (as_f32) for (int k = 0; k < 4; ++k) bf[k] = (float)a.boxes64[(size_t)i * 4 + k];
+    if (a.boxes64 && !as_f32) {
         const double* b = a.boxes64 + (size_t)i * 4;
         const double w = b[2] - b[0], h = b[3] - b[1];
         if (w <= (double)a.min_face || h <= (double)a.min_face || !(w == w) || !(h == h)) return;
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64) void crop_params_kernel(CropParamArgs a) {
         cf[0] = (float)wc; cf[1] = (float)hc; cf[2] = (float)x0; cf[3] = (float)y0; cf[4] = (float)add;
         return;
     }
-    const float* b = a.boxes + (size_t)i * 4;
+    const float* b = as_f32 ? bf : a.boxes + (size_t)i * 4;
     const float w = __fsub_rn(b[2], b[0]), h = __fsub_rn(b[3], b[1]);
     if (w <= a.min_face || h <= a.min_face || !(w == w) || !(h == h)) return;
     const int add = (int)fmaxf(w, h);

@@ -130,11 +130,12 @@ int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const Lett
 
 // crop boxes -> uint8 crops (FaceLandmark.preprocess)
 int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
-                   const float* d_boxes, const int* d_counts, int faces, int per_frame, int S, const double* d_boxes64 = nullptr) {
+                   const float* d_boxes, const int* d_counts, int faces, int per_frame, int S, const double* d_boxes64 = nullptr,
+                   const int* d_boxes64_f32 = nullptr) {
     PipelineScratch& s = h->pipe;
     if (ensure_dev(h, s.d_crops, s.crops_bytes, (size_t)faces * S * S * 3)) return 1;
     CropParamArgs ca{};
-    ca.boxes = d_boxes; ca.boxes64 = d_boxes64; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
+    ca.boxes = d_boxes; ca.boxes64 = d_boxes64; ca.boxes64_f32 = d_boxes64_f32; ca.counts = d_counts; ca.params = s.d_crop_params; ca.cropf = s.d_cropf;
     ca.n = faces; ca.per_frame = per_frame; ca.H = H; ca.W = W;
     ca.min_face = 20.f;                  // FaceLandmark.min_face, face_landmark.py:26
     ca.width_factor = 1 + 2 * 0.2;       // (1 + 2*extend[0]) with extend = [0.2, 0.3], Skps.yml:14
@@ -158,11 +159,12 @@ int run_crop_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, in
 
 // crops -> landmark program (with back-projection to frame coordinates)
 int run_landmark_stage(pf_handle* h, const unsigned char* d_frames, int H, int W, int row_stride,
-                       const float* d_boxes, const int* d_counts, int faces, int per_frame, const double* d_boxes64 = nullptr) {
+                       const float* d_boxes, const int* d_counts, int faces, int per_frame, const double* d_boxes64 = nullptr,
+                       const int* d_boxes64_f32 = nullptr) {
     Program& lm = h->prog[PF_NET_LANDMARK];
     PipelineScratch& s = h->pipe;
     if (faces > lm.max_batch) PF_FAIL(h, "%d faces exceed the landmark program's max_batch %d", faces, lm.max_batch);
-    if (run_crop_stage(h, d_frames, H, W, row_stride, d_boxes, d_counts, faces, per_frame, lm.hdr.in_h, d_boxes64)) return 1;
+    if (run_crop_stage(h, d_frames, H, W, row_stride, d_boxes, d_counts, faces, per_frame, lm.hdr.in_h, d_boxes64, d_boxes64_f32)) return 1;
     s.d_crop_for_decode = s.d_cropf;
     s.d_kps_for_decode = s.d_kps;
     const int rc = run_program(h, PF_NET_LANDMARK, s.d_crops, PF_INPUT_U8_NHWC, faces);

@@ -23,6 +23,8 @@ int ensure_track(pf_handle* h, int top_k) {
     PF_HIP(h, hipMalloc((void**)&t.d_n_track, sizeof(int)));
     PF_HIP(h, hipMalloc((void**)&t.d_n_judged, sizeof(int)));
     PF_HIP(h, hipMalloc((void**)&t.d_n_sel, sizeof(int)));
+    PF_HIP(h, hipMalloc((void**)&t.d_f32, 4 * sizeof(int)));
+    PF_HIP(h, hipMemset(t.d_f32, 0, 4 * sizeof(int)));
     t.top_k = top_k;
     t.has_track = t.lm_valid = false;
     t.cur = 0;
@@ -90,6 +92,7 @@ static int track_frame_impl(pf_handle* h, const uint8_t* bgr, int mem, int heigh
     begin_call(h);
     const double* d_boxes_in = t.d_track_box;      // boxes that enter sort_and_filter
     const int* d_n_in = t.d_n_track;
+    const int* d_in_f32 = t.d_f32 + 0;             // ... and their dtype flag (k_track.h): track_box's, unless the detector runs
     if (run_det) {
         const LetterboxGeom g = letterbox_geom(height, width, det.hdr.in_h, det.hdr.in_w);
         if (run_detector_stage(h, d_frame, 1, height, width, row_stride, g)) return 1;
@@ -103,20 +106,22 @@ static int track_frame_impl(pf_handle* h, const uint8_t* bgr, int mem, int heigh
         }
         if (run_nms_stage(h, d_rows, rows, 1, g, score_thres, nms_iou_thres, 0.f, 1, false)) return 1;
         JudgeArgs ja{};
-        ja.prev = t.d_track_box; ja.n_prev = t.d_n_track; ja.has_prev = t.has_track ? 1 : 0;
-        ja.now_f32 = h->pipe.d_keep_rows; ja.now_stride = 16; ja.now_f64 = nullptr; ja.n_now = h->pipe.d_keep_count;
-        ja.out = t.d_judged; ja.n_out = t.d_n_judged; ja.iou_thres = track_iou_thres; ja.alpha = smooth_box; ja.max_now = kTrackMaxNow;
+        ja.prev = t.d_track_box; ja.n_prev = t.d_n_track; ja.has_prev = t.has_track ? 1 : 0; ja.prev_f32 = t.d_f32 + 0;
+        ja.now_f32 = h->pipe.d_keep_rows; ja.now_stride = 16; ja.now_f64 = nullptr; ja.now_f32_flag = nullptr; ja.n_now = h->pipe.d_keep_count;
+        ja.out = t.d_judged; ja.n_out = t.d_n_judged; ja.out_f32 = t.d_f32 + 1;
+        ja.iou_thres = track_iou_thres; ja.alpha = smooth_box; ja.max_now = kTrackMaxNow;
         PF_LAUNCH(track_judge_kernel, dim3(1), dim3(256), h->stream, ja);
         t.lm_valid = false;                        // trace.previous_landmarks_set = None (facer.py:60)
         d_boxes_in = t.d_judged;
         d_n_in = t.d_n_judged;
+        d_in_f32 = t.d_f32 + 1;
     }
     // 2. sort_and_filter -> boxes_return (float64 rows, stay on the device)
     SelectArgs sa{};
-    sa.boxes = d_boxes_in; sa.n = d_n_in; sa.out = t.d_sel; sa.n_out = t.d_n_sel; sa.min_face = min_face; sa.top_k = top_k;
+    sa.boxes = d_boxes_in; sa.n = d_n_in; sa.out = t.d_sel; sa.n_out = t.d_n_sel; sa.boxes_f32 = d_in_f32; sa.min_face = min_face; sa.top_k = top_k;
     PF_LAUNCH(track_select_kernel, dim3(1), dim3(64), h->stream, sa);
     // 3. landmark stage on the selected boxes (count read on the device: slots >= n_sel are skipped)
-    if (run_landmark_stage(h, d_frame, height, width, row_stride, h->pipe.d_sel_boxes, t.d_n_sel, top_k, top_k, t.d_sel)) return 1;
+    if (run_landmark_stage(h, d_frame, height, width, row_stride, h->pipe.d_sel_boxes, t.d_n_sel, top_k, top_k, t.d_sel, d_in_f32)) return 1;
     // 4. One-Euro smoothing against the previous sets + hull boxes
     const int nxt = t.cur ^ 1;
     PF_LAUNCH(track_count_kernel, dim3(1), dim3(64), h->stream, (const int*)h->pipe.d_crop_params, (const int*)t.d_n_sel, t.d_n_lm[nxt]);
@@ -124,6 +129,9 @@ static int track_frame_impl(pf_handle* h, const uint8_t* bgr, int mem, int heigh
     ga.kps = h->pipe.d_kps; ga.scores_in = (const float*)lm.buf_ptr(lm.hdr.out_buf1); ga.crop_params = h->pipe.d_crop_params;
     ga.n_sel = t.d_n_sel;
     ga.prev_lm = t.d_lm[t.cur]; ga.prev_dx = t.d_dx[t.cur]; ga.n_prev = t.d_n_lm[t.cur]; ga.prev_valid = t.lm_valid ? 1 : 0;
+    ga.prev_f32 = t.d_f32 + 2 + t.cur; ga.out_f32 = t.d_f32 + 2 + nxt;
+    static const int one = 1;     // the new sets are float32 (the network's landmarks) unless a face is smoothed against the previous ones
+    PF_HIP(h, hipMemcpyAsync(t.d_f32 + 2 + nxt, &one, sizeof(int), hipMemcpyHostToDevice, h->stream));
     ga.out_lm = t.d_lm[nxt]; ga.out_dx = t.d_dx[nxt]; ga.n_out = t.d_n_lm[nxt];
     ga.hull = t.d_hull; ga.scores_out = t.d_scores;
     ga.iou_thres = track_iou_thres; ga.scale_w = (double)width; ga.scale_h = (double)height;
@@ -131,9 +139,10 @@ static int track_frame_impl(pf_handle* h, const uint8_t* bgr, int mem, int heigh
     PF_LAUNCH(track_group_kernel, dim3(top_k), dim3(128), h->stream, ga);
     // 5. track_box = judge_boxs(boxes_return, hull boxes) (facer.py:70-81)
     JudgeArgs jb{};
-    jb.prev = t.d_sel; jb.n_prev = t.d_n_sel; jb.has_prev = 1;
-    jb.now_f32 = nullptr; jb.now_stride = 4; jb.now_f64 = t.d_hull; jb.n_now = t.d_n_lm[nxt];
-    jb.out = t.d_track_box; jb.n_out = t.d_n_track; jb.iou_thres = track_iou_thres; jb.alpha = smooth_box; jb.max_now = top_k;
+    jb.prev = t.d_sel; jb.n_prev = t.d_n_sel; jb.has_prev = 1; jb.prev_f32 = d_in_f32;
+    jb.now_f32 = nullptr; jb.now_stride = 4; jb.now_f64 = t.d_hull; jb.now_f32_flag = t.d_f32 + 2 + nxt; jb.n_now = t.d_n_lm[nxt];
+    jb.out = t.d_track_box; jb.n_out = t.d_n_track; jb.out_f32 = t.d_f32 + 0;
+    jb.iou_thres = track_iou_thres; jb.alpha = smooth_box; jb.max_now = top_k;
     PF_LAUNCH(track_judge_kernel, dim3(1), dim3(256), h->stream, jb);
     t.cur = nxt;
     t.lm_valid = true;
