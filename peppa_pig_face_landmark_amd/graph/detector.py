@@ -58,13 +58,18 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
     x = conv(pb.view(cat, h2, w2, 32, 0, 32), "model.0.stem_3", name="model.0")
 
     # ---- ShuffleV2 backbone -----------------------------------------------------------------------
-    def shuffle_block(x, prefix, inp, oup, stride, name=""):
+    def shuffle_block(x, prefix, inp, oup, stride, name="", into=None):
+        """``into = (buffer, channel offset, pixel stride)``: write the block's output straight into a channel slice of a
+        concat buffer (the PAN head's torch.cat inputs) instead of a buffer of its own."""
         tx = pb.tensors[x]
         bf = oup // 2
         oh, ow = tx.H // stride, tx.W // stride
-        out_buf = pb.buffer(oh * ow * oup, ir.ELEM_ACT, name or prefix)
-        even = pb.strided_view(out_buf, oh, ow, bf, 0, oup)
-        odd = pb.strided_view(out_buf, oh, ow, bf, 1, oup)
+        if into is None:
+            out_buf, ocoff, old = pb.buffer(oh * ow * oup, ir.ELEM_ACT, name or prefix), 0, oup
+        else:
+            out_buf, ocoff, old = into
+        even = pb.strided_view(out_buf, oh, ow, bf, ocoff + 0, old)
+        odd = pb.strided_view(out_buf, oh, ow, bf, ocoff + 1, old)
         if stride == 1 and fuse_units and pb.shuffle_unit_supported(bf):
             x1 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff, tx.ld)
             x2 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff + bf, tx.ld)
@@ -72,7 +77,7 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
             wd, bd = ir.fold_bn(w[f"{prefix}.branch2.3.weight"], None, _bn(w, f"{prefix}.branch2.4"), BN_EPS)
             w2, b2 = ir.fold_bn(w[f"{prefix}.branch2.5.weight"], None, _bn(w, f"{prefix}.branch2.6"), BN_EPS)
             pb.shuffle_unit(x2, w1, b1, wd, bd, w2, b2, "silu", odd, 2, x1, even)
-            return pb.view(out_buf, oh, ow, oup, 0, oup, name=name)
+            return pb.view(out_buf, oh, ow, oup, ocoff, old, name=name)
         if stride == 1:
             pb.copy(pb.view(tx.buf, tx.H, tx.W, bf, tx.coff, tx.ld), even, out_cs=2)
             x2 = pb.view(tx.buf, tx.H, tx.W, bf, tx.coff + bf, tx.ld)
@@ -88,16 +93,28 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
         y = pb.dw(y, wt, b, "none", stride=stride, pad=1)
         wt, b = ir.fold_bn(w[f"{prefix}.branch2.5.weight"], None, _bn(w, f"{prefix}.branch2.6"), BN_EPS)
         pb.conv(y, wt, b, "silu", out=odd, out_cs=2)
-        return pb.view(out_buf, oh, ow, oup, 0, oup, name=name)
+        return pb.view(out_buf, oh, ow, oup, ocoff, old, name=name)
+
+    # ---- concat buffers of the PAN head, allocated up front: every torch.cat input that is produced at the concat's own
+    # resolution is WRITTEN into its channel slice by its producer (6 of the 8 copy launches of the straightforward graph are
+    # gone); only the two nearest-x2 upsampled inputs are still copied
+    h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+    cat9 = pb.buffer(h16 * w16 * 192, ir.ELEM_ACT, "cat9")        # [up(model.7) 64 | model.4 128] @ /16
+    cat13 = pb.buffer(h8 * w8 * 128, ir.ELEM_ACT, "cat13")        # [up(model.11) 64 | model.2 64] @ /8
+    cat16 = pb.buffer(h16 * w16 * 128, ir.ELEM_ACT, "cat16")      # [model.15 64 | model.11 64] @ /16
+    cat19 = pb.buffer(h32 * w32 * 128, ir.ELEM_ACT, "cat19")      # [model.18 64 | model.7 64] @ /32
+    into = {2: (cat13, 64, 128), 4: (cat9, 64, 192)}
 
     feats = {}
     for li, cin, cout, reps in _BACKBONE:
         x = shuffle_block(x, f"model.{li}", cin, cout, 2, name=f"model.{li}")
         for r in range(reps):
-            x = shuffle_block(x, f"model.{li + 1}.{r}", cout, cout, 1, name=f"model.{li + 1}" if r == reps - 1 else "")
+            last = r == reps - 1
+            x = shuffle_block(x, f"model.{li + 1}.{r}", cout, cout, 1, name=f"model.{li + 1}" if last else "",
+                              into=into.get(li + 1) if last else None)
         feats[li + 1] = x
 
-    # ---- PAN head -------------------------------------------------------------------------------------
+    # ---- PAN head -------------------------------------------------------------------------------------------------
     def c3(x, prefix, name):
         tx = pb.tensors[x]
         catb = pb.buffer(tx.H * tx.W * 64, ir.ELEM_ACT, prefix + ".cat")
@@ -107,23 +124,16 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
         conv(x, f"{prefix}.cv2", out=pb.view(catb, tx.H, tx.W, 32, 32, 64))
         return conv(pb.view(catb, tx.H, tx.W, 64, 0, 64), f"{prefix}.cv3", name=name)
 
-    def concat2(a, up, b_, name):
-        ta, tb = pb.tensors[a], pb.tensors[b_]
-        hh, ww = ta.H * up, ta.W * up
-        assert (hh, ww) == (tb.H, tb.W)
-        buf = pb.buffer(hh * ww * (ta.C + tb.C), ir.ELEM_ACT, name)
-        pb.copy(a, pb.view(buf, hh, ww, ta.C, 0, ta.C + tb.C), out_cs=1, up=up)
-        pb.copy(b_, pb.view(buf, hh, ww, tb.C, ta.C, ta.C + tb.C), out_cs=1, up=1)
-        return pb.view(buf, hh, ww, ta.C + tb.C, 0, ta.C + tb.C)
-
-    l7 = conv(feats[6], "model.7")
-    l10 = c3(concat2(l7, 2, feats[4], "cat9"), "model.10", "model.10")
-    l11 = conv(l10, "model.11")
-    l14 = c3(concat2(l11, 2, feats[2], "cat13"), "model.14", "model.14")
-    l15 = conv(l14, "model.15", 3, 2)
-    l17 = c3(concat2(l15, 1, l11, "cat16"), "model.17", "model.17")
-    l18 = conv(l17, "model.18", 3, 2)
-    l20 = c3(concat2(l18, 1, l7, "cat19"), "model.20", "model.20")
+    l7 = conv(feats[6], "model.7", out=pb.view(cat19, h32, w32, 64, 64, 128), name="model.7")
+    pb.copy(l7, pb.view(cat9, h16, w16, 64, 0, 192), out_cs=1, up=2)
+    l10 = c3(pb.view(cat9, h16, w16, 192, 0, 192), "model.10", "model.10")
+    l11 = conv(l10, "model.11", out=pb.view(cat16, h16, w16, 64, 64, 128), name="model.11")
+    pb.copy(l11, pb.view(cat13, h8, w8, 64, 0, 128), out_cs=1, up=2)
+    l14 = c3(pb.view(cat13, h8, w8, 128, 0, 128), "model.14", "model.14")
+    conv(l14, "model.15", 3, 2, out=pb.view(cat16, h16, w16, 64, 0, 128), name="model.15")
+    l17 = c3(pb.view(cat16, h16, w16, 128, 0, 128), "model.17", "model.17")
+    conv(l17, "model.18", 3, 2, out=pb.view(cat19, h32, w32, 64, 0, 128), name="model.18")
+    l20 = c3(pb.view(cat19, h32, w32, 128, 0, 128), "model.20", "model.20")
 
     # ---- Detect + decode ----------------------------------------------------------------------------------
     levels = [l14, l17, l20]
