@@ -297,8 +297,17 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 // capped at 128 VGPRs (4 waves) the 24-channel variant spills 14 registers and runs 20 % slower.
 // NOEXP: depthwise-separable block (timm DepthwiseSeparableConv, encoder block 0): no expand conv, the
 // "expanded" map is the input itself (the halo fragments are stored to LDS as they are).
-template <int S, int CP, int PH, int PW, bool NOEXP = false>
+// SP (f32s programs, round 3): the same kernel with its matrix products on v_mfma_f32_16x16x16_f16, split precision.  The
+// f32 variant turned out to be bound by the f32 matrix pipe itself -- v_mfma_f32_16x16x4_f32 takes 32 cycles, four of them
+// per 16-deep K block: 12 k cycles of MFMA issue per patch and SIMD are exactly what block 1.0 measured -- whereas K = 16 is
+// the native depth of the 16x16x16 f16 instruction (4 f16 per lane, the SAME lane / k mapping as four 16x16x4 f32 steps,
+// and hi + lo fragments in the registers one f32 fragment took): 3 x 16 cycles instead of 4 x 32 per K block.  Weights are
+// scaled by a power of two and split when fetched (a.scale_exp / a.scale_pwl = 2^-s undo the scaling), activations are split
+// once per patch / per 16 depthwise channels.
+template <int S, int CP, int PH, int PW, bool NOEXP = false, bool SP = false>
 __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
+    unsigned amax = 0;                         // range guard (pf_common.h): only the SP variant splits anything
+    const unsigned amax_seen = SP ? pf_amax_seen(a.range_slot) : 0u;
     constexpr int PP = PH * PW, MPW = PP / 16;
     constexpr int HH = (PH - 1) * S + 3, HW = (PW - 1) * S + 3, HP = HH * HW;
     constexpr int MH = (HP + 15) / 16, HPP = MH * 16;
@@ -320,6 +329,17 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
     const float* in = a.in + (size_t)b * a.inH * a.inW * a.inLd;
     const int frow = lane & 15, fk = (lane >> 4) * 4;
+    auto split4 = [&](const pf_f32x4& v, float scale, pf_half4& hi, pf_half4& lo, bool track) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float x = v[e] * scale;
+            const pf_half hv = (pf_half)x;
+            hi[e] = hv;
+            lo[e] = (pf_half)(x - (float)hv);
+            if (track) amax = pf_amax(amax, x);
+        }
+    };
+    const float up_exp = 1.f / a.scale_exp, up_pwl = 1.f / a.scale_pwl;     // powers of two: exact
 
     pf_f32x4 xf[MH][KK];
     unsigned inside = 0;
@@ -336,6 +356,14 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
             if (ok && kk * 16 + fk < a.Cin)
                 xf[mt][kk] = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)iy * a.inW + ix) * a.inLd + kk * 16 + fk);
         }
+    }
+    // SP: the halo fragments as f16 hi / lo (they overlay the registers of xf, which is dead afterwards unless NOEXP)
+    pf_half4 xh[SP && !NOEXP ? MH : 1][KK], xl[SP && !NOEXP ? MH : 1][KK];
+    if constexpr (SP && !NOEXP) {
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) split4(xf[mt][kk], 1.f, xh[mt][kk], xl[mt][kk], true);
     }
     pf_f32x4 acc[MPW][MAXNT];
 #pragma unroll
@@ -381,10 +409,22 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
                 *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = xf[mt][0];   // zero outside the image already
             } else {
                 pf_f32x4 e = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (SP) {
 #pragma unroll
-                for (int kk = 0; kk < KK; ++kk)
+                    for (int kk = 0; kk < KK; ++kk) {
+                        pf_half4 wh, wl;
+                        split4(wv[kk], up_exp, wh, wl, false);
+                        e = pf_mfma_16x16x16_f16(wl, xh[mt][kk], e);
+                        e = pf_mfma_16x16x16_f16(wh, xl[mt][kk], e);
+                        e = pf_mfma_16x16x16_f16(wh, xh[mt][kk], e);
+                    }
+                    e *= a.scale_exp;
+                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
+                    for (int kk = 0; kk < KK; ++kk)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
+                }
                 pf_f32x4 o = e + be;
                 pf_act_rh<4>(o, a.act);
                 *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -417,15 +457,30 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MPW; ++mt) {
             const pf_f32x4 d4 = *reinterpret_cast<const pf_f32x4*>(ds + (mt * 16 + frow) * 16 + fk);
+            if constexpr (SP) {
+                pf_half4 dh, dl;
+                split4(d4, 1.f, dh, dl, true);
 #pragma unroll
-            for (int nt = 0; nt < MAXNT; ++nt)
-                if (nt < NTC) {
+                for (int nt = 0; nt < MAXNT; ++nt)
+                    if (nt < NTC) {
+                        pf_half4 ph, pl;
+                        split4(pv[nt], up_pwl, ph, pl, false);
+                        acc[mt][nt] = pf_mfma_16x16x16_f16(pl, dh, acc[mt][nt]);
+                        acc[mt][nt] = pf_mfma_16x16x16_f16(ph, dl, acc[mt][nt]);
+                        acc[mt][nt] = pf_mfma_16x16x16_f16(ph, dh, acc[mt][nt]);
+                    }
+            } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[mt][nt] = pf_mfma_16x16x4_f32(pv[nt][j], d4[j], acc[mt][nt]);
-                }
+                for (int nt = 0; nt < MAXNT; ++nt)
+                    if (nt < NTC) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[mt][nt] = pf_mfma_16x16x4_f32(pv[nt][j], d4[j], acc[mt][nt]);
+                    }
+            }
         }
         fetch_project(mc + 16);
     }
+    if constexpr (SP) pf_amax_commit(a.range_slot, amax, amax_seen);
 #pragma unroll
     for (int mt = 0; mt < MPW; ++mt)
 #pragma unroll
@@ -437,7 +492,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
             const size_t pix = ((size_t)b * a.outH + oy) * a.outW + ox;
             pf_f32x4 v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r] + a.b_pwl[co + r];
+            for (int r = 0; r < 4; ++r) v[r] = (SP ? acc[mt][nt][r] * a.scale_pwl : acc[mt][nt][r]) + a.b_pwl[co + r];
             if (a.res) {
                 const pf_f32x4 rv = *reinterpret_cast<const pf_f32x4*>(a.res + pix * a.resLd + co);
 #pragma unroll

@@ -3,6 +3,7 @@
 // Thin named wrappers over the gfx950 matrix-core and cross-lane builtins so every kernel
 // states which instruction it relies on:
 //   pf_mfma_16x16x32_f16  -> v_mfma_f32_16x16x32_f16  (8 f16 per lane per operand, f32 accumulate)
+//   pf_mfma_16x16x16_f16  -> v_mfma_f32_16x16x16_f16  (4 f16 per lane per operand: K = 16 blocks without zero padding)
 //   pf_mfma_16x16x4_f32   -> v_mfma_f32_16x16x4_f32   (exact f32, verification mode)
 // Fragment layout (cdna_hip_programming.md section 3): operand lane l supplies row/col (l & 15) and
 // k-group (l >> 4); accumulator lane l, register r holds D[4*(l>>4)+r][l&15].
@@ -18,6 +19,10 @@ typedef float pf_f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ pf_f32x4 pf_mfma_16x16x32_f16(pf_half8 a, pf_half8 b, pf_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// v_mfma_f32_16x16x16_f16: 4 f16 per lane per operand (k = 4 * (lane >> 4) .. + 3), same accumulator layout
+__device__ __forceinline__ pf_f32x4 pf_mfma_16x16x16_f16(pf_half4 a, pf_half4 b, pf_f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

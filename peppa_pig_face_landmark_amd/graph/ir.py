@@ -253,6 +253,15 @@ class ProgramBuilder:
         blocks = np.stack([hi.reshape(rows, k // 32, 32), lo.reshape(rows, k // 32, 32)], axis=2)
         return np.ascontiguousarray(blocks), float(2.0 ** (-s))
 
+    def _pow2_unscale(self, w: np.ndarray) -> float:
+        """2^-s for weights the SPLIT flavour of the exact-f32 block kernels scales by 2^s and splits when it fetches them
+        (same rule as _split_rows: the largest magnitude lands in [8192, 16384], so the low halves stay normal f16 numbers);
+        1.0 in f32 / f16 programs, whose kernels use the weights as they are."""
+        if not self.split:
+            return 1.0
+        wmax = float(np.abs(w).max())
+        return 1.0 if wmax == 0.0 else float(2.0 ** (-int(np.floor(np.log2(16384.0 / wmax)))))
+
     def mbconv(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray,
                w_pwl: np.ndarray, b_pwl: np.ndarray, act: str, *, stride: int, pad: int, dil: int = 1,
                res: int = -1, out_name: str = "") -> int:
@@ -279,7 +288,7 @@ class ProgramBuilder:
             bp = np.zeros(coutp); bp[:cout] = b_pwl
             self._op(OP_MBCONV, [x, out, res, self.const_f32(we), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
                                  self.const_f32(wp), self.const_f32(bp), k, stride, pad, dil, ACT[act], mid16, cp, coutp, cout,
-                                 mid16, fbits(1.0), fbits(1.0), 1],
+                                 mid16, fbits(self._pow2_unscale(we)), fbits(self._pow2_unscale(wp)), 1],
                      [self._tb(x), self._tb(res)], [self._tb(out)])
             return out
         midp, cp = _round_up(mid, 32), _round_up(cin, 32)

@@ -39,6 +39,32 @@ inline pf_f32x4 pf_mfma_16x16x32_f16(pf_half8 a, pf_half8 b, pf_f32x4 c) {
     return d;
 }
 
+//   v_mfma_f32_16x16x16_f16 : A lane l = A[i=l&15][k=4*(l>>4)..+3], B lane l = B[k=4*(l>>4)..+3][j=l&15]
+inline pf_f32x4 pf_mfma_16x16x16_f16(pf_half4 a, pf_half4 b, pf_f32x4 c) {
+    struct Pack { pf_half4 a, b; };
+    static_assert(sizeof(Pack) == 16, "pack");
+    pf_emu::WaveState& w = pf_emu::wave_state();
+    const int buf = w.gen & 1;
+    const int l = pf_emu::lane_id();
+    Pack p{a, b};
+    std::memcpy(w.stage[buf][l], &p, sizeof(p));
+    pf_emu::wave_barrier();
+    const int col = l & 15;
+    pf_f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (l >> 4) + r;
+        float acc = c[r];
+        for (int g = 0; g < 4; ++g) {
+            Pack pa, pb;
+            std::memcpy(&pa, w.stage[buf][row + 16 * g], sizeof(Pack));
+            std::memcpy(&pb, w.stage[buf][col + 16 * g], sizeof(Pack));
+            for (int e = 0; e < 4; ++e) acc += (float)pa.a[e] * (float)pb.b[e];
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
 inline pf_f32x4 pf_mfma_16x16x4_f32(float a, float b, pf_f32x4 c) {
     struct Pack { float a, b; };
     pf_emu::WaveState& w = pf_emu::wave_state();
