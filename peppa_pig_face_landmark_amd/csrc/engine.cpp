@@ -19,7 +19,6 @@
 #include "k_mbconv.h"
 #include "k_chain.h"
 #include "k_sepup.h"
-#include "k_hero.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
 #include "k_track.h"
@@ -225,15 +224,6 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
-            // the Student's hero layer: one 16-wave workgroup per CU on 256-pixel tiles, a barrier per kernel row (k_hero.h)
-            const bool wide_ok = a.Npad == 128 && a.N == 128 && a.outCs == 1 && !a.res && !a.fbias && a.store_out && (a.Cpad % 32) == 0 &&
-                                 a.inC == a.Cpad && (a.inLd % 4) == 0 && (a.outLd % 4) == 0 && ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 4096);
-            if (wide_ok) {
-                const dim3 wg(M / 256);
-                if (a.outW == 64) PF_LAUNCH((hero_wide_kernel<64>), wg, dim3(1024), h->stream, a);
-                else if (a.outW == 32) PF_LAUNCH((hero_wide_kernel<32>), wg, dim3(1024), h->stream, a);
-                else PF_LAUNCH((hero_wide_kernel<16>), wg, dim3(1024), h->stream, a);
-            } else
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
             else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);
@@ -810,15 +800,8 @@ void pf_destroy(pf_handle* h) {
     }
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_dbg) {
-        unsigned long long v[48];
+        unsigned long long v[32];
         if (hipMemcpy(v, h->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (v[32 + 3]) {
-                const unsigned long long* q = v + 32;
-                const double steps = (double)q[4] / (double)q[3];
-                fprintf(stderr, "[hero_pipe] per wave and step (cycles): producer patch %.0f dma %.0f wait %.0f | consumer mfma %.0f stores/epilogue %.0f wait %.0f  (%.0f steps/wave)\n",
-                        q[0] / (double)q[3] / steps, q[1] / (double)q[3] / steps, q[2] / (double)q[3] / steps, q[5] / (double)q[8] / steps, q[6] / (double)q[8] / steps,
-                        q[7] / (double)q[8] / steps, steps);
-            }
             for (int k = 0; k < 2; ++k) {
                 const unsigned long long* q = v + 16 * k;
                 if (!q[2]) continue;

@@ -58,7 +58,6 @@ struct ConvGemmArgs {
     // first channel chunk only, 128 = no per-tap barrier; conv_gemm_split_kernel: 16 as above, 256 = operands (pixels AND weights)
     // fetched for the first K step only, 512 = no split / LDS store of the pixel operand.  Tables: profiles/r02_*ablations.md.
     int dbg;
-    unsigned long long* prof;   // dbg & 64: per-role cycle totals of hero_pipe_kernel (ablation build)
 };
 
 template <typename T> struct ConvMma;
