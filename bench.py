@@ -548,11 +548,11 @@ def main():
         try:
             if not have_pil:
                 raise ImportError("PIL not installed: no way to write the JPEG test files")
-            thr = max(1, min(32, (os.cpu_count() or 8) // max(1, lanes)))
+            thr = 4
             jpeg = {"note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
                             "feeds pf_run_frames, one host thread per lane drives decode + pipeline; output bit-identical with libjpeg.  The "
-                            "files carry no restart markers, so their Huffman streams are decoded on host threads (files WITH restart markers "
-                            "in batches of >= 4096 intervals are entropy-decoded on the device: tools/bench_jpeg.py --restart-rows 1)",
+                            "files carry no restart markers: the host threads only strip the byte stuffing, the Huffman stream is decoded on the "
+                            "device as self-synchronising 1024-bit sub-sequences (csrc/k_jpeg.h jpeg_sync_kernel)",
                     "host_threads_per_lane": thr}
             for key, rows in (("no_restart_markers", 0),):
                 total_bytes = state.enable_jpeg_frames(90, rows)
@@ -565,7 +565,7 @@ def main():
                     state.step_jpeg(thr)
                 state.sync()
                 dt = time.perf_counter() - t1
-                state.check()
+                state.check(compare_eager=False)     # (lossy files: their landmarks are not those of the resident frames)
                 jpeg[key] = {"faces_per_s": round(faces_per_step * js / dt, 1), "frames_per_s": round(args.frames * js / dt, 1),
                              "jpeg_MB_per_s": round(total_bytes * js / dt / 1e6, 1), "mean_file_KB": round(total_bytes / args.frames / 1e3, 1),
                              "steps": js}

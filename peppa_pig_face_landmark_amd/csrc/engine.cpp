@@ -741,6 +741,9 @@ static int check_numerics(pf_handle* h) {
     float v;
     memcpy(&v, &h->h_status[2], 4);
     h->h_status[0] = 0;
+    if (code == 3)
+        PF_FAIL(h, "pf_decode_jpeg_batch: the parallel entropy decoder did not synchronise (%d sub-sequence records still changing "
+                   "after the last round): the frames of that batch are invalid; decode it again with PEPPA_JPEG_ENTROPY=host", op);
     PF_FAIL(h, "activation range check failed: input of op %d of program %d has max |x| = %g, %s the range [9.8e-4, 6e4] the "
                "split-precision (f32s) convolutions can represent (outputs were set to NaN); rebuild the program with dtype 'f32'",
             op, slot, (double)v, code == 1 ? "above" : "below");

@@ -360,12 +360,12 @@ const char* jpeg_decode_scans(const unsigned char* d, size_t n, size_t pos, Jpeg
     return nullptr;
 }
 
-// Device entropy decoding applies when the file has restart markers, ONE interleaved scan in frame component order and table ids
-// 0 / 1: copies the scan, the interval offsets and the lookup tables into the frame's pinned region.  Returns false (file untouched)
+// Device entropy decoding applies when the file has ONE interleaved scan in frame component order and table ids 0 / 1 (with or
+// without restart markers): copies the scan, the interval offsets and the lookup tables into the frame's pinned region.  Returns false (file untouched)
 // when the file does not qualify or its markers do not add up -- the host decoder then takes it.
 bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHeader& hd, unsigned char* region, size_t region_cap,
                            JpegFrameDesc* desc, size_t* used_bytes) {
-    if (hd.restart <= 0 || sos + 4 > n || d[sos] != 0xFF || d[sos + 1] != 0xDA) return false;
+    if (sos + 4 > n || d[sos] != 0xFF || d[sos + 1] != 0xDA) return false;
     const size_t len = jpeg_be16(d + sos + 2);
     if (len < 2 || sos + 2 + len > n) return false;
     const unsigned char* s = d + sos + 4;
@@ -379,7 +379,7 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
     if (s[1 + 2 * hd.ncomp] != 0 || s[2 + 2 * hd.ncomp] != 63 || s[3 + 2 * hd.ncomp] != 0) return false;
     const size_t begin = sos + 2 + len;
     const int total_mcus = hd.mcux * hd.mcuy;
-    const int want = (total_mcus + hd.restart - 1) / hd.restart;
+    const int want = hd.restart > 0 ? (total_mcus + hd.restart - 1) / hd.restart : 1;     // no restart markers: one unbroken stream
     if (n - begin + 64 + (size_t)want * 4 + sizeof(JpegGpuTables) + 64 > region_cap) return false;
     // The scan is copied WITHOUT its byte stuffing and without the RSTn markers (offsets in the copied stream): the device threads
     // then refill their bit buffers four bytes at a time, branch-free -- with stuffing in place the 64 lanes of a wave each looped
@@ -419,7 +419,13 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
     }
     desc->scan_off = 0; desc->scan_len = (unsigned)scan_len;
     desc->offs_off = (unsigned)offs_off; desc->n_intervals = (unsigned)offs.size();
-    desc->tables_off = (unsigned)tables_off; desc->restart = (unsigned)hd.restart; desc->pad = 0;
+    desc->tables_off = (unsigned)tables_off; desc->restart = (unsigned)std::max(hd.restart, 0); desc->pad = 0;
+    if (hd.restart <= 0) {                         // decoded as sub-sequences of PF_JPEG_SUBSEQ_BITS bits (k_jpeg.h jpeg_sync_kernel)
+        int bpm = 0;
+        for (int i = 0; i < hd.ncomp; ++i) bpm += hd.c[i].h * hd.c[i].v;
+        if (hd.ncomp > 3 || bpm > 10) return false;
+        desc->n_intervals = (unsigned)std::max<size_t>(1, (scan_len * 8 + PF_JPEG_SUBSEQ_BITS - 1) / PF_JPEG_SUBSEQ_BITS);
+    }
     desc->tdta = 0;
     for (int i = 0; i < hd.ncomp; ++i) desc->tdta |= ((unsigned)hd.c[i].td << i) | ((unsigned)hd.c[i].ta << (4 + i));
     *used_bytes = tables_off + sizeof(JpegGpuTables);
@@ -441,6 +447,7 @@ void JpegState::release() {
     if (d_planes) (void)hipFree(d_planes);
     if (d_quant) (void)hipFree(d_quant);
     if (d_desc) (void)hipFree(d_desc);
+    if (d_sub) (void)hipFree(d_sub);
     *this = JpegState{};
 }
 
@@ -460,7 +467,7 @@ int pf_jpeg_info(const uint8_t* jpeg, size_t bytes, int* height, int* width, int
 
 // n equally shaped JPEGs -> [n][H][W][3] in device memory; the entropy decoding of the files runs on `threads` host threads
 static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, const size_t* sizes, int threads,
-                             int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host, bool final_sync) {
+                             int* height, int* width, const uint8_t** d_bgr, uint8_t* bgr_host, bool final_sync, bool force_host = false) {
     if (n < 1 || !jpegs || !sizes) PF_FAIL(h, "pf_decode_jpeg: bad arguments");
     PF_HIP(h, hipSetDevice(h->device));
     std::vector<JpegHeader> hds((size_t)n);
@@ -523,12 +530,17 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     // Where the Huffman stream is decoded.  A restart interval is one GPU thread, and a GPU thread is slow (a 120-MCU interval of a
     // 1080p file takes ~7 ms): the device wins when the batch offers thousands of intervals (96 files x 68: 11.8 k files/s against
     // 3.6-5.2 k on 16-96 host threads), a single file is faster on one host core (4 ms).  PEPPA_JPEG_ENTROPY=host|device overrides.
-    bool device_entropy = false;
+    // A file without restart markers is cut into 1024-bit sub-sequences that synchronise themselves (k_jpeg.h jpeg_sync_kernel): a
+    // 1080p file offers ~3 500 of them, so that path goes to the device for any batch size.
+    bool device_entropy = hd.restart <= 0;
     if (hd.restart > 0) {
         const long long intervals = (long long)n * ((hd.mcux * hd.mcuy + hd.restart - 1) / hd.restart);
         device_entropy = intervals >= 4096;
     }
     if (const char* e = getenv("PEPPA_JPEG_ENTROPY")) device_entropy = e[0] == 'd';
+    if (force_host) device_entropy = false;
+    int rounds = PF_JPEG_SYNC_ROUNDS;
+    if (const char* e = getenv("PEPPA_JPEG_ROUNDS")) rounds = std::max(1, std::min(PF_JPEG_SYNC_ROUNDS, atoi(e)));      // (tests: force the fallback)
     std::vector<std::atomic<int>> done((size_t)n);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     // workers are pure CPU (a HIP call from a fresh thread pays the runtime's per-thread set-up under its global lock: 60 ms
@@ -584,7 +596,53 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         ProfScope ps(h, "jpeg_unpack");
         PF_LAUNCH(jpeg_unpack_kernel, dim3((unsigned)pf_div_up(hd.total_blocks, 64), (unsigned)n), dim3(64), h->stream, ua);
     }
-    if (on_device) {
+    int on_sub = 0, max_sub = 0;
+    for (int f = 0; f < n; ++f)
+        if (descs[f].n_intervals && descs[f].restart == 0) { ++on_sub; max_sub = std::max(max_sub, (int)descs[f].n_intervals); }
+    if (on_sub) {
+        const size_t words = (size_t)n * max_sub * 5 + 16;
+        if (s.sub_cap < words) {
+            PF_HIP(h, hipStreamSynchronize(h->stream));
+            if (s.d_sub) (void)hipFree(s.d_sub);
+            s.d_sub = nullptr; s.sub_cap = 0;
+            PF_HIP(h, hipMalloc((void**)&s.d_sub, words * sizeof(unsigned)));
+            s.sub_cap = words;
+        }
+        JpegSubseqArgs qa{};
+        qa.pack = sl.d_pack; qa.frame_pack_bytes = frame_pack; qa.desc = s.d_desc; qa.coef = s.d_coef; qa.blocks = hd.total_blocks;
+        qa.ncomp = hd.ncomp; qa.mcux = hd.mcux; qa.total_mcus = hd.mcux * hd.mcuy; qa.bpm = 0;
+        for (int c = 0; c < hd.ncomp; ++c) {
+            qa.ch[c] = hd.c[c].h; qa.cv[c] = hd.c[c].v; qa.cblock0[c] = hd.c[c].block0; qa.cbw[c] = hd.c[c].bw;
+            qa.bpm += hd.c[c].h * hd.c[c].v;
+        }
+        const size_t per = (size_t)n * max_sub;
+        qa.exit_p = s.d_sub; qa.exit_s = s.d_sub + per; qa.nblk = s.d_sub + 2 * per; qa.blk0 = s.d_sub + 3 * per; qa.stamp = s.d_sub + 4 * per;
+        qa.changed = s.d_sub + 5 * per;
+        qa.max_sub = max_sub;
+        ProfScope ps(h, "jpeg_subseq");
+        PF_HIP(h, hipMemsetAsync(qa.changed, 0, 16 * sizeof(unsigned), h->stream));
+        // (the write pass stores only what it decodes: zero the blocks first)
+        if (on_sub == n) {
+            PF_HIP(h, hipMemsetAsync(s.d_coef, 0, coef_bytes, h->stream));
+        } else {
+            for (int f = 0; f < n; ++f)
+                if (descs[f].n_intervals && descs[f].restart == 0)
+                    PF_HIP(h, hipMemsetAsync(s.d_coef + (size_t)f * hd.total_blocks * 64, 0, (size_t)hd.total_blocks * 64 * sizeof(short), h->stream));
+        }
+        const dim3 sg((unsigned)pf_div_up(max_sub, 64), (unsigned)n);
+        qa.round = 0;
+        PF_LAUNCH(jpeg_sync_kernel<0>, sg, dim3(64), h->stream, qa);
+        for (int r = 1; r <= rounds; ++r) {
+            qa.round = r;
+            PF_LAUNCH(jpeg_sync_kernel<1>, sg, dim3(64), h->stream, qa);
+        }
+        PF_LAUNCH(jpeg_subseq_scan_kernel, dim3((unsigned)n), dim3(256), h->stream, qa);
+        qa.round = -1;
+        PF_LAUNCH(jpeg_sync_kernel<2>, sg, dim3(64), h->stream, qa);
+        PF_LAUNCH(jpeg_dc_prefix_kernel, dim3((unsigned)hd.ncomp, (unsigned)n), dim3(256), h->stream, qa);
+        PF_LAUNCH(jpeg_subseq_verdict_kernel, dim3(1), dim3(1), h->stream, qa.changed + rounds, h->h_status);
+    }
+    if (on_device > on_sub) {
         // (every block of such a frame is written whole by the kernel: an interleaved scan covers the MCU-padded planes)
         JpegHuffArgs ha{};
         ha.pack = sl.d_pack; ha.frame_pack_bytes = frame_pack; ha.desc = s.d_desc; ha.coef = s.d_coef; ha.blocks = hd.total_blocks;
@@ -629,7 +687,14 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
     }
     if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, sl.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
-    if (final_sync || bgr_host) PF_HIP(h, hipStreamSynchronize(h->stream));
+    if (final_sync || bgr_host) {
+        PF_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->h_status && h->h_status[0] == 3 && !force_host) {     // the sub-sequence decoder did not settle: the host decodes this batch
+            h->h_status[0] = 0;
+            return jpeg_decode_batch(h, n, jpegs, sizes, threads, height, width, d_bgr, bgr_host, final_sync, true);
+        }
+        if (check_numerics(h)) return 1;
+    }
     if (getenv("PEPPA_JPEG_TIMING")) {
         const auto t_end = std::chrono::steady_clock::now();
         size_t up = 0;

@@ -34,6 +34,8 @@ struct JpegState {
     size_t quant_cap = 0;
     struct JpegFrameDesc* d_desc = nullptr;   // [frames]
     size_t desc_cap = 0;
+    unsigned* d_sub = nullptr;            // sub-sequence records of the self-synchronising decode (jpeg_sync_kernel)
+    size_t sub_cap = 0;                   // in words
     void release();
 };
 
@@ -151,6 +153,7 @@ __device__ __forceinline__ int pf_jpeg_extend(int v, int s) { return s == 0 ? 0 
 __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
     const unsigned char* region = a.pack + (size_t)blockIdx.y * a.frame_pack_bytes;
     const JpegFrameDesc d = a.desc[blockIdx.y];
+    if (d.restart == 0) return;                           // no restart markers: jpeg_sync_kernel's frame
     const int iv = blockIdx.x * 64 + threadIdx.x;
     const unsigned* offs = reinterpret_cast<const unsigned*>(region + d.offs_off);
     // the file's lookup tables and the zigzag map into LDS: every lookup is on the thread's critical path, from global / constant
@@ -230,6 +233,266 @@ __global__ __launch_bounds__(64) void jpeg_huffman_kernel(JpegHuffArgs a) {
             }
         }
     }
+}
+
+// ---- entropy decoding on the device, for files WITHOUT restart markers: self-synchronising sub-sequence decode --------------
+// An ordinary camera file is one unbroken Huffman stream, but Huffman codes re-synchronise: a decoder started at an arbitrary bit
+// soon falls into step with the true symbol boundaries.  The (byte-unstuffed) scan is cut into sub-sequences of PF_JPEG_SUBSEQ_BITS
+// bits, one thread each:
+//   1. jpeg_sync_kernel, first pass: thread i decodes sub-sequence i from the GUESS "a block starts at my first bit" and records
+//      where it leaves: (bit position of the first symbol past its end, block of the MCU, coefficient index) and how many blocks
+//      it completed.  Thread 0's guess is the truth.
+//   2. jpeg_sync_kernel, rounds: thread i takes the recorded exit of sub-sequence i - 1 as its entry, decodes again and replaces
+//      its record if it differs (counting the change).  A thread works only if its predecessor's record changed in the round
+//      before, so after the first round almost nobody does.  When a round changes nothing every record is consistent with its
+//      predecessor, hence -- by induction from thread 0 -- correct.  The host queues a fixed number of rounds and the verdict
+//      (changes in the LAST round) travels with the engine's status word: no silent garbage if a stream needed more.
+//   3. jpeg_subseq_scan_kernel: exclusive prefix sum of the completed-block counts = each sub-sequence's first block ordinal.
+//   4. jpeg_sync_kernel, write pass: decode once more from the now-known entry and write the coefficients (DC as the raw
+//      difference) into the dense, pre-zeroed block buffer; 5. jpeg_dc_prefix_kernel turns the differences into DC values (a
+//      prefix sum per component in scan order -- without restart markers the prediction runs through the whole scan).
+// Same tables, bit reader and symbol decoding as jpeg_huffman_kernel; output bit-identical with the host decoder (ITU T.81 F.2).
+#define PF_JPEG_SUBSEQ_BITS 1024
+#define PF_JPEG_SYNC_ROUNDS 10
+#define PF_JPEG_WALK 64              // sub-sequences a thread whose record changed walks on through in one round
+
+struct JpegSubseqArgs {
+    const unsigned char* pack;            // [frame] regions of frame_pack_bytes
+    size_t frame_pack_bytes;
+    const JpegFrameDesc* desc;            // [frame]; restart == 0 marks a frame decoded this way, n_intervals = its sub-sequences
+    short* coef;                          // [frame][blocks][64], zeroed
+    int blocks;                           // per frame
+    int ncomp, mcux, total_mcus, bpm;     // bpm = blocks per MCU
+    int ch[3], cv[3], cblock0[3], cbw[3];
+    unsigned* exit_p;                     // [frame][max_sub] bit position of the first symbol past the sub-sequence
+    unsigned* exit_s;                     // [frame][max_sub] (block of the MCU << 8) | coefficient index
+    unsigned* nblk;                       // [frame][max_sub] blocks completed inside the sub-sequence
+    unsigned* blk0;                       // [frame][max_sub] first block ordinal (exclusive prefix sum of nblk)
+    unsigned* stamp;                      // [frame][max_sub] round in which the record last changed
+    unsigned* changed;                    // [PF_JPEG_SYNC_ROUNDS + 1] records changed per round (all frames)
+    int max_sub;
+    int round;                            // 0 = first pass, 1.. = synchronisation rounds, -1 = write pass
+};
+
+template <int MODE>                       // 0 first pass, 1 synchronisation round, 2 write pass
+__global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
+    const unsigned char* region = a.pack + (size_t)blockIdx.y * a.frame_pack_bytes;
+    const JpegFrameDesc d = a.desc[blockIdx.y];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    __shared__ JpegGpuTables tables;
+    __shared__ unsigned char zz[64];
+    constexpr int BLK_STRIDE = 72;                        // shorts per thread, as in jpeg_huffman_kernel
+    __shared__ __attribute__((aligned(16))) short blkbuf[MODE == 2 ? 64 * BLK_STRIDE : 8];
+    if (d.restart != 0 || blockIdx.x * 64 >= (int)d.n_intervals) return;      // (whole workgroup: not a frame / tile of this path)
+    zz[threadIdx.x] = (unsigned char)pf_jpeg_zigzag(threadIdx.x);
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(region + d.tables_off);
+        unsigned* dst = reinterpret_cast<unsigned*>(&tables);
+        for (unsigned k = threadIdx.x; k < sizeof(JpegGpuTables) / 4; k += 64) dst[k] = src[k];
+    }
+    __syncthreads();
+    if (i >= (int)d.n_intervals) return;
+    const size_t rec = (size_t)blockIdx.y * a.max_sub + i;
+    if (MODE == 1 && (i == 0 || a.stamp[rec - 1] != (unsigned)(a.round - 1))) return;   // predecessor unchanged: so is this record
+    const JpegGpuTables* t = &tables;
+    const unsigned total_bits = d.scan_len * 8u;
+    const unsigned end_bits = min((unsigned)(i + 1) * PF_JPEG_SUBSEQ_BITS, total_bits);      // (write pass)
+    unsigned p0 = (unsigned)i * PF_JPEG_SUBSEQ_BITS;
+    int bi = 0, z = 0;
+    if (MODE != 0 && i > 0) {
+        p0 = a.exit_p[rec - 1];
+        const unsigned st = a.exit_s[rec - 1];
+        bi = (int)(st >> 8);
+        z = (int)(st & 255u);
+    }
+    // block of the MCU -> component and position inside the MCU
+    int comp_of[10], v_of[10], h_of[10];
+    {
+        int j = 0;
+        for (int c = 0; c < a.ncomp; ++c)
+            for (int q = 0; q < a.ch[c] * a.cv[c] && j < 10; ++q, ++j) { comp_of[j] = c; v_of[j] = q / a.ch[c]; h_of[j] = q - v_of[j] * a.ch[c]; }
+    }
+    PfJpegBits br;
+    br.base = region;
+    br.pos = d.scan_off + (p0 >> 3);
+    br.limit = d.scan_off + d.scan_len + 8;              // (staged with 32 zero bytes behind the scan)
+    br.chunk = 0; br.ahead = 0; br.chunk_at = 0xFFFFFFF0u;
+    br.acc = 0; br.n = 0;
+    pf_jpeg_fill(br);
+    br.n -= (int)(p0 & 7u);
+    // bits consumed so far = 8 * (bytes taken into the accumulator) - bits still in it (the reader never runs past `limit` here:
+    // decoding stops at total_bits, at most 8 + 32 bits before it)
+    auto bitpos = [&]() { return (br.pos - d.scan_off) * 8u - (unsigned)br.n; };
+    unsigned done_blocks = 0;
+    unsigned ordinal = MODE == 2 ? a.blk0[rec] : 0u;
+    short* coef = a.coef + (size_t)blockIdx.y * a.blocks * 64;
+    short* mine = blkbuf + (MODE == 2 ? threadIdx.x * BLK_STRIDE : 0);
+    bool own = z == 0;                                    // this thread decodes the block from its DC on: it may store it whole
+    short* blk = nullptr;
+    auto block_ptr = [&](unsigned q) -> short* {
+        const int m = (int)(q / (unsigned)a.bpm), j = (int)(q - (unsigned)m * a.bpm);
+        const int my = m / a.mcux, mx = m - my * a.mcux, c = comp_of[j];
+        return coef + ((size_t)a.cblock0[c] + (size_t)(my * a.cv[c] + v_of[j]) * a.cbw[c] + (mx * a.ch[c] + h_of[j])) * 64;
+    };
+    if (MODE == 2) {
+        if (ordinal < (unsigned)a.total_mcus * a.bpm) blk = block_ptr(ordinal);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(mine)[k] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned total_blocks = (unsigned)a.total_mcus * a.bpm;
+    auto decode_until = [&](unsigned stop_bits) {
+    while (bitpos() < stop_bits && (MODE != 2 || ordinal < total_blocks)) {
+        const int c = comp_of[bi];
+        pf_jpeg_fill(br);
+        if (z == 0) {
+            const int s = pf_jpeg_huff(br, t, (d.tdta >> c) & 1);
+            const int sb = s > 15 ? 15 : s;
+            pf_jpeg_fill(br);
+            const int diff = sb ? pf_jpeg_extend(pf_jpeg_peek(br, sb), sb) : 0;
+            br.n -= sb;
+            if (MODE == 2) mine[0] = (short)diff;
+            z = 1;
+        } else {
+            const int ta = 2 + ((d.tdta >> (4 + c)) & 1);
+            const int fa = t->fast_ac[ta][pf_jpeg_peek(br, 9)];
+            int r, val = 0;
+            bool coefficient = true;
+            if (fa) {
+                br.n -= fa & 15;
+                r = (fa >> 4) & 15;
+                val = fa >> 8;
+            } else {
+                const int rs = pf_jpeg_huff(br, t, ta);
+                const int sz = rs & 15;
+                r = rs >> 4;
+                if (sz == 0) {
+                    coefficient = false;
+                    if (r != 15) z = 64; else z += 16;   // end of block / sixteen zeros
+                } else {
+                    val = pf_jpeg_extend(pf_jpeg_peek(br, sz), sz);
+                    br.n -= sz;
+                }
+            }
+            if (coefficient) {
+                z += r;
+                if (z <= 63) {
+                    if (MODE == 2) {
+                        if (own) mine[zz[z]] = (short)val;
+                        else if (blk) blk[zz[z]] = (short)val;       // a block another thread began: only what is decoded here
+                    }
+                    ++z;
+                } else {
+                    z = 64;                                // a run past the block: the host decoder ends the block here too
+                }
+            }
+        }
+        if (z >= 64) {                                    // block complete
+            if (MODE == 2) {
+                if (own) {
+                    if (blk) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(blk)[k] = reinterpret_cast<const pf_f32x4*>(mine)[k];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(mine)[k] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                ++ordinal;
+                blk = ordinal < total_blocks ? block_ptr(ordinal) : nullptr;
+                own = true;
+            }
+            ++done_blocks;
+            z = 0;
+            bi = bi + 1 == a.bpm ? 0 : bi + 1;
+        }
+    }
+    };
+    if (MODE == 2) {
+        decode_until(end_bits);
+        // the block still open at the exit continues in the next sub-sequence: hand over what was decoded here, entry by entry
+        if (own && z > 0 && blk) {
+            for (int k = 0; k < 64; ++k)
+                if (mine[k]) blk[k] = mine[k];
+        }
+        return;
+    }
+    // A thread whose record turns out wrong walks on into the following sub-sequences (its exit is their better entry) until it
+    // meets a record that agrees -- otherwise a stretch that does not re-synchronise (long blocks without end-of-block codes:
+    // quality-100 noise) would move one sub-sequence per round.  Records it rewrites carry this round's stamp, so their successors
+    // check themselves in the next round; whichever of two racing writers wins, the loser's successor is marked too.
+    int cur = i;
+    for (int walked = 0;; ++walked) {
+        const size_t rc = (size_t)blockIdx.y * a.max_sub + cur;
+        done_blocks = 0;
+        decode_until(min((unsigned)(cur + 1) * PF_JPEG_SUBSEQ_BITS, total_bits));
+        const unsigned ep = bitpos(), es = ((unsigned)bi << 8) | (unsigned)z;
+        if (MODE == 1 && a.exit_p[rc] == ep && a.exit_s[rc] == es && a.nblk[rc] == done_blocks) break;
+        a.exit_p[rc] = ep;
+        a.exit_s[rc] = es;
+        a.nblk[rc] = done_blocks;
+        a.stamp[rc] = (unsigned)a.round;
+        if (MODE == 1) atomicAdd(a.changed + a.round, 1u);
+        if (MODE == 0 || walked + 1 >= PF_JPEG_WALK || cur + 1 >= (int)d.n_intervals) break;
+        ++cur;
+    }
+}
+
+// exclusive prefix sum of the completed-block counts of one frame's sub-sequences (one workgroup per frame)
+__global__ __launch_bounds__(256) void jpeg_subseq_scan_kernel(JpegSubseqArgs a) {
+    const JpegFrameDesc d = a.desc[blockIdx.x];
+    if (d.restart != 0 || d.n_intervals == 0) return;
+    __shared__ unsigned part[256];
+    const int n = (int)d.n_intervals, t = threadIdx.x;
+    const int per = (n + 255) / 256;
+    const size_t base = (size_t)blockIdx.x * a.max_sub;
+    unsigned sum = 0;
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) sum += a.nblk[base + k];
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        unsigned run = 0;
+        for (int k = 0; k < 256; ++k) { const unsigned v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    unsigned run = part[t];
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) { a.blk0[base + k] = run; run += a.nblk[base + k]; }
+}
+
+// DC differences -> DC values: prefix sum over a component's blocks in scan order (one workgroup per (component, frame))
+__global__ __launch_bounds__(256) void jpeg_dc_prefix_kernel(JpegSubseqArgs a) {
+    const JpegFrameDesc d = a.desc[blockIdx.y];
+    const int c = blockIdx.x;
+    if (d.restart != 0 || d.n_intervals == 0 || c >= a.ncomp) return;
+    __shared__ int part[256];
+    const int nb = a.ch[c] * a.cv[c];
+    const int n = a.total_mcus * nb, t = threadIdx.x;
+    const int per = (n + 255) / 256;
+    short* coef = a.coef + (size_t)blockIdx.y * a.blocks * 64;
+    auto dc_of = [&](int k) -> short* {
+        const int m = k / nb, r = k - m * nb;
+        const int v = r / a.ch[c], hh = r - v * a.ch[c];
+        const int my = m / a.mcux, mx = m - my * a.mcux;
+        return coef + ((size_t)a.cblock0[c] + (size_t)(my * a.cv[c] + v) * a.cbw[c] + (mx * a.ch[c] + hh)) * 64;
+    };
+    int sum = 0;
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) sum += *dc_of(k);
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 0; k < 256; ++k) { const int v = part[k]; part[k] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int k = t * per; k < min(n, (t + 1) * per); ++k) {
+        short* p = dc_of(k);
+        run += *p;
+        *p = (short)run;
+    }
+}
+
+// a stream that needed more rounds than were queued must not pass silently: code 3 in the engine's status word
+__global__ void jpeg_subseq_verdict_kernel(const unsigned* changed_last, int* status) {
+    if (*changed_last != 0 && status[0] == 0) { status[1] = (int)*changed_last; status[0] = 3; }
 }
 
 struct JpegIdctArgs {

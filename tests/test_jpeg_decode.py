@@ -103,6 +103,33 @@ def _check_cases(eng):
     names = list(eng.profile_fetch())
     assert "jpeg_huffman" in names, names
     eng.profile_enable(False)
+    # files WITHOUT restart markers (what cameras write): the stream is cut into 1024-bit sub-sequences that synchronise themselves
+    # on the device (csrc/k_jpeg.h jpeg_sync_kernel); quality 100 noise has 64-coefficient blocks without end-of-block codes, the
+    # slowest case to synchronise (threads walk on through the following sub-sequences)
+    os.environ.pop("PEPPA_JPEG_ENTROPY", None)
+    eng.profile_enable(True)
+    eng.profile_fetch()
+    for (h, w), kw in (((120, 160), dict(quality=100, subsampling=2)), ((64, 64), dict(quality=100, subsampling=0)),
+                       ((97, 131), dict(quality=92, subsampling=1)), ((72, 104), dict(quality=30, subsampling=2))):
+        data = _encode(_image(h, w, seed=3 * h + w), **kw)
+        assert b"\xff\xdd" not in data
+        _, _, _, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data)), (h, w, kw)
+    names = list(eng.profile_fetch())
+    assert "jpeg_subseq" in names and "jpeg_unpack" not in names, names
+    # a stream that needs more rounds than were queued is NOT passed on: the synchronous call falls back to the host decoder
+    os.environ["PEPPA_JPEG_ROUNDS"] = "1"
+    data = _encode(_image(120, 160, seed=520), quality=100, subsampling=2)
+    _, _, _, got = eng.decode_jpeg(data)
+    assert np.array_equal(got, _pil_decode(data))
+    assert "jpeg_unpack" in list(eng.profile_fetch())
+    # ... and the asynchronous batch call reports it at the next synchronisation
+    eng.decode_jpeg_batch([data, data], threads=1)
+    with pytest.raises(_native.PeppaHipError, match="did not synchronise"):
+        eng.sync()
+    os.environ.pop("PEPPA_JPEG_ROUNDS", None)
+    eng.profile_enable(False)
+    os.environ["PEPPA_JPEG_ENTROPY"] = "device"
     # a batch that mixes both kinds: each file takes its own route
     imgs = [_image(48, 80, seed=60 + i) for i in range(4)]
     files = [_encode(im, quality=85, subsampling=2, **(dict(restart_marker_rows=1) if i % 2 else {})) for i, im in enumerate(imgs)]
