@@ -147,10 +147,13 @@ int pf_set_frame(pf_handle* h, const uint8_t* bgr, int mem, int height, int widt
 int pf_forget_frames(pf_handle* h);
 
 /* Frame ingest: cv2.imread(path) for JPEG files (demo.py:76) without the host-side decode and the
- * upload of a 6 MB frame.  The entropy-coded scan is decoded on the host (a serial bit stream, ~0.1 byte per pixel); the
- * 16-bit coefficient blocks go to the device through page-locked memory and dequantisation, inverse DCT, chroma upsampling
- * and YCbCr->BGR run as kernels, bit-identical with libjpeg(-turbo)'s default decoder (JDCT_ISLOW, fancy upsampling), i.e.
- * with what cv2.imread returns.  The frame (packed BGR, 3*width bytes per row) stays in device memory owned by the handle until
+ * upload of a 6 MB frame.  Single-scan baseline files -- what cameras and cv2.imwrite produce -- are entropy-decoded on the
+ * DEVICE: the host strips the byte stuffing, the Huffman stream (~0.1 byte per pixel) crosses PCIe and is decoded as
+ * self-synchronising 1024-bit sub-sequences (or one thread per restart interval when the file carries restart markers, see
+ * below).  Other files (several scans, table ids above 1, tiny images) are Huffman-decoded on the host and their 16-bit
+ * coefficient records go up through page-locked memory.  Dequantisation, inverse DCT, chroma upsampling and YCbCr->BGR run as
+ * kernels either way, bit-identical with libjpeg(-turbo)'s default decoder (JDCT_ISLOW, fancy upsampling), i.e. with what
+ * cv2.imread returns.  A stream whose sub-sequences do not settle within the queued rounds is decoded again on the host.  The frame (packed BGR, 3*width bytes per row) stays in device memory owned by the handle until
  * the decode after the next one; *d_bgr is that pointer -- hand it to pf_set_frame / pf_detect / pf_landmarks / pf_run_frames /
  * pf_track_frame with mem = PF_MEM_DEVICE.  bgr_host (may be NULL): host copy for drawing, height*width*3 bytes (sizes from
  * pf_jpeg_info).  Supported: 8-bit baseline / extended-sequential Huffman JPEG, greyscale or YCbCr 4:4:4 / 4:2:2 / 4:2:0,
@@ -163,7 +166,10 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
  * pf_run_frames(mem = PF_MEM_DEVICE): the files' Huffman streams are decoded on `threads` host threads (one file per task), the
  * device stages run once over the whole batch.  Files that carry restart markers (one interleaved scan, table ids 0 / 1) in batches
  * of >= 4096 restart intervals skip the host Huffman loop: one device thread per interval decodes the stream, and only the
- * compressed scan crosses PCIe (PEPPA_JPEG_ENTROPY=host|device overrides the choice).  Asynchronous like pf_run_frames: the frames are valid in the order of the
+ * compressed scan crosses PCIe; files WITHOUT restart markers always take the device's sub-sequence decoder
+ * (PEPPA_JPEG_ENTROPY=host|device overrides either choice).  If that decoder does not settle, this asynchronous call cannot decode
+ * again by itself: the next synchronising call on the handle fails with "did not synchronise" and the batch has to be resubmitted
+ * with PEPPA_JPEG_ENTROPY=host (ordinary photographs settle in the first round).  Asynchronous like pf_run_frames: the frames are valid in the order of the
  * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets
  * alternate, so the pointer of call k stays valid until call k + 2 and the host work of call k + 1 overlaps the pipeline still
  * running on the frames of call k. */
