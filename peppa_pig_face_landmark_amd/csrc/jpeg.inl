@@ -619,7 +619,6 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         qa.exit_p = s.d_sub; qa.exit_s = s.d_sub + per; qa.nblk = s.d_sub + 2 * per; qa.blk0 = s.d_sub + 3 * per; qa.stamp = s.d_sub + 4 * per;
         qa.changed = s.d_sub + 5 * per;
         qa.max_sub = max_sub;
-        ProfScope ps(h, "jpeg_subseq");
         PF_HIP(h, hipMemsetAsync(qa.changed, 0, 16 * sizeof(unsigned), h->stream));
         // (the write pass stores only what it decodes: zero the blocks first)
         if (on_sub == n) {
@@ -630,17 +629,23 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
                     PF_HIP(h, hipMemsetAsync(s.d_coef + (size_t)f * hd.total_blocks * 64, 0, (size_t)hd.total_blocks * 64 * sizeof(short), h->stream));
         }
         const dim3 sg((unsigned)pf_div_up(max_sub, 64), (unsigned)n);
-        qa.round = 0;
-        PF_LAUNCH(jpeg_sync_kernel<0>, sg, dim3(64), h->stream, qa);
-        for (int r = 1; r <= rounds; ++r) {
-            qa.round = r;
-            PF_LAUNCH(jpeg_sync_kernel<1>, sg, dim3(64), h->stream, qa);
+        {
+            ProfScope ps(h, "jpeg_subseq");              // first pass + synchronisation rounds + block-ordinal scan
+            qa.round = 0;
+            PF_LAUNCH(jpeg_sync_kernel<0>, sg, dim3(64), h->stream, qa);
+            for (int r = 1; r <= rounds; ++r) {
+                qa.round = r;
+                PF_LAUNCH(jpeg_sync_kernel<1>, sg, dim3(64), h->stream, qa);
+            }
+            PF_LAUNCH(jpeg_subseq_scan_kernel, dim3((unsigned)n), dim3(256), h->stream, qa);
         }
-        PF_LAUNCH(jpeg_subseq_scan_kernel, dim3((unsigned)n), dim3(256), h->stream, qa);
-        qa.round = -1;
-        PF_LAUNCH(jpeg_sync_kernel<2>, sg, dim3(64), h->stream, qa);
-        PF_LAUNCH(jpeg_dc_prefix_kernel, dim3((unsigned)hd.ncomp, (unsigned)n), dim3(256), h->stream, qa);
-        PF_LAUNCH(jpeg_subseq_verdict_kernel, dim3(1), dim3(1), h->stream, qa.changed + rounds, h->h_status);
+        {
+            ProfScope ps(h, "jpeg_subseq_write");        // write pass + DC prefix + verdict
+            qa.round = -1;
+            PF_LAUNCH(jpeg_sync_kernel<2>, sg, dim3(64), h->stream, qa);
+            PF_LAUNCH(jpeg_dc_prefix_kernel, dim3((unsigned)hd.ncomp, (unsigned)n), dim3(256), h->stream, qa);
+            PF_LAUNCH(jpeg_subseq_verdict_kernel, dim3(1), dim3(1), h->stream, qa.changed + rounds, h->h_status);
+        }
     }
     if (on_device > on_sub) {
         // (every block of such a frame is written whole by the kernel: an interleaved scan covers the MCU-padded planes)

@@ -284,6 +284,15 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
     constexpr int BLK_STRIDE = 72;                        // shorts per thread, as in jpeg_huffman_kernel
     __shared__ __attribute__((aligned(16))) short blkbuf[MODE == 2 ? 64 * BLK_STRIDE : 8];
     if (d.restart != 0 || blockIdx.x * 64 >= (int)d.n_intervals) return;      // (whole workgroup: not a frame / tile of this path)
+    if (MODE == 1) {                                      // nobody's predecessor changed in the round before: nothing to load tables for
+        const bool dirty = i > 0 && i < (int)d.n_intervals && a.stamp[(size_t)blockIdx.y * a.max_sub + i - 1] == (unsigned)(a.round - 1);
+        __shared__ int any_dirty;
+        if (threadIdx.x == 0) any_dirty = 0;
+        __syncthreads();
+        if (dirty) any_dirty = 1;
+        __syncthreads();
+        if (!any_dirty) return;
+    }
     zz[threadIdx.x] = (unsigned char)pf_jpeg_zigzag(threadIdx.x);
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(region + d.tables_off);
@@ -342,48 +351,33 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
     const unsigned total_blocks = (unsigned)a.total_mcus * a.bpm;
     auto decode_until = [&](unsigned stop_bits) {
     while (bitpos() < stop_bits && (MODE != 2 || ordinal < total_blocks)) {
+        // ONE symbol per iteration, the same instruction sequence for the DC difference and for an AC (run, size) symbol: the 64
+        // lanes of a wave are at unrelated places of their blocks, and separate DC / AC / fast-path branches made the wave pay
+        // for every path on every step
         const int c = comp_of[bi];
-        pf_jpeg_fill(br);
-        if (z == 0) {
-            const int s = pf_jpeg_huff(br, t, (d.tdta >> c) & 1);
-            const int sb = s > 15 ? 15 : s;
-            pf_jpeg_fill(br);
-            const int diff = sb ? pf_jpeg_extend(pf_jpeg_peek(br, sb), sb) : 0;
-            br.n -= sb;
-            if (MODE == 2) mine[0] = (short)diff;
+        pf_jpeg_fill(br);                                 // > 32 bits: a code (<= 16) and its magnitude bits (<= 15)
+        const bool dc = z == 0;
+        const int sym = pf_jpeg_huff(br, t, dc ? (int)((d.tdta >> c) & 1u) : 2 + (int)((d.tdta >> (4 + c)) & 1u));
+        const int sz = dc ? (sym > 15 ? 15 : sym) : (sym & 15);
+        const int r = dc ? 0 : (sym >> 4);
+        const int raw = pf_jpeg_peek(br, sz ? sz : 1);
+        const int val = sz ? pf_jpeg_extend(raw, sz) : 0;
+        br.n -= sz;
+        if (dc) {
+            if (MODE == 2) mine[0] = (short)val;          // (a thread that meets a DC owns the block)
             z = 1;
+        } else if (sz == 0) {
+            z = r == 15 ? z + 16 : 64;                    // sixteen zeros / end of block
         } else {
-            const int ta = 2 + ((d.tdta >> (4 + c)) & 1);
-            const int fa = t->fast_ac[ta][pf_jpeg_peek(br, 9)];
-            int r, val = 0;
-            bool coefficient = true;
-            if (fa) {
-                br.n -= fa & 15;
-                r = (fa >> 4) & 15;
-                val = fa >> 8;
+            z += r;
+            if (z <= 63) {
+                if (MODE == 2) {
+                    if (own) mine[zz[z]] = (short)val;
+                    else if (blk) blk[zz[z]] = (short)val;           // a block another thread began: only what is decoded here
+                }
+                ++z;
             } else {
-                const int rs = pf_jpeg_huff(br, t, ta);
-                const int sz = rs & 15;
-                r = rs >> 4;
-                if (sz == 0) {
-                    coefficient = false;
-                    if (r != 15) z = 64; else z += 16;   // end of block / sixteen zeros
-                } else {
-                    val = pf_jpeg_extend(pf_jpeg_peek(br, sz), sz);
-                    br.n -= sz;
-                }
-            }
-            if (coefficient) {
-                z += r;
-                if (z <= 63) {
-                    if (MODE == 2) {
-                        if (own) mine[zz[z]] = (short)val;
-                        else if (blk) blk[zz[z]] = (short)val;       // a block another thread began: only what is decoded here
-                    }
-                    ++z;
-                } else {
-                    z = 64;                                // a run past the block: the host decoder ends the block here too
-                }
+                z = 64;                                   // a run past the block: the host decoder ends the block here too
             }
         }
         if (z >= 64) {                                    // block complete
@@ -431,7 +425,9 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
         a.nblk[rc] = done_blocks;
         a.stamp[rc] = (unsigned)a.round;
         if (MODE == 1) atomicAdd(a.changed + a.round, 1u);
-        if (MODE == 0 || walked + 1 >= PF_JPEG_WALK || cur + 1 >= (int)d.n_intervals) break;
+        // (round 1: every thread re-decodes anyway, and round 2 re-checks the successors of what changed -- a lane that walked would
+        //  only stretch its wave)
+        if (MODE == 0 || a.round == 1 || walked + 1 >= PF_JPEG_WALK || cur + 1 >= (int)d.n_intervals) break;
         ++cur;
     }
 }
