@@ -38,7 +38,7 @@ GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstre
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
-PMC_SQ_PROFILE = "r02_run5_pmc_sq_hero_and_expdw.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel
+PMC_SQ_PROFILE = "r03_run30_pmc_sq_hero_head.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel (score head fused)
 HERO_TAG = "conv3x3_argmax_c128_n128_64x64"   # up2.conv2 (model.py:165-172: 40.7 % of all MACs) with the hm score head in its epilogue (f32s programs)
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
 # algorithmic FLOPs per face of the other dense kernels of the Student (MACs x 2, model.py line ranges in DESIGN.md 5)
