@@ -38,13 +38,12 @@ GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstre
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
-PMC_SQ_PROFILE = "r03_run30_pmc_sq_hero_head.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel (score head fused)
-HERO_TAG = "conv3x3_argmax_c128_n128_64x64"   # up2.conv2 (model.py:165-172: 40.7 % of all MACs) with the hm score head in its epilogue (f32s programs)
+PMC_SQ_PROFILE = "r02_run5_pmc_sq_hero_and_expdw.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel
+HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
 # algorithmic FLOPs per face of the other dense kernels of the Student (MACs x 2, model.py line ranges in DESIGN.md 5)
 DENSE_FLOP_PER_FACE = {
     "conv3x3_c128_n128_64x64": 2.0 * 4096 * 128 * 128 * 9,
-    "conv3x3_argmax_c128_n128_64x64": 2.0 * 4096 * 128 * (128 * 9 + 98),    # + the 98 score rows of the hm head (model.py:271,520-522)
     "sepup_c280_n128_64x64": 2.0 * 4096 * 280 * (128 + 9),
     "sepup_c296_n256_32x32": 2.0 * 1024 * 296 * (256 + 9),
     "conv1x1_argmax_c128_n98_64x64": 2.0 * 4096 * 128 * 294,       # the whole hm head (98 scores executed; offsets at the arg-max only)
@@ -86,7 +85,6 @@ def tag_flops_per_face(tag: str):
 
 
 KERNEL_OF_TAG_F32S = (   # profile tag prefix -> the HIP kernel that runs it in an f32s program (csrc/engine.cpp dispatch)
-    ("conv3x3_argmax_c128_n128", "conv3x3_halo_split_kernel<128,4,2,128,HEAD>"),
     ("conv3x3_c128_n128_64x64", "conv3x3_halo_split_kernel<128,4,2>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
     ("sepup_", "sepup_patch_kernel"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
     ("conv", "conv_gemm_split_kernel"))

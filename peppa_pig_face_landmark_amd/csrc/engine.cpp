@@ -37,7 +37,7 @@ struct Program {
     std::vector<PfOpRec> ops;
     char* d_const = nullptr;
     char* d_arena = nullptr;
-    unsigned* d_range = nullptr;     // f32s range guard: one slot per op + one for a fused score head's input (k_layers.h range_verdict_kernel)
+    unsigned* d_range = nullptr;     // f32s range guard: one slot per op (k_layers.h range_verdict_kernel)
     size_t arena_bytes = 0;
     int max_batch = 0;
     int esize = 2;
@@ -152,7 +152,6 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 template <typename T, bool SPLIT>
 static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B, unsigned* range_slot) {
-    // (range_slot != nullptr: the guard is on; a fused score head then reports its input in the program's extra slot, index n_ops)
     const int32_t* f = op.f;
     const PfTensorRec& ti = p.tens[f[0]];
     const PfTensorRec& to = p.tens[f[1]];
@@ -175,13 +174,6 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
     memcpy(&a.acc_scale, &f[22], 4);
     a.dbg = h->dbg;
     a.range_slot = range_slot;
-    const bool head = f[24] != 0;        // heat-map score head fused into this conv's epilogue (graph/ir.py fuse_argmax_head)
-    if (head) {
-        a.head_wt = p.cptr(f[25]);
-        a.head_bias = (const float*)p.cptr(f[26]);
-        memcpy(&a.head_scale, &f[27], 4);
-        a.head_range_slot = range_slot ? p.d_range + p.ops.size() * PF_RANGE_SUBSLOTS : nullptr;
-    }
     // tile configurations: index -> (BM pixels, BN channels).  The channel tile is chosen so that
     // q tiles of NT*16 channels cover Npad with the least padding (NT <= 8), ties -> fewer tiles.
     static const int bm[PF_CONV_NCFG] = {128, 128, 256, 256, 128, 128, 128, 256, 128};
@@ -225,18 +217,13 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
         break;
     // 3x3 / stride 1 / pad 1 with 128 outputs on 16-, 32- or 64-pixel-wide maps: input patch resident in LDS
     // (the Student's hero conv; HRNet's 18 / 36 / 72-channel 3x3 stacks of the Teacher take the narrow variants)
-    if (SPLIT && use_split && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && !a.gate && (!a.amax_val || head) &&
+    if (SPLIT && use_split && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && !a.gate && !a.amax_val &&
         (a.outW == 16 || a.outW == 32 || a.outW == 64) && ((a.outH * a.outW) % 128) == 0 && a.inH == a.outH && a.inW == a.outW &&
         (a.Npad == 128 || (a.Npad == 64 && a.outW == 64) || a.Npad == 32 || a.Npad == 48 || a.Npad == 80)) {
         if constexpr (SPLIT) {
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
-            if (head) {
-                if (a.Npad != 128 || a.N != 128 || a.Cpad != 128 || a.res || a.fbias || !a.store_out || a.outCs != 1 || (a.outLd & 3))
-                    PF_FAIL(h, "fused score head on a conv that is not the 128 -> 128 halo case");
-                PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2, 128, true>), grid, dim3(512), h->stream, a);
-            } else
             if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
             else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);
@@ -718,7 +705,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     }
     if (guard) {
         RangeVerdictArgs v{};
-        v.slots = p.d_range; v.n_ops = (int)p.ops.size() + 1;     // + the fused score head's input
+        v.slots = p.d_range; v.n_ops = (int)p.ops.size();
         v.lo = 0.0009765625f;            // 2^-10: below this a tensor's low halves sit in the f16 subnormal range
         v.hi = 6.0e4f;                   // f16 overflows at 65504
         v.status = h->h_status; v.prog_slot = slot;
@@ -894,7 +881,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes));
     PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
     if (hd.dtype == PF_DTYPE_F32_SPLIT) {
-        const size_t rb = ((size_t)hd.n_ops + 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);      // one slot per op + the fused score head's input
+        const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);
         PF_HIP(h, hipMalloc((void**)&p.d_range, rb));
         PF_HIP(h, hipMemset(p.d_range, 0, rb));
     }

@@ -22,8 +22,6 @@
 #pragma once
 #include "pf_common.h"
 
-#define PF_HEAD_ROWS 112    // score rows of the fused heat-map head (98 points padded to whole 16-row MFMA tiles)
-
 struct ConvGemmArgs {
     const void* in;
     const void* wt;       // [Npad][KH*KW][Cpad], element type T, zero padded
@@ -60,13 +58,6 @@ struct ConvGemmArgs {
     // first channel chunk only, 128 = no per-tap barrier; conv_gemm_split_kernel: 16 as above, 256 = operands (pixels AND weights)
     // fetched for the first K step only, 512 = no split / LDS store of the pixel operand.  Tables: profiles/r02_*ablations.md.
     int dbg;
-    // heat-map score head fused into the epilogue of the 128-output halo kernel (conv3x3_halo_split_kernel<..., HEAD = true>):
-    // head_wt = [head_npad rows][Npad / 32 chunks][hi 32 | lo 32] f16 (pack_conv_weight's pointwise format), scores =
-    // acc * head_scale + head_bias; the per-(face, point) partial maxima go to amax_val / amax_idx (amaxN points)
-    const void* head_wt;
-    const float* head_bias;
-    float head_scale;
-    unsigned* head_range_slot;   // range guard of the head's input (= this conv's output), separate from range_slot (its input)
 };
 
 template <typename T> struct ConvMma;
@@ -1024,7 +1015,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
 // per tap (LDS-DMA, two stages).  Activation fetches, conversions and LDS writes drop ~4x (halo overhead 2.06x
 // at W = 64); the matrix-core work and the epilogue are unchanged.  Host guarantees: pad = dil = stride = 1,
 // W in {16, 32, 64}, (H * W) % 128 == 0, no input gate.
-template <int BN, int WARPS_M, int WARPS_N, int BM = 128, bool HEAD = false>
+template <int BN, int WARPS_M, int WARPS_N, int BM = 128>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void conv3x3_halo_split_kernel(ConvGemmArgs a) {
     constexpr int NTHR = WARPS_M * WARPS_N * 64;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N;
@@ -1038,11 +1029,10 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
     constexpr int WCHUNKS = (BN * 8 + NTHR - 1) / NTHR;
     constexpr int W_BYTES = WCHUNKS * NTHR * 16;
     static_assert(NTHR == 512 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + 2 * W_BYTES + (HEAD ? 1024 : 0)];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + 2 * W_BYTES];
     unsigned char* xh = smem;
     unsigned char* xl = smem + PLANE_X;
     unsigned char* wbase = smem + 2 * PLANE_X;
-    float* const sbias = reinterpret_cast<float*>(smem + 2 * PLANE_X + 2 * W_BYTES);   // HEAD: this layer's bias [128], the head's [112]
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -1135,10 +1125,6 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         hp0[i] = ty * HW2 + tx;
     }
 
-    if constexpr (HEAD) {
-        if (t < 128) sbias[t] = a.bias[t];
-        else if (t < 128 + PF_HEAD_ROWS) sbias[t] = a.head_bias[t - 128];
-    }
     load_x(0);
     load_w(0, 0, 0);
     store_x();
@@ -1207,157 +1193,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
         if (!(pf_dbg(a) & 128)) __syncthreads();
         if (last_tap) { tap = 0; ++cb; } else ++tap;
     }
-    if constexpr (!HEAD) {
-        pf_amax_commit(a.range_slot, amax, amax_seen);
-        conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
-    } else {
-        // ---- fused heat-map score head (COTRAIN.forward hm conv + postp arg-max, model.py:271,295,520-522) ---------------------
-        // The separate score-head launch re-read this layer's whole output from HBM (537 MB per 256 faces at 64 x 64) for a 128 ->
-        // 98 pointwise GEMM and kept only 98 maxima per face.  Here the tile's 128 x 128 activations go to global memory (the
-        // offset gather of hm_decode_kernel needs them at the arg-max pixels) AND, split to f16 hi / lo, into the LDS the main
-        // loop is done with, 64 channels (one wave column) at a time; the head's weights for those 64 channels arrive by LDS-DMA
-        // meanwhile, and every wave multiplies 16 pixels x 112 score rows.  Arithmetic per score: the same three-product split
-        // GEMM over the same 32-channel chunks in the same order as the stand-alone head.
-        static_assert(BM == 128 && BN == 128 && WARPS_M == 4 && WARPS_N == 2 && MT == 2 && NT == 4, "fused head: hero configuration");
-        constexpr int HT = PF_HEAD_ROWS / 16;
-        // LDS of the main loop, reused: the patch planes hold two 32-channel chunks of the pixel operand ([chunk][hi | lo][128 rows
-        // x 64 B]), the two weight stages one chunk of head weights each (hi rows then lo rows)
-        static_assert(2 * 16384 <= 2 * PLANE_X && PF_HEAD_ROWS * 128 <= W_BYTES && W_BYTES == 16384, "fused head: LDS of the main loop is reused");
-        unsigned char* const hx = smem;
-        const unsigned char* __restrict__ hwt = static_cast<const unsigned char*>(a.head_wt);
-        auto head_w_issue = [&](int c, int stage) {      // chunk c (32 input channels) of every score row -> weight stage
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int sl = t + NTHR * q;
-                if (sl < PF_HEAD_ROWS * 8) {             // (whole waves: 896 = 14 x 64)
-                    const int plane = sl >= PF_HEAD_ROWS * 4 ? 1 : 0;
-                    const int row = (sl - plane * PF_HEAD_ROWS * 4) >> 2;
-                    const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                    pf_glds16(hwt + ((size_t)row * (a.Npad >> 5) + c) * 128 + plane * 64 + chunk * 16, wbase + stage * W_BYTES + sl * 16);
-                }
-            }
-        };
-        const int crow = fchunk * 4;
-        const int hp_row = wave * 16 + frow;             // this lane's pixel in the score GEMM: wave w owns pixels 16 w .. 16 w + 15
-        float* __restrict__ orow = static_cast<float*>(a.out) + (size_t)m0 * a.outLd;
-        pf_f32x4 sc[HT];
-#pragma unroll
-        for (int j = 0; j < HT; ++j) sc[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        pf_amax_commit(a.range_slot, amax, amax_seen);   // this conv's input; from here on amax follows the head's input
-        amax = 0;
-        const unsigned amax2_seen = pf_amax_seen(a.head_range_slot);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if (half) __syncthreads();                   // the previous half is done with the LDS (the main loop ended on a barrier)
-            head_w_issue(2 * half, 0);
-            head_w_issue(2 * half + 1, 1);
-            if (wn == half) {                            // this wave column's 64 channels -> the split pixel operand
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int n = wn * WN + j * 16 + crow;
-                    const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(sbias + n);
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const int m = wm * WM + i * 16 + frow;
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.acc_scale + bv[r];
-                        pf_act_n<4>(v, a.act);
-                        pf_half4 hi, lo;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const pf_half hv = (pf_half)v[r];
-                            hi[r] = hv;
-                            lo[r] = (pf_half)(v[r] - (float)hv);
-                            amax = pf_amax(amax, v[r]);
-                        }
-                        // channel 16 j + 4 fchunk + r of this wave column = chunk j >> 1, 16-byte piece 2 (j & 1) + (fchunk >> 1), half (fchunk & 1)
-                        unsigned char* dst = hx + (j >> 1) * 16384 + pf_lds_chunk_off(m, 2 * (j & 1) + (fchunk >> 1)) + (fchunk & 1) * 8;
-                        *reinterpret_cast<pf_half4*>(dst) = hi;
-                        *reinterpret_cast<pf_half4*>(dst + 8192) = lo;
-                    }
-                }
-            }
-            __syncthreads();                             // (drains the weight requests)
-            // 16 pixels x 112 score rows x the two chunks; the three products of a (row tile, chunk) pair are spread over groups
-            // of row tiles so that consecutive MFMAs never share an accumulator
-            const int xo = pf_lds_chunk_off(hp_row, fchunk);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const unsigned char* xs = hx + c * 16384;
-                const pf_half8 xhf = *reinterpret_cast<const pf_half8*>(xs + xo);
-                const pf_half8 xlf = *reinterpret_cast<const pf_half8*>(xs + 8192 + xo);
-                const unsigned char* wh = wbase + c * W_BYTES;
-                const unsigned char* wl2 = wh + PF_HEAD_ROWS * 64;
-#pragma unroll
-                for (int g = 0; g < HT; g += 4) {
-                    pf_half8 whf[4], wlf[4];
-#pragma unroll
-                    for (int j = g; j < HT && j < g + 4; ++j) {
-                        const int off = pf_lds_chunk_off(j * 16 + frow, fchunk);
-                        whf[j - g] = *reinterpret_cast<const pf_half8*>(wh + off);
-                        wlf[j - g] = *reinterpret_cast<const pf_half8*>(wl2 + off);
-                    }
-#pragma unroll
-                    for (int j = g; j < HT && j < g + 4; ++j) sc[j] = pf_mfma_16x16x32_f16(wlf[j - g], xhf, sc[j]);      // small terms first
-#pragma unroll
-                    for (int j = g; j < HT && j < g + 4; ++j) sc[j] = pf_mfma_16x16x32_f16(whf[j - g], xlf, sc[j]);
-#pragma unroll
-                    for (int j = g; j < HT && j < g + 4; ++j) sc[j] = pf_mfma_16x16x32_f16(whf[j - g], xhf, sc[j]);
-                }
-            }
-        }
-        // the layer's own output (hm_decode_kernel's offset gather reads it at the arg-max pixels) leaves AFTER the last barrier:
-        // a barrier with LDS-DMA pending drains vmcnt to 0, stores included
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = wn * WN + j * 16 + crow;
-            const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(sbias + n);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int m = wm * WM + i * 16 + frow;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[j][i][r] * a.acc_scale + bv[r];
-                pf_act_n<4>(v, a.act);
-                *reinterpret_cast<pf_f32x4*>(orow + (size_t)m * a.outLd + n) = pf_f32x4{v[0], v[1], v[2], v[3]};
-            }
-        }
-        pf_amax_commit(a.head_range_slot, amax, amax2_seen);
-        // bias, then (max, first index) over this wave's 16 pixels by DPP row exchanges; slot = (tile of the face) * 8 + wave
-        const int b = m0 / OHW;
-        const int local = m0 - b * OHW + hp_row;
-        const int nslots = (OHW / BM) * 8;
-        const int slot = ((m0 - b * OHW) / BM) * 8 + wave;
-#pragma unroll
-        for (int j = 0; j < PF_HEAD_ROWS / 16; ++j) {
-            const int n = j * 16 + crow;
-            float best_v[4];
-            int best_i[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                best_v[r] = fmaf(sc[j][r], a.head_scale, sbias[128 + n + r]);
-                best_i[r] = local;
-            }
-#define PF_AMAX_STEP(STEP)                                                                                   \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                              \
-        const float ov = pf_row_xchg_f32<STEP>(best_v[r]);                                                    \
-        const int oi = pf_row_xchg_i32<STEP>(best_i[r]);                                                      \
-        if (ov > best_v[r] || (ov == best_v[r] && oi < best_i[r])) { best_v[r] = ov; best_i[r] = oi; }        \
-    }
-            PF_AMAX_STEP(0) PF_AMAX_STEP(1) PF_AMAX_STEP(2) PF_AMAX_STEP(3)
-#undef PF_AMAX_STEP
-            if (frow == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < a.amaxN) {
-                        const size_t o = ((size_t)b * a.amaxN + n + r) * nslots + slot;
-                        a.amax_val[o] = best_v[r];
-                        a.amax_idx[o] = best_i[r];
-                    }
-            }
-        }
-    }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
+    conv_gemm_epilogue<float, BM, BN, WARPS_M, WARPS_N>(a, acc, m0, n0, wm, wn, lane, M, OHW, a.acc_scale);
 }
 
 // ---- fused DecoderBlock front end with the low-res patch and its filters resident in LDS ------------------------

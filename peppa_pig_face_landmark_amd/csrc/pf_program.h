@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 9
+#define PF_PROGRAM_VERSION 8
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -38,7 +38,6 @@ enum PfOpCode : int32_t {
     PF_OP_STEM = 1,     // f: in_t(-1 = program input) out_t wt(u8 input, 1/255 folded) bias act wt(f32 input)
     PF_OP_CONV = 2,     // f: in_t out_t wt bias res_t gate_buf fbias_buf KH KW stride pad dil Cpad Npad N act
                         //    outCs amax_val_buf amax_idx_buf amaxN store_out cfg acc_scale(float bits) use_split
-                        //    [24] fused arg-max head (0/1) head_wt head_bias head_scale(float bits): graph/ir.py fuse_argmax_head
     PF_OP_DW = 3,       // f: in_t out_t wt bias K stride pad dil act
     PF_OP_UPCAT = 4,    // f: lo_t skip_t out_t
     PF_OP_GAP = 5,      // f: in_t out_buf

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 9
+VERSION = 8
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
@@ -219,38 +219,6 @@ class ProgramBuilder:
                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], 1 if use_split else 0],
                  [self._tb(x), self._tb(res), gate_buf, fbias_buf], [self._tb(out), av, ai])
         return out
-
-    HEAD_ROWS = 112          # score rows the fused head keeps in LDS (csrc/k_conv_gemm.h, HEAD = true)
-
-    def argmax_head_slots(self, feat: int, weight: np.ndarray) -> int:
-        """Partial-maximum slots per point when a pointwise arg-max head on ``feat`` can ride in the epilogue of the conv that
-        produced it -- the LAST op, and the 128-output halo kernel's case (3x3, stride 1, pad 1, 128 -> 128, split precision,
-        16/32/64-pixel-wide map of whole 128-pixel tiles); 0 otherwise."""
-        code, f, _, _ = self.ops[-1]
-        tf = self.tensors[feat]
-        n, cin = weight.shape[0], weight.shape[1]
-        ok = (code == OP_CONV and f[1] == feat and f[7] == 3 and f[8] == 3 and f[9] == 1 and f[10] == 1 and f[11] == 1 and
-              f[12] == 128 and f[13] == 128 and f[14] == 128 and f[16] == 1 and f[23] == 1 and f[4] < 0 and f[5] < 0 and
-              f[6] < 0 and f[17] < 0 and tf.W in (16, 32, 64) and (tf.H * tf.W) % 128 == 0 and cin == 128 and
-              n <= self.HEAD_ROWS and tuple(weight.shape[2:]) == (1, 1) and self.split)
-        return (tf.H * tf.W // 128) * 8 if ok else 0
-
-    def fuse_argmax_head(self, feat: int, weight: np.ndarray, bias: np.ndarray, amax: Tuple[int, int, int]):
-        """Attaches the head (bias only, nothing stored) to that conv: it then runs in the kernel's epilogue instead of re-reading
-        ``feat`` from HBM.  ``amax`` buffers hold argmax_head_slots() slots per point."""
-        assert self.argmax_head_slots(feat, weight) > 0
-        code, f, reads, writes = self.ops[-1]
-        n, cin = weight.shape[0], weight.shape[1]
-        wpad = np.zeros((self.HEAD_ROWS, 128), np.float64)
-        wpad[:n] = weight.astype(np.float64).reshape(n, cin)
-        blocks, scale = self._split_rows(wpad)
-        b = np.zeros(self.HEAD_ROWS, np.float64)
-        b[:n] = bias
-        av, ai, an = amax
-        f[17], f[18], f[19] = av, ai, an
-        f[24], f[25], f[26] = 1, self.const(blocks), self.const_f32(b)
-        f[27] = struct.unpack("<i", struct.pack("<f", scale))[0]
-        writes += [av, ai]
 
     def dw(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
            dil: int = 1, out_name: str = "") -> int:

@@ -109,18 +109,12 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
         warps_m *= 2       # the split-precision kernels run 8 waves (2x the M-waves) per workgroup
     assert (h4 * h4) % bm == 0, "heat-map area must be a multiple of the GEMM pixel tile"
     nslots = (h4 * h4 // bm) * warps_m
-    # the score head rides in the epilogue of up2.conv2 when that is the halo kernel's 128 -> 128 case (f32s, maps up to 64 wide)
-    fused = 0 if debug_full_hm else pb.argmax_head_slots(decx4, hw[:NUM_POINTS])
-    nslots = fused or nslots
     val = pb.buffer(NUM_POINTS * nslots, ir.ELEM_F32, "amax_val")
     idx = pb.buffer(NUM_POINTS * nslots, ir.ELEM_I32, "amax_idx")
-    if fused:
-        pb.fuse_argmax_head(decx4, hw[:NUM_POINTS], hb[:NUM_POINTS], (val, idx, NUM_POINTS))
-    else:
-        dummy = pb.tensor(h4, h4, ir._round_up(NUM_POINTS, pb.ve), buf=pb.buffer(pb.ve, ir.ELEM_ACT, "hm.unused"),
-                          coff=0, ld=ir._round_up(NUM_POINTS, pb.ve))
-        pb.conv(decx4, hw[:NUM_POINTS], hb[:NUM_POINTS], "none", out=dummy, amax=(val, idx, NUM_POINTS),
-                store_out=False, cfg=0)
+    dummy = pb.tensor(h4, h4, ir._round_up(NUM_POINTS, pb.ve), buf=pb.buffer(pb.ve, ir.ELEM_ACT, "hm.unused"),
+                      coff=0, ld=ir._round_up(NUM_POINTS, pb.ve))
+    pb.conv(decx4, hw[:NUM_POINTS], hb[:NUM_POINTS], "none", out=dummy, amax=(val, idx, NUM_POINTS),
+            store_out=False, cfg=0)
     loc, score = pb.hmdec(val, idx, decx4, hw[NUM_POINTS:, :, 0, 0], hb[NUM_POINTS:], NUM_POINTS, nslots)
     return loc, score, info
 
