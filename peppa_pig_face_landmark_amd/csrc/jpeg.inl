@@ -689,7 +689,10 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     }
     {
         ProfScope ps(h, "jpeg_color");
-        PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
+        if ((hd.W & 3) == 0 && (reinterpret_cast<uintptr_t>(sl.d_bgr) & 3) == 0)
+            PF_LAUNCH(jpeg_color4_kernel, dim3((unsigned)(((long long)(hd.W / 4) * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
+        else
+            PF_LAUNCH(jpeg_color_kernel, dim3((unsigned)(((long long)hd.W * hd.H + 255) / 256), (unsigned)n), dim3(256), h->stream, ca);
     }
     if (bgr_host) PF_HIP(h, hipMemcpyAsync(bgr_host, sl.d_bgr, out_bytes, hipMemcpyDeviceToHost, h->stream));
     if (final_sync || bgr_host) {

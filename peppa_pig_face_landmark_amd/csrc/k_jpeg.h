@@ -629,3 +629,32 @@ __global__ __launch_bounds__(256) void jpeg_color_kernel(JpegColorArgs a) {
     const int g = Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16);
     o[0] = pf_jpeg_clamp8(b); o[1] = pf_jpeg_clamp8(g); o[2] = pf_jpeg_clamp8(r);
 }
+
+// Four pixels of a row per thread (W % 4 == 0): one 4-byte luma load and three 4-byte stores instead of four and twelve single
+// bytes -- the per-pixel kernel above ran at ~1 TB/s on byte stores.  Same arithmetic, pixel by pixel.
+__global__ __launch_bounds__(256) void jpeg_color4_kernel(JpegColorArgs a) {
+    const int W4 = a.W >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)W4 * a.H) return;
+    const int yy = (int)(i / W4), x0 = (int)(i - (long long)yy * W4) * 4;
+    const size_t po = (size_t)blockIdx.y * a.frame_plane_bytes;
+    const unsigned y4 = *reinterpret_cast<const unsigned*>(a.y + po + (size_t)yy * a.ys + x0);
+    unsigned char px[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int Y = (int)((y4 >> (8 * k)) & 255u);
+        if (a.mode == 0) {
+            px[3 * k] = px[3 * k + 1] = px[3 * k + 2] = (unsigned char)Y;
+        } else {
+            const int cb = pf_jpeg_chroma(a.cb + po, a.cs, a.cw, a.ch, a.mode, x0 + k, yy) - 128;
+            const int cr = pf_jpeg_chroma(a.cr + po, a.cs, a.cw, a.ch, a.mode, x0 + k, yy) - 128;
+            px[3 * k + 2] = pf_jpeg_clamp8(Y + ((91881 * cr + 32768) >> 16));
+            px[3 * k] = pf_jpeg_clamp8(Y + ((116130 * cb + 32768) >> 16));
+            px[3 * k + 1] = pf_jpeg_clamp8(Y + ((-22554 * cb + 32768 - 46802 * cr) >> 16));
+        }
+    }
+    unsigned* o = reinterpret_cast<unsigned*>(a.out + ((size_t)blockIdx.y * a.W * a.H + (size_t)yy * a.W + x0) * 3);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        o[q] = (unsigned)px[4 * q] | ((unsigned)px[4 * q + 1] << 8) | ((unsigned)px[4 * q + 2] << 16) | ((unsigned)px[4 * q + 3] << 24);
+}
