@@ -180,6 +180,20 @@ def test_decode_matches_libjpeg_gpu(hip_library):
         data = _encode(img, quality=90, subsampling=2)
         _, _, _, got = eng.decode_jpeg(data)
         assert np.array_equal(got, _pil_decode(data))
+        # the sub-sequence decoder's rounds race by design (a record may be rewritten while its successor reads it; the work lists
+        # make somebody check again afterwards): slow-to-synchronise streams, many sub-sequences, many repetitions
+        for (h, w), kw in (((480, 640), dict(quality=100, subsampling=2)), ((360, 480), dict(quality=100, subsampling=0)),
+                           ((1080, 1920), dict(quality=97, subsampling=2))):
+            data = _encode(_image(h, w, seed=h + w), **kw)
+            ref = _pil_decode(data)
+            eng.profile_enable(True)
+            eng.profile_fetch()
+            for rep in range(12):
+                _, _, _, got = eng.decode_jpeg(data)
+                assert np.array_equal(got, ref), (h, w, kw, rep)
+            names = list(eng.profile_fetch())
+            eng.profile_enable(False)
+            assert "jpeg_subseq" in names, names
     finally:
         eng.close()
 
