@@ -416,6 +416,9 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
         memcpy(t->maxcode[i], src.maxcode, sizeof(src.maxcode));
         memcpy(t->valoff[i], src.valoff, sizeof(src.valoff));
         memcpy(t->vals[i], src.vals, sizeof(src.vals));
+        t->limit[i][0] = 0;
+        for (int l = 1; l <= 16; ++l)                  // lengths without codes keep the bound of the shorter ones
+            t->limit[i][l] = src.maxcode[l] >= 0 ? (src.maxcode[l] + 1) << (16 - l) : t->limit[i][l - 1];
     }
     desc->scan_off = 0; desc->scan_len = (unsigned)scan_len;
     desc->offs_off = (unsigned)offs_off; desc->n_intervals = (unsigned)offs.size();

@@ -93,6 +93,7 @@ struct JpegGpuTables {                    // index 0, 1: DC tables 0 / 1; 2, 3: 
     int maxcode[4][18];
     int valoff[4][17];
     unsigned char vals[4][256];
+    int limit[4][17];                     // left-justified (16-bit) exclusive upper bound of the codes of each length; [0] = 0
 };
 
 
@@ -146,6 +147,21 @@ __device__ __forceinline__ int pf_jpeg_huff(PfJpegBits& br, const JpegGpuTables*
         if (l > 16) return 0;
         if (t->maxcode[ti][l] >= 0 && code <= t->maxcode[ti][l]) return t->vals[ti][(code + t->valoff[ti][l]) & 0xFF];
     }
+}
+
+// The same symbol without the bit-by-bit search: a canonical code's length is the number of per-length upper bounds its 16-bit
+// left-justified window has reached.  In a wave whose 64 lanes sit at unrelated places of their streams SOME lane needs the
+// search on almost every step, and the wave paid for the longest loop (up to seven rounds of shift / compare / branch).
+__device__ __forceinline__ int pf_jpeg_huff_flat(PfJpegBits& br, const JpegGpuTables* t, int ti) {
+    const int lk = t->look[ti][pf_jpeg_peek(br, 9)];
+    if (lk) { br.n -= lk >> 8; return lk & 0xFF; }
+    const int c = pf_jpeg_peek(br, 16);
+    int l = 10;
+#pragma unroll
+    for (int q = 10; q <= 15; ++q) l += c >= t->limit[ti][q] ? 1 : 0;
+    br.n -= l;
+    if (c >= t->limit[ti][16]) return 0;                  // no such code (corrupt stream)
+    return t->vals[ti][((c >> (16 - l)) + t->valoff[ti][l]) & 0xFF];
 }
 
 __device__ __forceinline__ int pf_jpeg_extend(int v, int s) { return s == 0 ? 0 : (v < (1 << (s - 1)) ? v - (1 << s) + 1 : v); }
@@ -300,15 +316,16 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
         for (unsigned k = threadIdx.x; k < sizeof(JpegGpuTables) / 4; k += 64) dst[k] = src[k];
     }
     __syncthreads();
-    if (i >= (int)d.n_intervals) return;
-    const size_t rec = (size_t)blockIdx.y * a.max_sub + i;
+    const bool idle = i >= (int)d.n_intervals;            // (write pass: the lane still helps to move its neighbours' blocks)
+    if (idle && MODE != 2) return;
+    const size_t rec = (size_t)blockIdx.y * a.max_sub + (idle ? 0 : i);
     if (MODE == 1 && (i == 0 || a.stamp[rec - 1] != (unsigned)(a.round - 1))) return;   // predecessor unchanged: so is this record
     const JpegGpuTables* t = &tables;
     const unsigned total_bits = d.scan_len * 8u;
     const unsigned end_bits = min((unsigned)(i + 1) * PF_JPEG_SUBSEQ_BITS, total_bits);      // (write pass)
-    unsigned p0 = (unsigned)i * PF_JPEG_SUBSEQ_BITS;
+    unsigned p0 = idle ? 0u : (unsigned)i * PF_JPEG_SUBSEQ_BITS;
     int bi = 0, z = 0;
-    if (MODE != 0 && i > 0) {
+    if (MODE != 0 && i > 0 && !idle) {
         p0 = a.exit_p[rec - 1];
         const unsigned st = a.exit_s[rec - 1];
         bi = (int)(st >> 8);
@@ -349,15 +366,14 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
         for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(mine)[k] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const unsigned total_blocks = (unsigned)a.total_mcus * a.bpm;
-    auto decode_until = [&](unsigned stop_bits) {
-    while (bitpos() < stop_bits && (MODE != 2 || ordinal < total_blocks)) {
+    auto symbol_step = [&]() {
         // ONE symbol per iteration, the same instruction sequence for the DC difference and for an AC (run, size) symbol: the 64
         // lanes of a wave are at unrelated places of their blocks, and separate DC / AC / fast-path branches made the wave pay
         // for every path on every step
         const int c = comp_of[bi];
         pf_jpeg_fill(br);                                 // > 32 bits: a code (<= 16) and its magnitude bits (<= 15)
         const bool dc = z == 0;
-        const int sym = pf_jpeg_huff(br, t, dc ? (int)((d.tdta >> c) & 1u) : 2 + (int)((d.tdta >> (4 + c)) & 1u));
+        const int sym = pf_jpeg_huff_flat(br, t, dc ? (int)((d.tdta >> c) & 1u) : 2 + (int)((d.tdta >> (4 + c)) & 1u));
         const int sz = dc ? (sym > 15 ? 15 : sym) : (sym & 15);
         const int r = dc ? 0 : (sym >> 4);
         const int raw = pf_jpeg_peek(br, sz ? sz : 1);
@@ -380,30 +396,53 @@ __global__ __launch_bounds__(64) void jpeg_sync_kernel(JpegSubseqArgs a) {
                 z = 64;                                   // a run past the block: the host decoder ends the block here too
             }
         }
-        if (z >= 64) {                                    // block complete
-            if (MODE == 2) {
-                if (own) {
-                    if (blk) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(blk)[k] = reinterpret_cast<const pf_f32x4*>(mine)[k];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) reinterpret_cast<pf_f32x4*>(mine)[k] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+    };
+    auto decode_until = [&](unsigned stop_bits) {         // (guess pass and synchronisation rounds: nothing is written)
+        while (bitpos() < stop_bits) {
+            symbol_step();
+            if (z >= 64) {                                // block complete
+                ++done_blocks;
+                z = 0;
+                bi = bi + 1 == a.bpm ? 0 : bi + 1;
+            }
+        }
+    };
+    if (MODE == 2) {
+        // Write pass.  A completed block the lane owns (it decoded it from the DC on) is moved from LDS to the dense buffer by the
+        // WHOLE wave -- lane k stores coefficient k: one 2-byte store instruction per block -- because completions happen at
+        // unrelated moments in the 64 lanes: as a per-lane branch (eight 16-byte stores, eight LDS reads, eight LDS writes to
+        // clear, the block address arithmetic) that path ran ~320 times per wave and was more than half of this pass's
+        // instructions (SQ_INSTS_VALU 47 k per wave against 20 k for the guess pass, profiles/r03_run33_pmc_sq_jpeg_sync_kernels.json).
+        const int lane = threadIdx.x;
+        bool active = !idle && bitpos() < end_bits && ordinal < total_blocks;
+        while (__ballot(active)) {
+            bool finished = false;
+            if (active) {
+                symbol_step();
+                finished = z >= 64;
+            }
+            unsigned long long m = __ballot(finished && own && blk != nullptr);
+            const unsigned long long bp = reinterpret_cast<unsigned long long>(blk);
+            while (m) {
+                const int L = __builtin_ctzll(m);
+                m &= m - 1;
+                const unsigned lo = (unsigned)pf_shfl_i32((int)(unsigned)bp, L), hi = (unsigned)pf_shfl_i32((int)(unsigned)(bp >> 32), L);
+                short* dst = reinterpret_cast<short*>(((unsigned long long)hi << 32) | lo);
+                short* src = blkbuf + L * BLK_STRIDE;
+                dst[lane] = src[lane];
+                src[lane] = 0;
+            }
+            if (finished) {
                 ++ordinal;
                 blk = ordinal < total_blocks ? block_ptr(ordinal) : nullptr;
                 own = true;
+                z = 0;
+                bi = bi + 1 == a.bpm ? 0 : bi + 1;
             }
-            ++done_blocks;
-            z = 0;
-            bi = bi + 1 == a.bpm ? 0 : bi + 1;
+            active = active && bitpos() < end_bits && ordinal < total_blocks;
         }
-    }
-    };
-    if (MODE == 2) {
-        decode_until(end_bits);
         // the block still open at the exit continues in the next sub-sequence: hand over what was decoded here, entry by entry
-        if (own && z > 0 && blk) {
+        if (!idle && own && z > 0 && blk) {
             for (int k = 0; k < 64; ++k)
                 if (mine[k]) blk[k] = mine[k];
         }
