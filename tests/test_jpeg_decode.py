@@ -151,6 +151,42 @@ def _check_cases(eng):
     assert np.array_equal(lb_dev[0], lb_host[0]) and np.array_equal(lb_dev[1], lb_host[1])
 
 
+def _corrupt_scan_case(library):
+    """Damaged entropy-coded data (no marker damage, so the file still takes the device's sub-sequence decoder): every thread's
+    decode is bounded by its bit range and every block address by the block count -- the call returns (pixels are garbage, like
+    libjpeg's 'corrupt data' warning path) or reports that the stream did not synchronise; it never hangs or writes out of range."""
+    eng = _native.Engine(0, library)
+    try:
+        rng = np.random.default_rng(99)
+        data = bytearray(_encode(_image(72, 104, seed=5), quality=80, subsampling=2))
+        sos = bytes(data).find(b"\xff\xda")
+        start = sos + 2 + int.from_bytes(data[sos + 2:sos + 4], "big")
+        for trial in range(6):
+            bad = bytearray(data)
+            for pos in rng.integers(start, len(bad) - 2, 25):
+                bad[pos] = int(rng.integers(0, 255))          # never 0xFF: no new markers
+            if trial == 5:
+                bad = bad[:start + (len(bad) - start) // 2] + b"\xff\xd9"      # truncated scan
+            try:
+                _, h, w, got = eng.decode_jpeg(bytes(bad))
+                assert got.shape == (72, 104, 3)
+            except _native.PeppaHipError:
+                pass
+        _, _, _, got = eng.decode_jpeg(bytes(data))            # the engine is still usable
+        assert np.array_equal(got, _pil_decode(bytes(data)))
+    finally:
+        eng.close()
+
+
+def test_corrupt_scan_terminates_emulator(emu_library):
+    _corrupt_scan_case(emu_library)
+
+
+@pytest.mark.gpu
+def test_corrupt_scan_terminates_gpu(hip_library):
+    _corrupt_scan_case(hip_library)
+
+
 def test_decode_matches_libjpeg_emulator(emu_library):
     eng = _native.Engine(0, emu_library)
     try:
