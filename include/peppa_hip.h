@@ -169,7 +169,9 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
  * compressed scan crosses PCIe; files WITHOUT restart markers always take the device's sub-sequence decoder
  * (PEPPA_JPEG_ENTROPY=host|device overrides either choice).  If that decoder does not settle, this asynchronous call cannot decode
  * again by itself: the next synchronising call on the handle fails with "did not synchronise" and the batch has to be resubmitted
- * with PEPPA_JPEG_ENTROPY=host (ordinary photographs settle in the first round).  Asynchronous like pf_run_frames: the frames are valid in the order of the
+ * with PEPPA_JPEG_ENTROPY=host (ordinary photographs settle in the first rounds; PEPPA_JPEG_ROUNDS=1..10 queues fewer rounds than
+ * the default 10 -- it can only make the decoder give up sooner, i.e. fall back or report, never return different pixels; the tests
+ * use it to reach the fallback).  Asynchronous like pf_run_frames: the frames are valid in the order of the
  * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets
  * alternate, so the pointer of call k stays valid until call k + 2 and the host work of call k + 1 overlaps the pipeline still
  * running on the frames of call k. */
