@@ -115,6 +115,10 @@ def _check_cases(eng):
         assert b"\xff\xdd" not in data
         _, _, _, got = eng.decode_jpeg(data)
         assert np.array_equal(got, _pil_decode(data)), (h, w, kw)
+    for (h, w), q in (((200, 300), 80), ((203, 301), 95)):       # greyscale: one block per MCU; odd width = the per-pixel colour kernel
+        data = _encode(_image(h, w, seed=h)[..., 1], quality=q)
+        _, _, _, got = eng.decode_jpeg(data)
+        assert np.array_equal(got, _pil_decode(data)), (h, w, q)
     names = list(eng.profile_fetch())
     assert "jpeg_subseq" in names and "jpeg_unpack" not in names, names
     # a stream that needs more rounds than were queued is NOT passed on: the synchronous call falls back to the host decoder
