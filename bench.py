@@ -110,6 +110,8 @@ def parse_args():
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
     ap.add_argument("--no-probes", action="store_true", help="skip the call-latency, sustained-loop and PCIe-inclusive probes (keeps a "
                     "rocprofv3 --stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel HIP-event pass after the timed steps (lane sweeps, "
+                    "rocprofv3 traces of the multi-lane steady state); roofline is null then")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
                     "(a sustained rate an external GPU-busy sampler can see)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -455,7 +457,7 @@ def main():
 
     # ---- per-kernel device time (HIP events on the engine's own stream), dominant kernel roofline ---
     PROF_STEPS = 3
-    prof = state.profile(PROF_STEPS)
+    prof = {} if args.no_kernel_table else state.profile(PROF_STEPS)
     faces_per_launch = faces_per_step // lanes      # the profiled lane processes 1/lanes of the step
     frames_per_launch = args.frames // lanes
     # The dominant kernel = the dense-conv tag with the most device time per lane-step IN THIS RUN (the Student's hero conv

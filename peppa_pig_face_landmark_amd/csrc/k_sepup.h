@@ -403,6 +403,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             const unsigned long long c0 = prof ? pf_clock() : 0;
             unsigned long long c1 = c0, c2 = c0;
             int nreq = 0;
+            bool stored = false;                                    // did this step issue a pending-vector store behind its weight requests?
             if (g >= 1) {
                 const int c = g - 1;
                 if (!W_BY_PROD && issued_w < S && !(pf_dbg(a) & 1)) { w_issue(issued_w); ++issued_w; nreq += WI; }
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
                     for (int k = 0; k < NV; ++k)
                         if (pend_left == NV - k) store_vec(pend_row, k, pend[DEFER ? k : 0]);
                     --pend_left;
+                    stored = true;
                 }
                 if (++ccb == NK) {                                  // the tile is complete: bias, activation, store (or park)
                     int face, y0, gt;
@@ -467,7 +469,12 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             }
             const unsigned long long c3 = prof ? pf_clock() : 0;
             if (EXP_C == 0) pf_wait_vm_barrier<63>();
-            else if (nreq == EXP_C) pf_wait_vm_barrier<(D - 2) * EXP_C + (DEFER ? 1 : 0)>();   // + the pending-vector store of this step
+            // The wait must retire everything OLDER than the (D - 2) steps of weight requests that may stay in flight.  A step that
+            // also issued a pending-vector store (younger than its requests) may leave one more operation outstanding; a step that
+            // did not -- every step of a workgroup's first tile, steps past the eighth of later tiles -- must not, or the count
+            // would cover the previous step's second request, whose lo-plane weights are read right after this barrier.
+            else if (nreq == EXP_C && stored) pf_wait_vm_barrier<(D - 2) * EXP_C + 1>();
+            else if (nreq == EXP_C) pf_wait_vm_barrier<(D - 2) * EXP_C>();
             else pf_wait_vm_barrier<0>();
             if (prof) { t_dma += c1 - c0; t_mma += c2 - c1; t_epi += c3 - c2; t_wait += pf_clock() - c3; }
         }
