@@ -38,7 +38,21 @@ GFLOP_DETECTOR = 0.34        # yolov5n-0.5 @384x640 per frame (upstre
 PEAK_TFLOPS = {"f32": 157.3, "f16": 2500.0, "f32s": 2500.0}
 PEAK_HBM_GBPS = 8000.0
 MFMA_INSTR_PER_PRODUCT = {"f32": 1, "f16": 1, "f32s": 3}
-PMC_SQ_PROFILE = "r02_run5_pmc_sq_hero_and_expdw.json"   # committed rocprofv3 --pmc SQ pass of the hero kernel
+
+
+def newest_hero_pmc():
+    """profiles/rNN_runM_pmc_hero.json with the largest (round, run): the counter passes of the hero kernel are re-collected
+    per round (tools/pmc_kernel.py) and named by round."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_run*_pmc_hero.json")):
+        m = re.match(r"r(\d+)_run(\d+)_", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), int(m.group(2))) > best[0]):
+            best = ((int(m.group(1)), int(m.group(2))), f)
+    return best[1] if best else None
+
+
 HERO_TAG = "conv3x3_c128_n128_64x64"          # up2.conv2 (model.py:165-172): 40.7 % of all MACs
 HERO_FLOP_PER_FACE = 2.0 * 64 * 64 * 128 * 128 * 9
 # algorithmic FLOPs per face of the other dense kernels of the Student (MACs x 2, model.py line ranges in DESIGN.md 5)
@@ -86,7 +100,7 @@ def tag_flops_per_face(tag: str):
 
 KERNEL_OF_TAG_F32S = (   # profile tag prefix -> the HIP kernel that runs it in an f32s program (csrc/engine.cpp dispatch)
     ("conv3x3_c128_n128_64x64", "conv3x3_halo_split_kernel<128,4,2>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
-    ("sepup_", "sepup_patch_kernel"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
+    ("sepup_", "sepup_skip_kernel + sepup_pipe_kernel (sepup_patch_kernel fallback)"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
     ("conv", "conv_gemm_split_kernel"))
 
 
@@ -215,7 +229,8 @@ def hbm_ops_table(prof, steps, frames_per_launch, faces_per_launch, frame_hw, fa
     H, W = frame_hw
     s_crop = 280 * H // 1080        # synthetic boxes are 200 px wide at 1080p: crop side 2 * floor(0.7 w)
     per = {
-        "letterbox": ("K1 cv2 resize+pad -> u8 384x640x3", frames_per_launch * (H * W * 3 + 384 * 640 * 3)),
+        "letterbox": ("K1 cv2 resize+pad -> u8 384x640x3 (algorithmic bytes, SURVEY 8d: the frame once + the letterboxed image)",
+                      frames_per_launch * (H * W * 3 + 384 * 640 * 3)),
         "detect_decode": ("K3 in-graph Detect decode, f32 rows read + written", frames_per_launch * 2 * 15120 * 16 * 4),
         "nms": ("K4 xywh2xyxy + NMS + scale_coords + top-k, f32 rows read once", frames_per_launch * (15120 * 16 * 4 + faces_per_frame * 64)),
         "crop_resize": ("K5 crop + cv2.resize -> u8 256x256x3", faces_per_launch * (3 * s_crop * s_crop + 3 * 256 * 256)),
@@ -232,6 +247,14 @@ def hbm_ops_table(prof, steps, frames_per_launch, faces_per_launch, frame_hw, fa
         out[tag] = {"what": what, "algorithmic_bytes_per_step": int(nbytes), "ms_per_step": round(avg_ms, 4),
                     "launches_per_step": launches_per_step, "achieved_GBps": round(gbps, 1),
                     "frac_of_hbm_peak": round(gbps / PEAK_HBM_GBPS, 4)}
+        if tag == "letterbox":
+            # the bilinear taps of an output row touch two source rows: below a scale of 1/2 rows in between are never fetched
+            # (1080p -> 360 rows: rows 3d+1 and 3d+2 only, 2/3 of the frame) -- the rate the memory system actually saw
+            rh = min(384, int(H * min(384.0 / H, 640.0 / W)))
+            rows_touched = min(H, 2 * rh)
+            fetched = frames_per_launch * (rows_touched * W * 3 + 384 * 640 * 3)
+            out[tag]["fetched_bytes_per_step"] = int(fetched)
+            out[tag]["physical_GBps"] = round(fetched / (avg_ms * 1e-3) / 1e9, 1)
     return out
 
 
@@ -415,10 +438,21 @@ def main():
         state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank, graph=not args.no_graph,
                                     frame_hw=tuple(args.frame_hw))
     else:
+        # the product's multi-lane runner (pf_batch_* of the C ABI; FrameBatchRunner sits on the same object): the library
+        # splits a step's frames over its own `lanes` engines / HIP streams -- bench.py makes ONE call per step
         eng.close()
-        state = bs.MultiLanePipeline(lambda: Engine(local_rank), blobs, dev, args.frames, args.faces_per_frame,
-                                     seed=7 + rank, lanes=lanes, graph=not args.no_graph, frame_hw=tuple(args.frame_hw))
-        eng = state.lanes[0].eng
+        from peppa_pig_face_landmark_amd._native import BatchEngine, PF_OPT_RANGE_CHECK
+        if args.frames % lanes:
+            raise SystemExit("bench.py: --frames %d is not a multiple of --lanes %d" % (args.frames, lanes))
+        batch = BatchEngine(local_rank, lanes)
+        if os.environ.get("PEPPA_BENCH_NO_GUARD"):       # measurement aid only: what the always-on f32s range guard costs
+            batch.set_option(PF_OPT_RANGE_CHECK, 0)
+        per_lane = args.frames // lanes
+        batch.load_program(PF_NET_LANDMARK, blobs[PF_NET_LANDMARK], per_lane * args.faces_per_frame)
+        batch.load_program(PF_NET_DETECTOR, blobs[PF_NET_DETECTOR], per_lane)
+        state = bs.BatchPipelineWorkload(batch, dev, args.frames, args.faces_per_frame, seed=7 + rank, lanes=lanes,
+                                         graph=not args.no_graph, frame_hw=tuple(args.frame_hw))
+        eng = batch.lane(0)
 
     def barrier():
         if use_dist:
@@ -490,28 +524,31 @@ def main():
                     "executed_mfma_tflops": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype], 2),
                     "executed_mfma_frac": round(achieved * MFMA_INSTR_PER_PRODUCT[args.dtype] / PEAK_TFLOPS[args.dtype], 4)}
         # PMC figures cannot be collected from inside this process (rocprofv3 owns the counters): they are attached from
-        # the COMMITTED profile of the same kernel and flagged as such -- they do not move when the kernel regresses.
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_hero_kernel.json")
-        if dom == HERO_TAG and args.dtype in ("f32", "f32s") and os.path.exists(pmc_path):
+        # the NEWEST committed counter file of the hero kernel (profiles/rNN_runM_pmc_hero.json, tools/pmc_kernel.py) and
+        # flagged as such -- they do not move when the kernel regresses.
+        pmc_path = newest_hero_pmc()
+        if dom == HERO_TAG and args.dtype == "f32s" and pmc_path:
             with open(pmc_path) as f:
                 pmc = json.load(f)
-            roofline["traffic"] = int(pmc["traffic_bytes_per_launch"] * faces_per_launch / pmc["faces_per_launch"])
-            roofline["traffic_from_committed_profile"] = True
-            roofline["traffic_source"] = "profiles/pmc_hero_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, scaled to this launch size)"
-        sq_path = os.path.join(ROOT, "profiles", PMC_SQ_PROFILE)
-        if dom == HERO_TAG and args.dtype == "f32s" and os.path.exists(sq_path):
-            with open(sq_path) as f:
-                sq = json.load(f)["derived"]
-            key = [k for k in sq if "conv3x3_halo_split_kernel<128" in k]
-            if key:
-                roofline["mfma_pipe_busy_pmc"] = sq[key[0]]["mfma_pipe_busy_frac"]
+            faces_pmc = int(pmc.get("_meta", {}).get("faces_per_launch", 256))
+            rec = next((v for k, v in pmc.items() if "conv3x3_halo_split_kernel<128" in k), None)
+            if rec and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
+                # raw counters are KB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM)
+                roofline["traffic"] = int((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0 * faces_per_launch / faces_pmc)
+                roofline["traffic_from_committed_profile"] = True
+                roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; 2 x FETCH_SIZE + WRITE_SIZE, scaled to this launch size)" % os.path.basename(pmc_path)
+            if rec and "SQ_VALU_MFMA_BUSY_CYCLES" in rec and rec.get("SQ_BUSY_CU_CYCLES"):
+                roofline["mfma_pipe_busy_pmc"] = round(rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * rec["SQ_BUSY_CU_CYCLES"]), 4)
                 roofline["mfma_pipe_busy_from_committed_profile"] = True
-                roofline["pmc_source"] = "profiles/" + PMC_SQ_PROFILE
+                roofline["pmc_source"] = "profiles/" + os.path.basename(pmc_path)
     if args.dump_profile and rank == 0:
         with open(args.dump_profile, "w") as f:
             json.dump({"steps": PROF_STEPS, "faces_per_step": faces_per_step, "dtype": args.dtype, "workload": workload,
                        "kernels": {k: {"ms_per_step": v[0] / PROF_STEPS, "launches_per_step": v[1] / PROF_STEPS}
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}}, f, indent=1)
+    one_lane = None
+    if workload == "pipeline" and hasattr(state, "one_lane_rate") and not args.no_probes:
+        one_lane = round(state.one_lane_rate(max(4, min(args.steps, 12))), 1)
     latency = None
     if workload == "pipeline" and not args.no_probes:
         l1 = state.latency_p50(1)
@@ -583,7 +620,8 @@ def main():
         "config": {"workload": ("%s full pipeline: %d x %dx%d frames x %d planted faces per GPU per step" % (
                        "configs[2]" if tuple(args.frame_hw) == (1080, 1920) else "configs[4]-shaped", args.frames, args.frame_hw[1], args.frame_hw[0], args.faces_per_frame))
                    if workload == "pipeline" else ("configs[1] landmark-only: %d pre-cropped 256x256 faces per GPU per step" % args.batch),
-                   "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU, no data-path collective" % (world, lanes),
+                   "faces_per_step_per_gpu": faces_per_step, "parallelism": "frame-sharded x%d GPUs, %d HIP streams per GPU%s, no data-path collective" % (
+                       world, lanes, " (pf_batch_run_frames: one call per step, lanes inside the library)" if lanes > 1 else ""),
                    "unique_frames_per_gpu": getattr(state, "unique_frames", None),
                    "results": "counts/boxes/landmarks/scores copied to page-locked host memory inside every step" if workload == "pipeline" else "device resident",
                    "weights": "synthetic (reference .onnx blobs absent), %s: %.1f MB%s" % (
@@ -598,6 +636,9 @@ def main():
                   "hbm_ops": hbm_ops_table(prof, PROF_STEPS, frames_per_launch, faces_per_launch, tuple(args.frame_hw), args.faces_per_frame) if workload == "pipeline" else None,
                   "dense_kernels": dense_kernel_table(prof, PROF_STEPS, faces_per_launch, args.dtype) if args.model == "student" else None,
                   "sustained": sustained,
+                  # what ONE engine / one stream delivers on a lane's share of the step (plain pf_run_frames, graph replay);
+                  # the headline is pf_batch_run_frames over `lanes` of them
+                  "one_lane_faces_per_s": one_lane,
                   "latency": latency,
                   "pcie_inclusive": pcie, "jpeg_ingest": jpeg,
                   "weight_broadcast": bcast,

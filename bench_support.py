@@ -200,25 +200,8 @@ class PipelineWorkload:
         self.graph = bool(graph)
         self.H, self.W = frame_hw                            # (2160, 3840) x 32 faces = BASELINE config 5 / SURVEY C5
         eng.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)   # replay the step from a captured hipGraph
-        base_frames, base_rows = [], []
-        for i in range(min(frames, 2)):
-            if faces_per_frame == 32:
-                fr, boxes = make_frame_grid(self.H, self.W, 8, 4, seed=seed + i)
-            else:
-                fr, boxes = make_frame(self.H, self.W, faces_per_frame, seed=seed + i)
-            base_frames.append(fr)
-            base_rows.append(plant_rows(boxes, (self.H, self.W), self.ROWS, (384, 640), 24, seed=seed + i))
-        reps = (frames + len(base_frames) - 1) // len(base_frames)
-        self.frames = torch.from_numpy(np.stack((base_frames * reps)[:frames])).to(dev)
-        # every frame slot gets its own pixels (+-3 of per-frame noise on top of the two base scenes), so the step
-        # reads F distinct frames from HBM instead of two cache-resident ones (96 x 6.2 MB = 597 MB > the 256 MB L3)
-        gen = torch.Generator(device=dev)
-        gen.manual_seed(1000 + seed)
-        for i in range(frames):
-            nz = torch.randint(-3, 4, self.frames[i].shape, dtype=torch.int16, device=dev, generator=gen)
-            self.frames[i] = (self.frames[i].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
+        self.frames, self.rows = self.synth_inputs(dev, frames, faces_per_frame, seed, frame_hw)
         self.unique_frames = frames
-        self.rows = torch.from_numpy(np.stack((base_rows * reps)[:frames])).to(dev)
         n = frames * faces_per_frame
         self.counts = torch.zeros((frames,), dtype=torch.int32, device=dev)
         self.boxes = torch.zeros((n, 4), dtype=torch.float32, device=dev)
@@ -233,6 +216,33 @@ class PipelineWorkload:
         for a in (self.h_counts, self.h_boxes, self.h_kps, self.h_scores):
             a[...] = 0
         torch.cuda.synchronize()
+
+    @staticmethod
+    def synth_inputs(dev, frames: int, faces_per_frame: int, seed: int, frame_hw):
+        """(frames uint8 [F,H,W,3], planted rows f32 [F,15120,16]) on the device: two base scenes tiled over the slots, every
+        slot with its own +-3 of pixel noise so a step reads F distinct frames from HBM."""
+        import torch
+        from peppa_pig_face_landmark_amd.synth import make_frame, make_frame_grid, plant_rows
+        H, W = frame_hw
+        base_frames, base_rows = [], []
+        for i in range(min(frames, 2)):
+            if faces_per_frame == 32:
+                fr, boxes = make_frame_grid(H, W, 8, 4, seed=seed + i)
+            else:
+                fr, boxes = make_frame(H, W, faces_per_frame, seed=seed + i)
+            base_frames.append(fr)
+            base_rows.append(plant_rows(boxes, (H, W), PipelineWorkload.ROWS, (384, 640), 24, seed=seed + i))
+        reps = (frames + len(base_frames) - 1) // len(base_frames)
+        frames_t = torch.from_numpy(np.stack((base_frames * reps)[:frames])).to(dev)
+        # every frame slot gets its own pixels (+-3 of per-frame noise on top of the two base scenes), so the step
+        # reads F distinct frames from HBM instead of two cache-resident ones (96 x 6.2 MB = 597 MB > the 256 MB L3)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(1000 + seed)
+        for i in range(frames):
+            nz = torch.randint(-3, 4, frames_t[i].shape, dtype=torch.int16, device=dev, generator=gen)
+            frames_t[i] = (frames_t[i].to(torch.int16) + nz).clamp_(0, 255).to(torch.uint8)
+        rows_t = torch.from_numpy(np.stack((base_rows * reps)[:frames])).to(dev)
+        return frames_t, rows_t
 
     def step(self):
         self.eng.run_frames_device(self.frames.data_ptr(), self.F, self.H, self.W, 0.5, 0.3, 1600.0, self.K,
@@ -320,69 +330,158 @@ class PipelineWorkload:
     sync = LandmarkWorkload.sync
 
 
-class MultiLanePipeline:
-    """`lanes` independent engines (one HIP stream + one arena each) on the SAME GPU, each taking an
-    equal share of the step's frames.  Launches are asynchronous, so enqueueing lane after lane from one
-    host thread lets the GPU overlap the many small kernels of one lane (detector, gates, NMS) with the
-    large ones of the others: 34.9 k / 39.2 k / 40.4 k / 39.1 k faces/s at 1 / 2 / 3 / 4 lanes (32 frames per lane) on MI355X."""
+class BatchPipelineWorkload:
+    """BASELINE configs[2] on the product's multi-lane runner (``_native.BatchEngine`` = ``pf_batch_*`` of the C ABI,
+    the engine behind ``FrameBatchRunner``): ONE ``pf_batch_run_frames`` call per step; the library splits the frames
+    into contiguous per-lane slices and runs them on its own HIP streams.  This file only synthesises the inputs, owns
+    the result buffers and compares -- the orchestration that produces the headline is the package's.
+    (34.9 k / 39.2 k / 40.4 k / 39.1 k faces/s at 1 / 2 / 3 / 4 lanes of 32 frames in round 1.)"""
 
-    def __init__(self, make_engine, blobs, dev, frames: int, faces_per_frame: int, seed: int, lanes: int = 2,
+    ROWS = 15120
+
+    def __init__(self, batch, dev, frames: int, faces_per_frame: int, seed: int, lanes: int,
                  graph: bool = True, frame_hw: Tuple[int, int] = (1080, 1920)):
+        import torch
         assert frames % lanes == 0
-        self.lanes = []
-        per = frames // lanes
-        for i in range(lanes):
-            eng = make_engine()
-            load_programs(eng, blobs, "pipeline", per * faces_per_frame, per)
-            self.lanes.append(PipelineWorkload(eng, dev, per, faces_per_frame, seed + 101 * i, graph=graph, frame_hw=frame_hw))
+        self.batch, self.F, self.K, self.L = batch, frames, faces_per_frame, lanes
+        self.per = frames // lanes
+        self.H, self.W = frame_hw
+        self.graph = bool(graph)
+        batch.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)
+        # the same per-lane scenes as the per-engine workload used to build (seed + 101 * lane), concatenated in lane order
+        parts = [PipelineWorkload.synth_inputs(dev, self.per, faces_per_frame, seed + 101 * i, frame_hw) for i in range(lanes)]
+        self.frames = torch.cat([p[0] for p in parts])
+        self.rows = torch.cat([p[1] for p in parts])
+        del parts
+        self.unique_frames = frames
+        n = frames * faces_per_frame
+        self.counts = torch.zeros((frames,), dtype=torch.int32, device=dev)
+        self.boxes = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        self.kps = torch.zeros((n, 98, 2), dtype=torch.float32, device=dev)
+        self.scores = torch.zeros((n, 98), dtype=torch.float32, device=dev)
+        self.h_counts = batch.pinned_empty((frames,), np.int32)
+        self.h_boxes = batch.pinned_empty((n, 4), np.float32)
+        self.h_kps = batch.pinned_empty((n, 98, 2), np.float32)
+        self.h_scores = batch.pinned_empty((n, 98), np.float32)
+        for a in (self.h_counts, self.h_boxes, self.h_kps, self.h_scores):
+            a[...] = 0
+        torch.cuda.synchronize()
+
+    def _run(self, to_host: bool):
+        c, b, k, s = ((self.h_counts.ctypes.data, self.h_boxes.ctypes.data, self.h_kps.ctypes.data, self.h_scores.ctypes.data) if to_host
+                      else (self.counts.data_ptr(), self.boxes.data_ptr(), self.kps.data_ptr(), self.scores.data_ptr()))
+        self.batch.run_frames_device(self.frames.data_ptr(), self.F, self.H, self.W, 0.5, 0.3, 1600.0, self.K,
+                                     d_planted=self.rows.data_ptr(), rows=self.ROWS, d_counts=c, d_boxes=b, d_kps=k, d_scores=s,
+                                     out_mem=_native.PF_MEM_HOST_PINNED if to_host else _native.PF_MEM_DEVICE)
 
     def step(self):
-        for wl in self.lanes:
-            wl.step()
+        self._run(True)
 
     def sync(self):
-        for wl in self.lanes:
-            wl.eng.sync()
-
-    @property
-    def unique_frames(self):
-        return sum(wl.unique_frames for wl in self.lanes)
+        self.batch.sync()
 
     def check(self, compare_eager: bool = True):
-        for wl in self.lanes:
-            wl.check(compare_eager)
+        self.batch.sync()
+        if os.environ.get("PEPPA_DBG"):
+            return
+        assert bool((self.h_counts == self.K).all()), "NMS did not return the planted faces: %s" % self.h_counts.tolist()
+        assert bool(np.isfinite(self.h_kps).all()) and bool(np.isfinite(self.h_scores).all()), "non-finite landmarks"
+        assert float(np.abs(self.h_kps).max()) > 0.0, "results never reached the host buffers"
+        if self.graph and compare_eager:      # graph replay == the same inputs launched eagerly, bit for bit
+            self.batch.set_option(_native.PF_OPT_HIP_GRAPH, 0)
+            try:
+                self._run(False)
+                self.batch.sync()
+            finally:
+                self.batch.set_option(_native.PF_OPT_HIP_GRAPH, 1)
+            for name, host, dev_t in (("counts", self.h_counts, self.counts), ("boxes", self.h_boxes, self.boxes),
+                                      ("landmarks", self.h_kps, self.kps), ("scores", self.h_scores, self.scores)):
+                assert np.array_equal(host, dev_t.cpu().numpy()), "graph replay and eager launch disagree on " + name
 
-    def enable_host_frames(self):
-        for wl in self.lanes:
-            wl.enable_host_frames()
-
-    def step_host(self):
-        for wl in self.lanes:
-            wl.step_host()
-
-    def enable_jpeg_frames(self, quality: int = 90, restart_rows: int = 0):
-        return sum(wl.enable_jpeg_frames(quality, restart_rows) for wl in self.lanes)
-
-    def step_jpeg(self, threads: int):
-        """Every lane decodes and runs its files from its own host thread (the decode call blocks on the Huffman stage; ctypes
-        releases the GIL), so one lane's host work overlaps the others' kernels."""
-        from concurrent.futures import ThreadPoolExecutor
-        if not hasattr(self, "_pool"):
-            self._pool = ThreadPoolExecutor(len(self.lanes))
-        list(self._pool.map(lambda wl: wl.step_jpeg(threads), self.lanes))
+    # ---- probes (never the headline) ------------------------------------------------------------------------------------------
+    def _lane_args(self, i: int):
+        f0 = i * self.per
+        return dict(d_planted=self.rows[f0:].data_ptr(), rows=self.ROWS, d_counts=self.counts[f0:].data_ptr(),
+                    d_boxes=self.boxes[f0 * self.K:].data_ptr(), d_kps=self.kps[f0 * self.K:].data_ptr(),
+                    d_scores=self.scores[f0 * self.K:].data_ptr())
 
     def profile(self, steps: int):
-        """Per-kernel HIP-event times of lane 0 running ALONE (profiling serialises its launches);
-        times are for that lane's share of the step."""
-        for wl in self.lanes:
-            wl.eng.sync()
-        return self.lanes[0].profile(steps)
+        """Per-kernel HIP-event times of lane 0 running ALONE on its slice (profiling serialises its launches)."""
+        self.batch.sync()
+        eng = self.batch.lane(0)
+        eng.profile_enable(True)
+        for _ in range(steps):
+            eng.run_frames_device(self.frames.data_ptr(), self.per, self.H, self.W, 0.5, 0.3, 1600.0, self.K, **self._lane_args(0))
+        eng.sync()
+        prof = eng.profile_fetch()
+        eng.profile_enable(False)
+        return prof
+
+    def one_lane_rate(self, steps: int):
+        """faces/s of ONE lane (one engine, one stream: what a plain pf_run_frames user gets) on its slice, graph replay."""
+        import time
+        self.batch.sync()
+        eng = self.batch.lane(0)
+        for _ in range(2):
+            eng.run_frames_device(self.frames.data_ptr(), self.per, self.H, self.W, 0.5, 0.3, 1600.0, self.K, **self._lane_args(0))
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.run_frames_device(self.frames.data_ptr(), self.per, self.H, self.W, 0.5, 0.3, 1600.0, self.K, **self._lane_args(0))
+        eng.sync()
+        return self.per * self.K * steps / (time.perf_counter() - t0)
 
     def latency_p50(self, frames: int, reps: int = 40):
-        for wl in self.lanes:
-            wl.eng.sync()
-        return self.lanes[0].latency_p50(frames, reps)
+        import time
+        self.batch.sync()
+        eng = self.batch.lane(0)
+        frames = min(frames, self.per)
+        ts = []
+        for _ in range(reps + 5):
+            t0 = time.perf_counter()
+            eng.run_frames_device(self.frames.data_ptr(), frames, self.H, self.W, 0.5, 0.3, 1600.0, self.K, **self._lane_args(0))
+            eng.sync()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts = sorted(ts[5:])
+        return ts[len(ts) // 2], ts[min(len(ts) - 1, int(len(ts) * 0.99))]
+
+    def enable_host_frames(self):
+        self.host_frames = self.batch.pinned_empty((self.F, self.H, self.W, 3), np.uint8)
+        self.host_frames[...] = self.frames.cpu().numpy()
+
+    def step_host(self):
+        self.batch.run_frames_host_async(self.host_frames, self.rows.data_ptr(), self.ROWS, 0.5, 0.3, 1600.0, self.K,
+                                         self.counts.data_ptr(), self.boxes.data_ptr(), self.kps.data_ptr(), self.scores.data_ptr())
+
+    def enable_jpeg_frames(self, quality: int = 90, restart_rows: int = 0):
+        import io
+        from PIL import Image
+        fr = self.frames.cpu().numpy()
+        self.jpegs = []
+        for i in range(self.F):
+            buf = io.BytesIO()
+            Image.fromarray(np.ascontiguousarray(fr[i][..., ::-1])).save(buf, format="JPEG", quality=quality, subsampling=2,
+                                                                        **(dict(restart_marker_rows=restart_rows) if restart_rows else {}))
+            self.jpegs.append(buf.getvalue())
+        return sum(len(j) for j in self.jpegs)
+
+    def step_jpeg(self, threads: int):
+        """Every lane decodes its files (pf_decode_jpeg_batch) and runs them from its own host thread (the decode call blocks on
+        the host-side stage; ctypes releases the GIL), so one lane's host work overlaps the others' kernels."""
+        from concurrent.futures import ThreadPoolExecutor
+        if not hasattr(self, "_pool"):
+            self._pool = ThreadPoolExecutor(self.L)
+
+        def one(i):
+            eng = self.batch.lane(i)
+            f0 = i * self.per
+            d, n, h, w = eng.decode_jpeg_batch(self.jpegs[f0:f0 + self.per], threads)
+            assert (n, h, w) == (self.per, self.H, self.W)
+            eng.run_frames_device(d, self.per, h, w, 0.5, 0.3, 1600.0, self.K, d_planted=self.rows[f0:].data_ptr(), rows=self.ROWS,
+                                  d_counts=self.h_counts[f0:].ctypes.data, d_boxes=self.h_boxes[f0 * self.K:].ctypes.data,
+                                  d_kps=self.h_kps[f0 * self.K:].ctypes.data, d_scores=self.h_scores[f0 * self.K:].ctypes.data,
+                                  out_mem=_native.PF_MEM_HOST_PINNED)
+        list(self._pool.map(one, range(self.L)))
 
     def close(self):
-        for wl in self.lanes:
-            wl.eng.close()
+        self.batch.close()

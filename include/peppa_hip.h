@@ -227,6 +227,30 @@ int pf_broadcast_weights(pf_handle* h, const void* rccl_unique_id, int rank, int
                          void* blob, size_t capacity, size_t* bytes, int max_batch, float* bcast_ms);
 int pf_comm_destroy(pf_handle* h);
 
+/* ---- multi-lane batch runner ---------------------------------------------------------------------------------------------
+ * FaceAna.run() is a per-frame call (Skps/core/api/facer.py:52-85) and the reference never wrote a batch path
+ * (face_landmark.py:119).  A pf_batch owns `lanes` engines -- one HIP stream, one activation arena and one graph cache
+ * each -- on ONE device and hands every call's frames to them as contiguous slices (lane i: frames [i * ceil(F / lanes), ...)),
+ * so the small kernels of one lane's detector overlap the large landmark kernels of the others.  This is the configuration
+ * bench.py measures (three lanes of 32 frames).  Semantics and argument meaning of pf_batch_run_frames are those of
+ * pf_run_frames_planted (det_rows == NULL: the detector's own rows); outputs cover all n_frames in frame order.  With
+ * out_mem == PF_MEM_DEVICE / PF_MEM_HOST_PINNED the call returns after enqueueing (results complete after pf_batch_sync);
+ * with PF_MEM_HOST it synchronises.  pf_batch_lane() exposes a lane's handle (owned by the batch) for pf_profile_* and
+ * the stage-level entry points; max_batch_per_lane of pf_batch_load_program bounds the frames (detector slot) / faces
+ * (landmark slot) of ONE lane's slice. */
+typedef struct pf_batch pf_batch;
+int pf_batch_create(int device_id, int lanes, pf_batch** out);
+void pf_batch_destroy(pf_batch* b);
+const char* pf_batch_last_error(pf_batch* b);
+int pf_batch_lanes(pf_batch* b);
+pf_handle* pf_batch_lane(pf_batch* b, int lane);
+int pf_batch_load_program(pf_batch* b, int slot, const void* blob, size_t bytes, int max_batch_per_lane);
+int pf_batch_set_option(pf_batch* b, int option, int value);
+int pf_batch_sync(pf_batch* b);
+int pf_batch_run_frames(pf_batch* b, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                        const float* det_rows, int rows, float score_thres, float iou_thres, float min_face, int top_k,
+                        int* counts, float* boxes, float* kps, float* scores, int out_mem);
+
 /* Engine options.  PF_OPT_HIP_GRAPH = 1: pf_run_frames* calls whose buffers all live on the device are captured
  * into a hipGraph per distinct (pointers, shapes, thresholds) and replayed (launch-latency bound small batches). */
 enum { PF_OPT_HIP_GRAPH = 1,

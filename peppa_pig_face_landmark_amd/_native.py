@@ -80,6 +80,20 @@ def _declare(lib):
     lib.pf_rccl_version.argtypes = [ip]
     lib.pf_broadcast_weights.argtypes = [vp, vp, i, i, i, vp, sz, C.POINTER(sz), i, fp]
     lib.pf_comm_destroy.argtypes = [vp]
+    lib.pf_batch_create.argtypes = [i, i, C.POINTER(vp)]
+    lib.pf_batch_destroy.argtypes = [vp]
+    lib.pf_batch_destroy.restype = None
+    lib.pf_batch_last_error.argtypes = [vp]
+    lib.pf_batch_last_error.restype = C.c_char_p
+    lib.pf_batch_lanes.argtypes = [vp]
+    lib.pf_batch_lane.argtypes = [vp, i]
+    lib.pf_batch_lane.restype = vp
+    lib.pf_batch_load_program.argtypes = [vp, i, vp, sz, i]
+    lib.pf_batch_set_option.argtypes = [vp, i, i]
+    lib.pf_batch_sync.argtypes = [vp]
+    lib.pf_batch_run_frames.argtypes = [vp, vp, i, i, i, i, vp, i, f, f, f, i, vp, vp, vp, vp, i]
+    for name in ("pf_batch_create", "pf_batch_lanes", "pf_batch_load_program", "pf_batch_set_option", "pf_batch_sync", "pf_batch_run_frames"):
+        getattr(lib, name).restype = i
     for name in ("pf_comm_unique_id", "pf_rccl_version", "pf_broadcast_weights", "pf_comm_destroy"):
         getattr(lib, name).restype = i
     for name in ("pf_create", "pf_sync", "pf_load_program", "pf_landmark_forward", "pf_detector_forward",
@@ -171,7 +185,8 @@ class Engine:
             self.lib.pf_host_free(p)
         self._pinned = []
         if getattr(self, "h", None) is not None and self.h:
-            self.lib.pf_destroy(self.h)
+            if not getattr(self, "_borrowed", False):      # a lane of a BatchEngine belongs to its pf_batch
+                self.lib.pf_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -517,3 +532,107 @@ class Engine:
         self._check(self.lib.pf_profile_fetch(self.h, names, 16384, ms, cnt, cap, C.byref(n)), "pf_profile_fetch")
         tags = [t for t in names.value.decode().split("\n") if t]
         return {tags[k]: (float(ms[k]), int(cnt[k])) for k in range(n.value)}
+
+
+class BatchEngine:
+    """``lanes`` engines (one HIP stream + one arena each) on ONE GPU behind one call: ``pf_batch_*`` of the C ABI.
+    Every ``run_frames*`` call hands its frames to the lanes as contiguous slices; launches are asynchronous, so the lanes'
+    kernels overlap on the device.  The reference has no batch path (face_landmark.py:119); this is the configuration
+    ``bench.py`` measures."""
+
+    def __init__(self, device: int = 0, lanes: int = 3, library: Optional[str] = None):
+        self.lib = load_library(library)
+        self.b = C.c_void_p()
+        if self.lib.pf_batch_create(int(device), int(lanes), C.byref(self.b)) != 0:
+            msg = self.lib.pf_batch_last_error(None)
+            raise PeppaHipError("pf_batch_create failed: " + (msg.decode() if msg else "unknown"))
+        self.device, self.lanes = device, int(lanes)
+        self._lane_engines = {}
+        self._host = Engine.__new__(Engine)          # page-locked allocations only (pf_host_alloc needs no handle)
+        self._host.lib, self._host.h, self._host._borrowed = self.lib, None, True
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.pf_batch_last_error(self.b)
+            raise PeppaHipError(f"{what} failed: " + (msg.decode() if msg else "unknown"))
+
+    def lane(self, i: int) -> "Engine":
+        """Lane ``i`` as an ``Engine`` (profiling, stage-level calls); the handle stays owned by the batch."""
+        if i not in self._lane_engines:
+            h = self.lib.pf_batch_lane(self.b, int(i))
+            if not h:
+                raise PeppaHipError("pf_batch_lane(%d): no such lane" % i)
+            e = Engine.__new__(Engine)
+            e.lib, e.h, e.device, e._programs, e._borrowed = self.lib, C.c_void_p(h), self.device, {}, True
+            self._lane_engines[i] = e
+        return self._lane_engines[i]
+
+    def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        return self._host.pinned_empty(shape, dtype)
+
+    def load_program(self, slot: int, blob: bytes, max_batch_per_lane: int):
+        buf = C.create_string_buffer(blob, len(blob))
+        self._check(self.lib.pf_batch_load_program(self.b, slot, C.cast(buf, C.c_void_p), len(blob), int(max_batch_per_lane)),
+                    "pf_batch_load_program")
+
+    def set_option(self, option: int, value: int):
+        self._check(self.lib.pf_batch_set_option(self.b, int(option), int(value)), "pf_batch_set_option")
+
+    def sync(self):
+        self._check(self.lib.pf_batch_sync(self.b), "pf_batch_sync")
+
+    def run_frames_device(self, d_frames: int, F: int, H: int, W: int, score_thres: float, iou_thres: float, min_face: float,
+                          top_k: int, d_planted: int = 0, rows: int = 0, d_counts: int = 0, d_boxes: int = 0, d_kps: int = 0,
+                          d_scores: int = 0, out_mem: int = PF_MEM_DEVICE):
+        """Device-resident frames in; results to device buffers or page-locked host buffers (``out_mem``), no synchronisation."""
+        rc = self.lib.pf_batch_run_frames(self.b, _ptr(d_frames), PF_MEM_DEVICE, F, H, W, _ptr(d_planted) if d_planted else None,
+                                          rows, score_thres, iou_thres, min_face, top_k, _ptr(d_counts) if d_counts else None,
+                                          _ptr(d_boxes) if d_boxes else None, _ptr(d_kps) if d_kps else None,
+                                          _ptr(d_scores) if d_scores else None, out_mem)
+        self._check(rc, "pf_batch_run_frames")
+
+    def run_frames_host_async(self, frames: np.ndarray, d_planted: int, rows: int, score_thres: float, iou_thres: float,
+                              min_face: float, top_k: int, d_counts: int, d_boxes: int, d_kps: int, d_scores: int):
+        """Host-resident frames (ideally from pinned_empty) in, device-resident results out, no synchronisation: every lane
+        copies its slice on its own stream, so one lane's copy overlaps the others' kernels.  Planted detector rows
+        (benchmark instrument) are a device pointer."""
+        F, H, W, _ = frames.shape
+        assert frames.dtype == np.uint8 and frames.flags["C_CONTIGUOUS"]
+        rc = self.lib.pf_batch_run_frames(self.b, _ptr(frames), PF_MEM_HOST | PF_MEM_ROWS_DEVICE, F, H, W,
+                                          _ptr(d_planted) if d_planted else None, rows, score_thres, iou_thres, min_face, top_k,
+                                          _ptr(d_counts), _ptr(d_boxes), _ptr(d_kps), _ptr(d_scores), PF_MEM_DEVICE)
+        self._check(rc, "pf_batch_run_frames")
+
+    def run_frames(self, frames: np.ndarray, score_thres: float, iou_thres: float, min_face: float, top_k: int,
+                   planted_rows: Optional[np.ndarray] = None):
+        """Host frames ``[F,H,W,3]`` uint8 in, numpy results out (synchronous): counts [F], boxes [F,top_k,4],
+        landmarks [F,top_k,98,2], scores [F,top_k,98]; rows of a frame beyond its count are undefined."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        F, H, W, _ = frames.shape
+        counts = np.zeros((F,), np.int32)
+        boxes = np.zeros((F, top_k, 4), np.float32)
+        kps = np.zeros((F, top_k, 98, 2), np.float32)
+        scores = np.zeros((F, top_k, 98), np.float32)
+        rows, pr = 0, None
+        if planted_rows is not None:
+            pr = np.ascontiguousarray(planted_rows, np.float32)
+            rows = pr.shape[1]
+        rc = self.lib.pf_batch_run_frames(self.b, _ptr(frames), PF_MEM_HOST, F, H, W, _ptr(pr), rows, score_thres, iou_thres,
+                                          min_face, top_k, _ptr(counts), _ptr(boxes), _ptr(kps), _ptr(scores), PF_MEM_HOST)
+        self._check(rc, "pf_batch_run_frames")
+        return counts, boxes, kps, scores
+
+    def close(self):
+        self._host.close()
+        for e in self._lane_engines.values():
+            e.close()
+        self._lane_engines = {}
+        if getattr(self, "b", None) is not None and self.b:
+            self.lib.pf_batch_destroy(self.b)
+            self.b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

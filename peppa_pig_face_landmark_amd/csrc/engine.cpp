@@ -18,6 +18,7 @@
 #include "k_layers.h"
 #include "k_mbconv.h"
 #include "k_chain.h"
+#include "k_det.h"
 #include "k_sepup.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
@@ -150,6 +151,28 @@ struct ProfScope {
 };
 
 // ---------------------------------------------------------------------------------------------
+// Output tile of a workgroup-level detector kernel (k_det.h): the largest-benefit TH x TW whose input region
+// ((TH-1)*S+3) x ((TW-1)*S+3) fits the kernel's MAXR LDS rows.  Cost model: launches of these kernels are chains of a few
+// phases (~3 us of fixed latency = ~768 rows' worth of work), so fewer rounds of workgroups over the chip come first, then
+// the smaller tile; the halo rows every extra tile re-computes count with the chip's width.
+static void det_pick_tile(int outH, int outW, int S, int max_rows, int B, int wg_per_cu, int* TH, int* TW) {
+    double best = 1e30;
+    *TH = 1; *TW = 1;
+    for (int div = 1; div <= 16; ++div) {
+        const int tw = (outW + div - 1) / div;
+        if (div > 1 && tw == (outW + div - 2) / (div - 1)) continue;
+        const int rw = (tw - 1) * S + 3;
+        for (int th = 1; th <= outH; ++th) {
+            const int rows = ((th - 1) * S + 3) * rw;
+            if (rows > max_rows) break;
+            const long long wgs = (long long)B * ((outH + th - 1) / th) * ((outW + tw - 1) / tw);
+            const long long rounds = (wgs + (long long)kNumCUs * wg_per_cu - 1) / ((long long)kNumCUs * wg_per_cu);
+            const double cost = (double)rounds * (768.0 + rows) + 0.5 * (double)wgs * rows / kNumCUs;
+            if (cost < best) { best = cost; *TH = th; *TW = tw; }
+        }
+    }
+}
+
 template <typename T, bool SPLIT>
 static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B, unsigned* range_slot) {
     const int32_t* f = op.f;
@@ -434,6 +457,119 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     PF_MBCONV_CASE(1, 3, 4, 8, 5, 4)
                     PF_FAIL(h, "mbconv: no kernel for stride %d, %d input channels, %d output channels", S, a.Cin, a.Cout);
 #undef PF_MBCONV_CASE
+                }
+                break;
+            }
+            case PF_OP_DETUNIT: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused ShuffleV2Block op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    DetUnitArgs a{};
+                    a.in = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.w1 = (const pf_half*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]);
+                    a.wd = (const float*)p.cptr(f[4]); a.bd = (const float*)p.cptr(f[5]);
+                    a.w2 = (const pf_half*)p.cptr(f[6]); a.b2 = (const float*)p.cptr(f[7]);
+                    a.wd1 = (const float*)p.cptr(f[8]); a.bd1 = (const float*)p.cptr(f[9]);
+                    a.w3 = (const pf_half*)p.cptr(f[10]); a.b3 = (const float*)p.cptr(f[11]);
+                    memcpy(&a.s1, &f[12], 4); memcpy(&a.s2, &f[13], 4); memcpy(&a.s3, &f[14], 4);
+                    const int C = f[15], K1 = f[16], S = f[17];
+                    a.Cin = f[18];
+                    a.B = B; a.inH = ti.H; a.inW = ti.W; a.inLd = ti.ld; a.outH = to.H; a.outW = to.W; a.outLd = to.ld;
+                    a.range_slot = slot_of(oi);
+                    if (host_dbg(h) & 4096) {      // per-phase cycle accounting of det_unit_kernel (ablation build; printed at pf_destroy)
+                        if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
+                        a.prof = h->d_dbg + 64 + 8 * ((C == 32 ? 0 : (C == 64 ? 1 : 2)) + 3 * (S - 1));
+                    }
+                    if (to.C != 2 * C || ti.C != a.Cin || (S != 1 && S != 2) || to.H != (ti.H - 1) / S + 1 || to.W != (ti.W - 1) / S + 1 ||
+                        (S == 1 && a.Cin != 2 * C) || (S == 2 && !a.w3))
+                        PF_FAIL(h, "detunit: inconsistent shapes");
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "unit_s%d_c%d_%dx%d", S, C, to.H, to.W);
+                    ProfScope ps(h, tagbuf);
+#define PF_DETUNIT_CASE(CC, KK, SS, MAXR, NTHR, PERCU)                                                             \
+    if (C == CC && K1 == KK && S == SS) {                                                                          \
+        det_pick_tile(to.H, to.W, SS, MAXR, B, PERCU, &a.TH, &a.TW);                                               \
+        a.tilesX = pf_div_up(to.W, a.TW);                                                                          \
+        PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR>), dim3(a.tilesX * pf_div_up(to.H, a.TH), B), dim3(NTHR), h->stream, a); \
+    } else
+                    PF_DETUNIT_CASE(32, 32, 1, 288, 512, 2)
+                    PF_DETUNIT_CASE(64, 64, 1, 144, 512, 2)
+                    PF_DETUNIT_CASE(128, 128, 1, 144, 512, 1)
+                    PF_DETUNIT_CASE(32, 32, 2, 576, 1024, 1)
+                    PF_DETUNIT_CASE(64, 64, 2, 288, 512, 1)
+                    PF_DETUNIT_CASE(128, 128, 2, 144, 512, 1)
+                    PF_FAIL(h, "detunit: no kernel for %d branch channels, K %d, stride %d", C, K1, S);
+#undef PF_DETUNIT_CASE
+                }
+                break;
+            }
+            case PF_OP_DETSTEM: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused StemBlock op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& to = p.tens[f[0]];
+                    DetStemArgs a{};
+                    a.in = d_input; a.in_f32_nchw = input_kind == PF_INPUT_F32_NCHW ? 1 : 0;
+                    a.out = (float*)p.tensor_ptr(f[0]); a.outLd = to.ld;
+                    a.w1_u8 = (const pf_half*)p.cptr(f[1]); a.w1_f32 = (const pf_half*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]);
+                    a.w2a = (const pf_half*)p.cptr(f[4]); a.b2a = (const float*)p.cptr(f[5]);
+                    a.w2b = (const pf_half*)p.cptr(f[6]); a.b2b = (const float*)p.cptr(f[7]);
+                    a.w3 = (const pf_half*)p.cptr(f[8]); a.b3 = (const float*)p.cptr(f[9]);
+                    memcpy(&a.s1_u8, &f[10], 4); memcpy(&a.s1_f32, &f[11], 4); memcpy(&a.s2a, &f[12], 4); memcpy(&a.s2b, &f[13], 4); memcpy(&a.s3, &f[14], 4);
+                    a.B = B; a.H = p.hdr.in_h; a.W = p.hdr.in_w; a.SH = (a.H + 1) / 2; a.SW = (a.W + 1) / 2; a.OH = to.H; a.OW = to.W;
+                    if (to.C != 16 || a.OH != (a.SH + 1) / 2 || a.OW != (a.SW + 1) / 2) PF_FAIL(h, "detstem: inconsistent shapes");
+                    a.TH = 4; a.TW = 16; a.tilesX = pf_div_up(a.OW, a.TW);
+                    a.range_slot = slot_of(oi);
+                    ProfScope ps(h, "stem_block");
+                    // tile 4 x 16: stem_1 region 9 x 33 = 297 (304 rows), image region 19 x 67 = 1273 pixels
+                    PF_LAUNCH((det_stem_kernel<64, 304, 1273, 256>), dim3(a.tilesX * pf_div_up(a.OH, a.TH), B), dim3(256), h->stream, a);
+                }
+                break;
+            }
+            case PF_OP_DETC3: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused C3 op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ta = p.tens[f[0]];
+                    DetC3Args a{};
+                    a.srcA = (const float*)p.tensor_ptr(f[0]); a.ldA = ta.ld; a.CA = ta.C;
+                    if (f[1] >= 0) { a.srcB = (const float*)p.tensor_ptr(f[1]); a.ldB = p.tens[f[1]].ld; }
+                    if (f[2] >= 0) { a.out = (float*)p.tensor_ptr(f[2]); a.outLd = p.tens[f[2]].ld; }
+                    if (f[3] >= 0) { a.out2 = (float*)p.tensor_ptr(f[3]); a.out2Ld = p.tens[f[3]].ld; }
+                    if (f[4] >= 0) a.rows = (float*)p.buf_ptr(f[4]);
+                    a.wA = (const pf_half*)p.cptr(f[5]); a.bA = (const float*)p.cptr(f[6]);
+                    a.wB = (const pf_half*)p.cptr(f[7]); a.bB = (const float*)p.cptr(f[8]);
+                    a.wC = (const pf_half*)p.cptr(f[9]); a.bC = (const float*)p.cptr(f[10]);
+                    a.wD = (const pf_half*)p.cptr(f[11]); a.bD = (const float*)p.cptr(f[12]);
+                    a.wE = (const pf_half*)p.cptr(f[13]); a.bE = (const float*)p.cptr(f[14]);
+                    a.anchors = (const float*)p.cptr(f[15]);
+                    memcpy(&a.sA, &f[16], 4); memcpy(&a.sB, &f[17], 4); memcpy(&a.sC, &f[18], 4); memcpy(&a.sD, &f[19], 4);
+                    memcpy(&a.sE, &f[20], 4); memcpy(&a.det_stride, &f[21], 4);
+                    const int CIN = f[22], tail = f[23];
+                    a.upA = f[24]; a.row0 = f[25]; a.nrows_total = f[26];
+                    a.B = B; a.H = ta.H << a.upA; a.W = ta.W << a.upA;
+                    a.range_slot = slot_of(oi);
+                    const int cb = f[1] >= 0 ? p.tens[f[1]].C : 0;
+                    if (ta.C + cb != CIN || (ta.C % 8) || (f[1] >= 0 && (p.tens[f[1]].H != a.H || p.tens[f[1]].W != a.W)) ||
+                        (tail == 1 && !a.out2) || (tail == 2 && (!a.rows || !a.anchors)))
+                        PF_FAIL(h, "detc3: inconsistent shapes");
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "c3_c%d_t%d_%dx%d", CIN, tail, a.H, a.W);
+                    ProfScope ps(h, tagbuf);
+#define PF_DETC3_CASE(CC, TT, MAXR, NTHR)                                                                          \
+    if (CIN == CC && tail == TT) {                                                                                 \
+        det_pick_tile(a.H, a.W, 1, MAXR, B, 1, &a.TH, &a.TW);                                                      \
+        a.tilesX = pf_div_up(a.W, a.TW);                                                                           \
+        PF_LAUNCH((det_c3_kernel<CC, TT, MAXR, NTHR>), dim3(a.tilesX * pf_div_up(a.H, a.TH), B), dim3(NTHR), h->stream, a); \
+    } else
+                    PF_DETC3_CASE(192, 1, 128, 512)
+                    PF_DETC3_CASE(128, 2, 176, 512)
+                    PF_FAIL(h, "detc3: no kernel for %d input channels, tail %d", CIN, tail);
+#undef PF_DETC3_CASE
                 }
                 break;
             }
@@ -803,6 +939,16 @@ void pf_destroy(pf_handle* h) {
     }
     if (h->d_stage) (void)hipFree(h->d_stage);
     if (h->d_dbg) {
+        unsigned long long u[48];
+        if (hipMemcpy(u, h->d_dbg + 64, sizeof(u), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long* q = u + 8 * k;
+                if (!q[4]) continue;
+                const double n = (double)q[4];
+                fprintf(stderr, "[det_unit C=%d S=%d] per workgroup (cycles): input+split %.0f | gemm1 %.0f | depthwise %.0f | gemm2+store %.0f  (%.0f workgroups)\n",
+                        k % 3 == 0 ? 32 : (k % 3 == 1 ? 64 : 128), k / 3 + 1, q[0] / n, q[1] / n, q[2] / n, q[3] / n, n);
+            }
+        }
         unsigned long long v[32];
         if (hipMemcpy(v, h->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int k = 0; k < 2; ++k) {
@@ -1001,3 +1147,4 @@ int pf_profile_fetch(pf_handle* h, char* names, size_t names_cap, float* ms, int
 #include "comm.inl"
 #include "track.inl"
 #include "jpeg.inl"
+#include "batch.inl"

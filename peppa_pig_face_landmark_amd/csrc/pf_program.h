@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 8
+#define PF_PROGRAM_VERSION 9
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -54,6 +54,15 @@ enum PfOpCode : int32_t {
                         //    convs + identity residual each), one face's map resident in LDS (k_chain.h); split programs only
     PF_OP_BLOCK = 17,   // f: in_t out_t C wt1 b1 s1 wt2 b2 s2 (s = acc_scale float bits): one BasicBlock, TR rows per workgroup, flat-K
                         //    weights (k_chain.h basic_block_kernel); split programs only
+    PF_OP_DETUNIT = 18, // f: in_t out_t w1 b1 wd bd w2 b2 wd1 bd1 w3 b3 s1 s2 s3 (float bits) C K1 stride Cin: a whole ShuffleV2Block of the
+                        //    detector per launch (k_det.h det_unit_kernel); in_t = the block's input (stride 1: both halves), out_t = its
+                        //    2C-channel output (channel shuffle folded into the store); wd1 .. s3 = branch 1 of a stride-2 block; split programs only
+    PF_OP_DETC3 = 19,   // f: srcA_t srcB_t(-1) out_t(-1) out2_t(-1) rows_buf(-1) wA bA wB bB wC bC wD bD wE bE anchors sA sB sC sD sE stride (float
+                        //    bits) CIN tail upA row0 nrows_total: a C3 block of the detector's PAN head per launch (k_det.h det_c3_kernel) on the
+                        //    concatenation [srcA (nearest x2 upsampled if upA) | srcB]; tail 1 = + a 1x1 conv (silu) into out2, tail 2 = + the
+                        //    Detect conv (raw output into out2 if given) and its decode into rows_buf; split programs only
+    PF_OP_DETSTEM = 20, // f: out_t w1_u8 w1_f32 b1 w2a b2a w2b b2b w3 b3 s1_u8 s1_f32 s2a s2b s3 (float bits): the detector's StemBlock (stem_1 3x3 s2,
+                        //    stem_2a 1x1, stem_2b 3x3 s2, max-pool, stem_3 1x1) in one launch on the program input (k_det.h det_stem_kernel)
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

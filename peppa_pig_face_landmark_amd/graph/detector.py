@@ -34,7 +34,9 @@ def _bn(w, prefix):
 
 
 def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, int] = (384, 640),
-                           dtype: str = "f32", keep_all: bool = False, fuse_units: bool = True):
+                           dtype: str = "f32", keep_all: bool = False, fuse_units: bool = True, wg_units: bool = True):
+    """``wg_units`` (f32s programs): every ShuffleV2Block is ONE workgroup-level launch (csrc/k_det.h); ``fuse_units`` alone
+    keeps round 1's wave-per-patch kernel for the stride-1 blocks and runs the stride-2 ones layer by layer."""
     w = weights
     H, W = input_hw
     assert H % 32 == 0 and W % 32 == 0
@@ -48,14 +50,20 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
         return pb.conv(x, wt, b, "silu", stride=s, pad=k // 2, out=out, out_name=name or prefix)
 
     # ---- StemBlock ------------------------------------------------------------------------------
+    if wg_units and fuse_units and pb.split:
+        x = pb.det_stem(*fconv("model.0.stem_1"), *fconv("model.0.stem_2a"), *fconv("model.0.stem_2b"), *fconv("model.0.stem_3"),
+                        out_name="model.0")
+    else:
+        x = None
     wt, b = fconv("model.0.stem_1")
-    s1 = pb.stem(wt, b, "silu", out_name="model.0.stem_1")
+    s1 = pb.stem(wt, b, "silu", out_name="model.0.stem_1") if x is None else -1
     h2, w2 = H // 4, W // 4
-    cat = pb.buffer(h2 * w2 * 32, ir.ELEM_ACT, "stem.cat")
-    s2a = conv(s1, "model.0.stem_2a")
-    conv(s2a, "model.0.stem_2b", 3, 2, out=pb.view(cat, h2, w2, 16, 0, 32))
-    pb.maxpool(s1, out=pb.view(cat, h2, w2, 16, 16, 32))
-    x = conv(pb.view(cat, h2, w2, 32, 0, 32), "model.0.stem_3", name="model.0")
+    if x is None:
+        cat = pb.buffer(h2 * w2 * 32, ir.ELEM_ACT, "stem.cat")
+        s2a = conv(s1, "model.0.stem_2a")
+        conv(s2a, "model.0.stem_2b", 3, 2, out=pb.view(cat, h2, w2, 16, 0, 32))
+        pb.maxpool(s1, out=pb.view(cat, h2, w2, 16, 16, 32))
+        x = conv(pb.view(cat, h2, w2, 32, 0, 32), "model.0.stem_3", name="model.0")
 
     # ---- ShuffleV2 backbone -----------------------------------------------------------------------
     def shuffle_block(x, prefix, inp, oup, stride, name="", into=None):
@@ -68,6 +76,19 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
             out_buf, ocoff, old = pb.buffer(oh * ow * oup, ir.ELEM_ACT, name or prefix), 0, oup
         else:
             out_buf, ocoff, old = into
+        if wg_units and fuse_units and pb.det_unit_supported(bf, tx.C, stride):
+            fb = lambda cw, bn: ir.fold_bn(w[f"{prefix}.{cw}.weight"], None, _bn(w, f"{prefix}.{bn}"), BN_EPS)
+            out_view = pb.view(out_buf, oh, ow, oup, ocoff, old, name=name)
+            w1, b1 = fb("branch2.0", "branch2.1")
+            wd, bd = fb("branch2.3", "branch2.4")
+            w2, b2 = fb("branch2.5", "branch2.6")
+            if stride == 1:
+                pb.det_unit(x, out_view, 1, w1, b1, wd, bd, w2, b2)
+            else:
+                wd1, bd1 = fb("branch1.0", "branch1.1")
+                w3, b3 = fb("branch1.2", "branch1.3")
+                pb.det_unit(x, out_view, 2, w1, b1, wd, bd, w2, b2, wd1, bd1, w3, b3)
+            return out_view
         even = pb.strided_view(out_buf, oh, ow, bf, ocoff + 0, old)
         odd = pb.strided_view(out_buf, oh, ow, bf, ocoff + 1, old)
         if stride == 1 and fuse_units and pb.shuffle_unit_supported(bf):
@@ -99,11 +120,15 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
     # resolution is WRITTEN into its channel slice by its producer (6 of the 8 copy launches of the straightforward graph are
     # gone); only the two nearest-x2 upsampled inputs are still copied
     h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
-    cat9 = pb.buffer(h16 * w16 * 192, ir.ELEM_ACT, "cat9")        # [up(model.7) 64 | model.4 128] @ /16
-    cat13 = pb.buffer(h8 * w8 * 128, ir.ELEM_ACT, "cat13")        # [up(model.11) 64 | model.2 64] @ /8
+    wg_c3 = wg_units and fuse_units and pb.det_c3_supported(192, "conv") and pb.det_c3_supported(128, "detect")
+    if not wg_c3:
+        cat9 = pb.buffer(h16 * w16 * 192, ir.ELEM_ACT, "cat9")        # [up(model.7) 64 | model.4 128] @ /16
+        cat13 = pb.buffer(h8 * w8 * 128, ir.ELEM_ACT, "cat13")        # [up(model.11) 64 | model.2 64] @ /8
     cat16 = pb.buffer(h16 * w16 * 128, ir.ELEM_ACT, "cat16")      # [model.15 64 | model.11 64] @ /16
     cat19 = pb.buffer(h32 * w32 * 128, ir.ELEM_ACT, "cat19")      # [model.18 64 | model.7 64] @ /32
-    into = {2: (cat13, 64, 128), 4: (cat9, 64, 192)}
+    # (with the workgroup-level C3 kernels the Upsample + Concat in front of model.10 / model.14 is never materialised: the
+    # kernel reads its two sources where they lie)
+    into = {} if wg_c3 else {2: (cat13, 64, 128), 4: (cat9, 64, 192)}
 
     feats = {}
     for li, cin, cout, reps in _BACKBONE:
@@ -123,6 +148,39 @@ def build_detector_program(weights: Dict[str, np.ndarray], input_hw: Tuple[int, 
         conv(y1, f"{prefix}.m.0.cv2", 3, 1, out=pb.view(catb, tx.H, tx.W, 32, 0, 64))
         conv(x, f"{prefix}.cv2", out=pb.view(catb, tx.H, tx.W, 32, 32, 64))
         return conv(pb.view(catb, tx.H, tx.W, 64, 0, 64), f"{prefix}.cv3", name=name)
+
+    if wg_c3:
+        levels = [(h8, w8), (h16, w16), (h32, w32)]
+        nrows = sum(3 * hh * ww for hh, ww in levels)
+        rows = pb.buffer(nrows * NO, ir.ELEM_F32, "rows", pinned=True)
+        row_starts = [0, 3 * h8 * w8, 3 * h8 * w8 + 3 * h16 * w16]
+
+        def c3_wg(src_a, src_b, up_a, prefix, **kw):
+            ws = []
+            for part in ("cv1", "cv2", "m.0.cv1", "m.0.cv2", "cv3"):
+                ws.extend(fconv(f"{prefix}.{part}"))
+            pb.det_c3(src_a, src_b, up_a, *ws, **kw)
+
+        def detect_tail(i, hh, ww):
+            raw = pb.tensor(hh, ww, 3 * NO, name=f"model.21.m.{i}") if keep_all else -1
+            return dict(tail="detect", w_tail=w[f"model.21.m.{i}.weight"].astype(np.float64), b_tail=w[f"model.21.m.{i}.bias"].astype(np.float64),
+                        out2=raw, rows_buf=rows, row0=row_starts[i], det_stride=STRIDES[i], anchors=ANCHORS[i], nrows_total=nrows)
+
+        l7 = conv(feats[6], "model.7", out=pb.view(cat19, h32, w32, 64, 64, 128), name="model.7")
+        l11 = pb.view(cat16, h16, w16, 64, 64, 128, name="model.11")
+        w11, b11 = fconv("model.11")
+        c3_wg(l7, feats[4], True, "model.10", tail="conv", w_tail=w11, b_tail=b11, out2=l11)
+        l14 = pb.tensor(h8, w8, 64, name="model.14")
+        c3_wg(l11, feats[2], True, "model.14", out=l14, **detect_tail(0, h8, w8))
+        conv(l14, "model.15", 3, 2, out=pb.view(cat16, h16, w16, 64, 0, 128), name="model.15")
+        l17 = pb.tensor(h16, w16, 64, name="model.17")
+        c3_wg(pb.view(cat16, h16, w16, 128, 0, 128), -1, False, "model.17", out=l17, **detect_tail(1, h16, w16))
+        conv(l17, "model.18", 3, 2, out=pb.view(cat19, h32, w32, 64, 0, 128), name="model.18")
+        l20 = pb.tensor(h32, w32, 64, name="model.20")
+        c3_wg(pb.view(cat19, h32, w32, 128, 0, 128), -1, False, "model.20", out=l20, **detect_tail(2, h32, w32))
+        blob = pb.finish([rows])
+        info = {"tensors": dict(pb.tensor_names), "rows": nrows, "n_ops": len(pb.ops), "dtype": dtype}
+        return blob, info
 
     l7 = conv(feats[6], "model.7", out=pb.view(cat19, h32, w32, 64, 64, 128), name="model.7")
     pb.copy(l7, pb.view(cat9, h16, w16, 64, 0, 192), out_cs=1, up=2)

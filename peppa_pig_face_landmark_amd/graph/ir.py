@@ -17,14 +17,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 8
+VERSION = 9
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK = range(1, 18)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM = range(1, 21)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -328,6 +328,109 @@ class ProgramBuilder:
                              ACT["none"], ACT[act], out_cs, pass_src, pass_dst],
                  [self._tb(x2), self._tb(pass_src)], [self._tb(out), self._tb(pass_dst)])
         return out
+
+    def det_unit_supported(self, c: int, cin: int, stride: int) -> bool:
+        """ShuffleV2Block as ONE workgroup-level launch (csrc/k_det.h det_unit_kernel): branch width c, block input cin."""
+        return self.split and c in (32, 64, 128) and ((stride == 1 and cin == 2 * c) or (stride == 2 and cin in (16, 64, 128) and cin <= c))
+
+    def det_unit(self, x: int, out: int, stride: int, w1: np.ndarray, b1: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray,
+                 w2: np.ndarray, b2: np.ndarray, w_dw1: Optional[np.ndarray] = None, b_dw1: Optional[np.ndarray] = None,
+                 w3: Optional[np.ndarray] = None, b3: Optional[np.ndarray] = None) -> int:
+        """Whole ShuffleV2Block (yolov5-face models/common.py; oracle/detector_net.py::_shuffle_block), BN-folded weights, SiLU:
+        stride 1: out[2i] = x[i], out[2i+1] = silu(pw2(dw(silu(pw1(x[c:])))))[i];
+        stride 2: out[2i] = silu(pw3(dw1(x)))[i], out[2i+1] = branch 2 on all of x.  `out` is a 2c-channel view."""
+        ti, to = self.tensors[x], self.tensors[out]
+        c = w1.shape[0]
+        cin = ti.C
+        assert self.det_unit_supported(c, cin, stride) and to.C == 2 * c and ti.real_c == ti.C
+        assert (to.H, to.W) == ((ti.H - 1) // stride + 1, (ti.W - 1) // stride + 1)
+        cin2 = c if stride == 1 else cin
+        k1 = _round_up(cin2, 32)
+        assert w1.shape[:2] == (c, cin2) and w2.shape[:2] == (c, c) and w_dw.shape == (c, 1, 3, 3)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+
+        def rows(w, k):
+            m = np.zeros((w.shape[0], k), np.float64)
+            m[:, :w.shape[1]] = w.reshape(w.shape[0], -1)
+            return self._split_rows(m)
+        w1s, s1 = rows(w1, k1)
+        w2s, s2 = rows(w2, c)
+        f = [x, out, self.const(w1s), self.const_f32(b1), self.const_f32(w_dw.reshape(c, 9).T), self.const_f32(b_dw),
+             self.const(w2s), self.const_f32(b2)]
+        if stride == 2:
+            assert w_dw1.shape == (cin, 1, 3, 3) and w3.shape[:2] == (c, cin)
+            wd1 = np.zeros((9, k1)); wd1[:, :cin] = w_dw1.reshape(cin, 9).T
+            bd1 = np.zeros(k1); bd1[:cin] = b_dw1
+            w3s, s3 = rows(w3, k1)
+            f += [self.const_f32(wd1), self.const_f32(bd1), self.const(w3s), self.const_f32(b3)]
+        else:
+            s3 = 1.0
+            f += [-1, -1, -1, -1]
+        f += [fbits(s1), fbits(s2), fbits(s3), c, k1, stride, cin]
+        self._op(OP_DETUNIT, f, [self._tb(x)], [self._tb(out)])
+        return out
+
+    def det_stem(self, w1, b1, w2a, b2a, w2b, b2b, w3, b3, out_name: str = "") -> int:
+        """yolov5-face StemBlock on the 3-channel program input in ONE launch (csrc/k_det.h det_stem_kernel), BN-folded weights:
+        stem_1 [16,3,3,3] s2, stem_2a [8,16,1,1], stem_2b [16,8,3,3] s2, stem_3 [16,32,1,1] over cat(stem_2b, maxpool2x2(stem_1))."""
+        assert self.split and w1.shape == (16, 3, 3, 3) and w2a.shape[:2] == (8, 16) and w2b.shape == (16, 8, 3, 3) and w3.shape[:2] == (16, 32)
+        assert self.in_h % 4 == 0 and self.in_w % 4 == 0
+        out = self.tensor(self.in_h // 4, self.in_w // 4, 16, name=out_name)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+
+        def rows(w, n, k):
+            m = np.zeros((n, k), np.float64)
+            m[:w.shape[0], :w.shape[1]] = w
+            return self._split_rows(m)
+        w1r = np.transpose(w1.astype(np.float64), (0, 2, 3, 1)).reshape(16, 27)          # k = (ky*3 + kx)*3 + ci
+        w1u, s1u = rows(w1r / 255.0, 16, 32)
+        w1f, s1f = rows(w1r, 16, 32)
+        wa, sa = rows(w2a.reshape(8, 16).astype(np.float64), 16, 32)
+        wb, sb = rows(np.transpose(w2b.astype(np.float64), (0, 2, 3, 1)).reshape(16, 72), 16, 96)   # k = tap*8 + c
+        wc, sc = rows(w3.reshape(16, 32).astype(np.float64), 16, 32)
+        b2 = np.zeros(16); b2[:8] = b2a
+        self._op(OP_DETSTEM, [out, self.const(w1u), self.const(w1f), self.const_f32(b1), self.const(wa), self.const_f32(b2), self.const(wb),
+                              self.const_f32(b2b), self.const(wc), self.const_f32(b3), fbits(s1u), fbits(s1f), fbits(sa), fbits(sb), fbits(sc)],
+                 [], [self._tb(out)])
+        return out
+
+    def det_c3_supported(self, cin: int, tail: str) -> bool:
+        return self.split and (cin, tail) in ((192, "conv"), (128, "detect"))
+
+    def det_c3(self, src_a: int, src_b: int, up_a: bool, w_cv1, b_cv1, w_cv2, b_cv2, w_m1, b_m1, w_m2, b_m2, w_cv3, b_cv3, *,
+               out: int = -1, tail: str = "none", w_tail=None, b_tail=None, out2: int = -1, rows_buf: int = -1, row0: int = 0,
+               det_stride: float = 0.0, anchors=None, nrows_total: int = 0) -> None:
+        """C3 block (n = 1, shortcut = False; oracle/detector_net.py::_c3) on cat(src_a [nearest x2 upsampled if up_a], src_b) in ONE
+        launch (csrc/k_det.h det_c3_kernel), BN-folded weights, SiLU everywhere.  tail "conv": + a 1x1 conv 64 -> 64 (silu) written
+        to `out2`; tail "detect": + the Detect 1x1 conv (48 outputs, bias, no activation; raw values to `out2` if given) and its
+        decode into rows [row0, row0 + 3 H W) of `rows_buf`."""
+        ta = self.tensors[src_a]
+        tb = self.tensors[src_b] if src_b >= 0 else None
+        H, W = (ta.H * 2, ta.W * 2) if up_a else (ta.H, ta.W)
+        cin = ta.C + (tb.C if tb else 0)
+        assert self.det_c3_supported(cin, tail) and ta.C % 8 == 0 and (tb is None or (tb.H, tb.W) == (H, W))
+        assert w_cv1.shape[:2] == (32, cin) and w_cv2.shape[:2] == (32, cin) and w_m1.shape[:2] == (32, 32) and w_m2.shape == (32, 32, 3, 3)
+        assert w_cv3.shape[:2] == (64, 64)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        wa, sa = self._split_rows(np.concatenate([w_cv1.reshape(32, cin), w_cv2.reshape(32, cin)], 0).astype(np.float64))
+        wb, sb = self._split_rows(w_m1.reshape(32, 32).astype(np.float64))
+        wc_off, npad, cpad, sc, _ = self.pack_conv_weight(w_m2, force_split=True)
+        assert (npad, cpad) == (32, 32)
+        wd, sd = self._split_rows(w_cv3.reshape(64, 64).astype(np.float64))
+        f = [src_a, src_b, out, out2, rows_buf, self.const(wa), self.const_f32(np.concatenate([b_cv1, b_cv2])), self.const(wb), self.const_f32(b_m1),
+             wc_off, self.const_f32(b_m2), self.const(wd), self.const_f32(b_cv3)]
+        se = 1.0
+        if tail == "conv":
+            assert w_tail.shape[:2] == (64, 64) and out2 >= 0
+            we, se = self._split_rows(w_tail.reshape(64, 64).astype(np.float64))
+            f += [self.const(we), self.const_f32(b_tail), -1]
+        else:
+            assert w_tail.shape[:2] == (48, 64) and rows_buf >= 0
+            we, se = self._split_rows(w_tail.reshape(48, 64).astype(np.float64))
+            f += [self.const(we), self.const_f32(b_tail), self.const_f32(np.asarray(anchors, np.float64).reshape(-1))]
+        f += [fbits(sa), fbits(sb), fbits(sc), fbits(sd), fbits(se), fbits(float(det_stride)), cin, {"conv": 1, "detect": 2}[tail],
+              1 if up_a else 0, row0, nrows_total]
+        self._op(OP_DETC3, f, [self._tb(src_a), self._tb(src_b)], [self._tb(out), self._tb(out2), rows_buf])
 
     def dsconv_supported(self, cin: int, k: int, stride: int, dil: int, cout: int) -> bool:
         return self.esize == 4 and cin == 16 and k == 3 and stride == 1 and dil == 1 and cout <= 32 and cout % 4 == 0

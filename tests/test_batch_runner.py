@@ -1,0 +1,135 @@
+"""The multi-lane batch runner (pf_batch_* of the C ABI, _native.BatchEngine, FrameBatchRunner): the configuration bench.py
+measures, as a product feature.  CPU tier: slicing / ragged splits / host staging on the SIMT emulator, bit-identical with one
+engine.  GPU tier: EXACTLY the bench shape -- 96 frames of 1080p x 8 planted faces, three lanes, hipGraph replay, results in
+page-locked host memory -- on the oracle-calibrated weights, a sample of faces checked against the oracle chain."""
+import numpy as np
+import pytest
+
+from oracle import prepost as pp
+from peppa_pig_face_landmark_amd import _native
+from peppa_pig_face_landmark_amd.graph.detector import build_detector_program
+from peppa_pig_face_landmark_amd.graph.student import build_student_program
+from peppa_pig_face_landmark_amd.synth import make_frame, plant_rows
+from tests import helpers
+
+
+def _small_inputs(F, seed=40):
+    frames, rows_all = [], []
+    for f in range(F):
+        frame, boxes = make_frame(270, 480, 4, seed=seed + f, face_w=300 + 20 * f, face_h=400)
+        boxes[:, 2] += np.arange(4) * 6
+        frames.append(frame)
+        rows_all.append(plant_rows(boxes, (270, 480), n_rows=1260, input_hw=(384, 640), per_box=6, seed=f))
+    return np.stack(frames), np.stack(rows_all)
+
+
+@pytest.mark.parametrize("F,lanes", [(5, 3), (2, 3), (4, 2)])
+def test_batch_equals_single_engine_emu(emu_library, student_weights, F, lanes):
+    """Ragged splits (5 frames over 3 lanes = 2 + 2 + 1; 2 frames over 3 lanes = an idle lane), pageable host outputs through the
+    page-locked staging: every array bit-identical with ONE engine on the same frames."""
+    S, top_k = 64, 3
+    blob, _ = build_student_program(student_weights, S, "f32")
+    frames, rows = _small_inputs(F)
+    one = _native.Engine(0, emu_library)
+    one.load_program(0, blob, F * top_k)
+    ref = one.run_frames(frames, 0.5, 0.3, 100.0, top_k, planted_rows=rows)
+    one.close()
+    be = _native.BatchEngine(0, lanes, emu_library)
+    assert be.lanes == lanes
+    be.load_program(0, blob, ((F + lanes - 1) // lanes) * top_k)
+    got = be.run_frames(frames, 0.5, 0.3, 100.0, top_k, planted_rows=rows)
+    got2 = be.run_frames(frames, 0.5, 0.3, 100.0, top_k, planted_rows=rows)       # staging reused
+    be.close()
+    assert ref[0].tolist() == [top_k] * F
+    for r, g, g2 in zip(ref, got, got2):
+        assert np.array_equal(r, g) and np.array_equal(r, g2)
+
+
+def test_batch_errors_name_the_lane_emu(emu_library, student_weights):
+    be = _native.BatchEngine(0, 2, emu_library)
+    frames, rows = _small_inputs(2)
+    with pytest.raises(_native.PeppaHipError, match="lane 0"):          # nothing loaded
+        be.run_frames(frames, 0.5, 0.3, 100.0, 3, planted_rows=rows)
+    blob, _ = build_student_program(student_weights, 64, "f32")
+    be.load_program(0, blob, 3)                                         # one frame of 3 faces per lane
+    with pytest.raises(_native.PeppaHipError, match="exceed"):
+        be.run_frames(np.concatenate([frames, frames]), 0.5, 0.3, 100.0, 3, planted_rows=np.concatenate([rows, rows]))
+    with pytest.raises(_native.PeppaHipError):
+        _native.BatchEngine(0, 0, emu_library)
+    be.close()
+
+
+@pytest.mark.gpu
+def test_bench_shape_96_frames_3_lanes_graph_pinned_matches_oracle(hip_library, student_weights, detector_weights):
+    """bench.py's timed program -- pf_batch_run_frames on 96 x 1080p x 8 planted faces, three lanes, graph replay, results to
+    page-locked host buffers -- with the ORACLE's weights; boxes bit-exact against numpy NMS / top-k for every frame, landmarks
+    of 40 faces (spread over all three lanes) within 1e-3 of the crop against the oracle chain."""
+    F, K, lanes, H, W = 96, 8, 3, 1080, 1920
+    be = _native.BatchEngine(0, lanes, hip_library)
+    be.set_option(_native.PF_OPT_HIP_GRAPH, 1)
+    be.load_program(_native.PF_NET_LANDMARK, build_student_program(student_weights, 256, "f32s")[0], F // lanes * K)
+    be.load_program(_native.PF_NET_DETECTOR, build_detector_program(detector_weights, (384, 640), "f32s")[0], F // lanes)
+    base = [make_frame(H, W, K, seed=7 + i) for i in range(4)]
+    rng = np.random.default_rng(3)
+    frames = be.pinned_empty((F, H, W, 3), np.uint8)
+    rows = np.empty((F, 15120, 16), np.float32)
+    for f in range(F):
+        nz = rng.integers(-3, 4, (H, W, 3), dtype=np.int16)
+        frames[f] = np.clip(base[f % 4][0].astype(np.int16) + nz, 0, 255).astype(np.uint8)
+        rows[f] = plant_rows(base[f % 4][1], (H, W), 15120, (384, 640), 24, seed=7 + f % 4)
+    import ctypes as C
+    import torch
+    d_frames = torch.from_numpy(np.asarray(frames)).cuda()
+    d_rows = torch.from_numpy(rows).cuda()
+    h_counts = be.pinned_empty((F,), np.int32)
+    h_boxes = be.pinned_empty((F, K, 4), np.float32)
+    h_kps = be.pinned_empty((F, K, 98, 2), np.float32)
+    h_scores = be.pinned_empty((F, K, 98), np.float32)
+    for rep in range(3):        # eager, capture, replay
+        for a in (h_counts, h_boxes, h_kps, h_scores):
+            a[...] = 0
+        be.run_frames_device(d_frames.data_ptr(), F, H, W, 0.5, 0.3, 1600.0, K, d_planted=d_rows.data_ptr(), rows=15120,
+                             d_counts=h_counts.ctypes.data, d_boxes=h_boxes.ctypes.data, d_kps=h_kps.ctypes.data,
+                             d_scores=h_scores.ctypes.data, out_mem=_native.PF_MEM_HOST_PINNED)
+        be.sync()
+    assert h_counts.tolist() == [K] * F
+    _, info = pp.detector_preprocess_u8(frames[0], (384, 640))
+    info = [np.float32(info[0]), info[1], info[2]]
+    for f in range(F):
+        kept = pp.detector_postprocess(rows[f], info, 0.3, 0.5)
+        assert np.array_equal(h_boxes[f], pp.sort_and_filter(kept, 1600.0, K)[:, :4]), f
+    worst = 0.0
+    for f in list(range(0, F, 12)) + [31, 63]:           # lanes 0, 1 and 2 (frames 0-31 / 32-63 / 64-95)
+        for k in range(0, K, 2):
+            ci = pp.landmark_crop_box(h_boxes[f, k], H, W)
+            crop = pp.landmark_crop(np.asarray(frames[f]), ci, (256, 256))
+            oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
+            ref = pp.landmark_backproject(oloc[0], ci)
+            safe = helpers.heat_margins(taps)[0] > 2e-3
+            err = np.abs(h_kps[f, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)
+            worst = max(worst, err)
+            assert err < 1e-3, (f, k, err)
+            assert np.abs(h_scores[f, k] - oscore[0])[safe].max() < 2e-3
+    print("bench-shape parity: 40 faces, worst landmark error %.2e of the crop" % worst)
+    del C
+    be.close()
+
+
+@pytest.mark.gpu
+def test_frame_batch_runner_facade(hip_library, student_weights, detector_weights):
+    """FrameBatchRunner.run(frames) returns per frame what a fresh FaceAna.run(frame) returns (device path, no tracking)."""
+    from peppa_pig_face_landmark_amd.core.api.batch_runner import FrameBatchRunner
+    from peppa_pig_face_landmark_amd.core.api.facer import FaceAna, get_cfg
+    cfg = get_cfg()
+    cfg["Skps"]["Detect"]["topk"] = 4
+    w = {"detector": detector_weights, "keypoints": student_weights}
+    r = FrameBatchRunner(cfg=cfg, weights=w, lanes=2, frames_per_lane=2, library=hip_library)
+    frames = [make_frame(540, 960, 3, seed=50 + i)[0] for i in range(3)]
+    got = r.run(frames)
+    r.close()
+    fa = FaceAna(cfg=cfg, weights=w, library=hip_library)
+    for f in range(3):
+        fa.reset()
+        want = fa.run(frames[f])
+        assert len(got[f]) == len(want)
+    fa.engine.close()

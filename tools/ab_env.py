@@ -25,7 +25,7 @@ for vi, spec in enumerate(sys.argv[2:]):
         sel = {n: round(v["ms_per_step"], 4) for n, v in k.items() if any(s in n for s in subs)}
         print("%-40s %8.0f faces/s  serial %.3f ms  %s" % (spec, d["value"], d["extra"]["lane_step_ms_serial"], sel), flush=True)
         for l in r.stderr.splitlines():
-            if l.startswith("[hero_pipe") or l.startswith("[sepup_pipe"):     # cycle accounting of the ablation build (PEPPA_DBG & 64)
+            if l.startswith("[hero_pipe") or l.startswith("[sepup_pipe") or l.startswith("[det_"):     # cycle accounting of the ablation build (PEPPA_DBG & 64)
                 print("    " + l, flush=True)
     except Exception as e:  # noqa: BLE001
         print(spec, "FAILED", e, r.stderr[-800:], flush=True)
