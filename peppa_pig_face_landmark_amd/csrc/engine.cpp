@@ -493,14 +493,14 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     if (C == CC && K1 == KK && S == SS) {                                                                          \
         det_pick_tile(to.H, to.W, SS, MAXR, B, PERCU, &a.TH, &a.TW);                                               \
         a.tilesX = pf_div_up(to.W, a.TW);                                                                          \
-        PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR>), dim3(a.tilesX * pf_div_up(to.H, a.TH), B), dim3(NTHR), h->stream, a); \
+        PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR, PERCU * NTHR / 256>), dim3(a.tilesX * pf_div_up(to.H, a.TH), B), dim3(NTHR), h->stream, a); \
     } else
-                    PF_DETUNIT_CASE(32, 32, 1, 288, 512, 2)
-                    PF_DETUNIT_CASE(64, 64, 1, 144, 512, 2)
+                    PF_DETUNIT_CASE(32, 32, 1, 256, 512, 2)
+                    PF_DETUNIT_CASE(64, 64, 1, 128, 512, 2)
                     PF_DETUNIT_CASE(128, 128, 1, 144, 512, 1)
-                    PF_DETUNIT_CASE(32, 32, 2, 576, 1024, 1)
-                    PF_DETUNIT_CASE(64, 64, 2, 288, 512, 1)
-                    PF_DETUNIT_CASE(128, 128, 2, 144, 512, 1)
+                    PF_DETUNIT_CASE(32, 32, 2, 480, 512, 1)
+                    PF_DETUNIT_CASE(64, 64, 2, 256, 512, 1)
+                    PF_DETUNIT_CASE(128, 128, 2, 128, 512, 1)
                     PF_FAIL(h, "detunit: no kernel for %d branch channels, K %d, stride %d", C, K1, S);
 #undef PF_DETUNIT_CASE
                 }
@@ -524,8 +524,11 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.TH = 4; a.TW = 16; a.tilesX = pf_div_up(a.OW, a.TW);
                     a.range_slot = slot_of(oi);
                     ProfScope ps(h, "stem_block");
-                    // tile 4 x 16: stem_1 region 9 x 33 = 297 (304 rows), image region 19 x 67 = 1273 pixels
-                    PF_LAUNCH((det_stem_kernel<64, 304, 1273, 256>), dim3(a.tilesX * pf_div_up(a.OH, a.TH), B), dim3(256), h->stream, a);
+                    if ((a.W & 3) || ((size_t)d_input & 3)) PF_FAIL(h, "detstem: the image width must be a multiple of 4 and the input 4-byte aligned");
+                    // tile 4 x 16: stem_1 region 9 x 33 = 297 (304 rows), image region 19 rows x 67 pixels (208 halves per LDS row)
+                    const dim3 sg(a.tilesX * pf_div_up(a.OH, a.TH), B);
+                    if (a.in_f32_nchw) PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, true, 256>), sg, dim3(256), h->stream, a);
+                    else PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, false, 256>), sg, dim3(256), h->stream, a);
                 }
                 break;
             }
@@ -848,7 +851,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
         v.poison0 = (float*)p.buf_ptr(p.hdr.out_buf0); v.n0 = (long long)B * p.bufs[p.hdr.out_buf0].elems_per_item;
         if (p.hdr.out_buf1 >= 0 && p.hdr.out_buf1 != p.hdr.out_buf0) { v.poison1 = (float*)p.buf_ptr(p.hdr.out_buf1); v.n1 = (long long)B * p.bufs[p.hdr.out_buf1].elems_per_item; }
         if (h->pipe.d_kps_for_decode) { v.poison2 = h->pipe.d_kps_for_decode; v.n2 = (long long)B * 98 * 2; }
-        PF_LAUNCH(range_verdict_kernel, dim3(1), dim3(256), h->stream, v);
+        PF_LAUNCH(range_verdict_kernel, dim3(v.n_ops), dim3(64), h->stream, v);
     }
     PF_HIP(h, hipGetLastError());
     return 0;
@@ -1028,8 +1031,9 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
     if (hd.dtype == PF_DTYPE_F32_SPLIT) {
         const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);
-        PF_HIP(h, hipMalloc((void**)&p.d_range, rb));
-        PF_HIP(h, hipMemset(p.d_range, 0, rb));
+        PF_HIP(h, hipMalloc((void**)&p.d_range, rb + PF_RANGE_TAIL_WORDS * sizeof(unsigned)));
+        PF_HIP(h, hipMemset(p.d_range, 0, rb + PF_RANGE_TAIL_WORDS * sizeof(unsigned)));
+        PF_HIP(h, hipMemset((char*)p.d_range + rb, 0xFF, 8));       // the verdict key: all ones = no violation (range_verdict_kernel)
     }
     p.loaded = true;
     return 0;

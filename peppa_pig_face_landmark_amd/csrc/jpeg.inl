@@ -420,13 +420,15 @@ bool jpeg_stage_for_device(const unsigned char* d, size_t n, size_t sos, JpegHea
         for (int l = 1; l <= 16; ++l)                  // lengths without codes keep the bound of the shorter ones
             t->limit[i][l] = src.maxcode[l] >= 0 ? (src.maxcode[l] + 1) << (16 - l) : t->limit[i][l - 1];
     }
+    if (hd.restart <= 0) {                         // the sub-sequence decoder's limits: checked BEFORE *desc is touched, so a refusal
+        int bpm = 0;                               // never leaves a half-filled descriptor that reads as a device frame
+        for (int i = 0; i < hd.ncomp; ++i) bpm += hd.c[i].h * hd.c[i].v;
+        if (hd.ncomp > 3 || bpm > 10) return false;
+    }
     desc->scan_off = 0; desc->scan_len = (unsigned)scan_len;
     desc->offs_off = (unsigned)offs_off; desc->n_intervals = (unsigned)offs.size();
     desc->tables_off = (unsigned)tables_off; desc->restart = (unsigned)std::max(hd.restart, 0); desc->pad = 0;
     if (hd.restart <= 0) {                         // decoded as sub-sequences of PF_JPEG_SUBSEQ_BITS bits (k_jpeg.h jpeg_sync_kernel)
-        int bpm = 0;
-        for (int i = 0; i < hd.ncomp; ++i) bpm += hd.c[i].h * hd.c[i].v;
-        if (hd.ncomp > 3 || bpm > 10) return false;
         desc->n_intervals = (unsigned)std::max<size_t>(1, (scan_len * 8 + PF_JPEG_SUBSEQ_BITS - 1) / PF_JPEG_SUBSEQ_BITS);
     }
     desc->tdta = 0;

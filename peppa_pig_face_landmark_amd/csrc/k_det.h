@@ -137,17 +137,19 @@ struct DetUnitArgs {
     unsigned long long* prof;   // ablation build only (PEPPA_DBG & 4096): [5] cycles of phase 0 / GEMM 1 / depthwise / last GEMMs, workgroups
 };
 
-template <int C, int K1, int S, int MAXR, int NTHR>
-__global__ __launch_bounds__(NTHR) void det_unit_kernel(DetUnitArgs a) {
-    constexpr int KS1 = K1 / 32, KSC = C / 32, ES = C + 4, NW = NTHR / 64, NTC = C / 16;
+// WPS: waves per SIMD the register allocation must leave room for (workgroups per CU x NTHR / 256)
+template <int C, int K1, int S, int MAXR, int NTHR, int WPS>
+__global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
+    constexpr int KS1 = K1 / 32, KSC = C / 32, ES = C + 4, NW = NTHR / 64, NTC = C / 16, MG = NW / NTC;
     constexpr int MAXD = S == 1 ? MAXR : ((MAXR / 4 + 15) / 16) * 16;
-    constexpr int XB = KS1 * 2 * MAXR * 64, DB = KSC * 2 * MAXD * 64, D1B = S == 2 ? KS1 * 2 * MAXD * 64 : 0;
-    constexpr int AB = XB > DB + D1B ? XB : DB + D1B;
+    constexpr int XB = KS1 * 2 * MAXR * 64, DB = KSC * 2 * MAXD * 64, D1B = S == 2 ? KS1 * 2 * MAXD * 64 : 16;
+    constexpr int AB = XB > DB ? XB : DB;
     static_assert(NW % NTC == 0 && (C % 32) == 0 && (K1 % 32) == 0, "wave -> channel-tile assignment");
-    __shared__ __attribute__((aligned(16))) unsigned char s_a[AB];     // X planes; later the depthwise outputs' planes
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[AB];     // X planes; later the branch-2 depthwise output's planes
+    __shared__ __attribute__((aligned(16))) unsigned char s_d1[D1B];   // stride 2: planes of the branch-1 depthwise output
     __shared__ __attribute__((aligned(16))) float s_e[MAXR * ES];      // expanded map, f32, [region pixel][C + 4]
     __shared__ unsigned char s_in[MAXR];                               // region pixel inside the image?
-    PF_EMU_POISON(s_a); PF_EMU_POISON(s_e); PF_EMU_POISON(s_in);
+    PF_EMU_POISON(s_a); PF_EMU_POISON(s_d1); PF_EMU_POISON(s_e); PF_EMU_POISON(s_in);
 
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
@@ -161,47 +163,109 @@ __global__ __launch_bounds__(NTHR) void det_unit_kernel(DetUnitArgs a) {
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
     const float* in = a.in + (size_t)b * a.inH * a.inW * a.inLd;
     const int xoff = S == 1 ? C : 0;                                   // branch 2 reads the second half of a stride-1 unit's input
-    const int nt = wave % NTC, g4 = (lane >> 4) * 4;
+    const int nt = wave % NTC, mg = wave / NTC, g4 = (lane >> 4) * 4;
 
-    // weights of the first GEMM and of the depthwise conv: requested before the input, consumed after it
-    pf_half8 w1h[KS1], w1l[KS1];
-    det_wfrag<KS1>(a.w1, nt, lane, w1h, w1l);
-    const pf_f32x4 b1v = *reinterpret_cast<const pf_f32x4*>(a.b1 + nt * 16 + g4);
-    constexpr int C4 = C / 4;
-    const int dc4 = tid % C4;
-    pf_f32x4 wdv[9];
+    // ---- phase 0: every global load of the launch's first half is issued before anything waits ----------------------------
+    // (a load issued inside a loop that also parks its result costs the loop one full memory latency per iteration: ~5 k
+    // cycles apiece when every workgroup of the launch starts at once -- the first cut of this kernel spent 10 k cycles here)
+    constexpr int C8 = K1 / 8, IT0 = (MAXR * C8 + NTHR - 1) / NTHR;
+    pf_f32x4 st[IT0][2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wdv[k] = *reinterpret_cast<const pf_f32x4*>(a.wd + k * C + 4 * dc4);
-    const pf_f32x4 bdv = *reinterpret_cast<const pf_f32x4*>(a.bd + 4 * dc4);
-
-    // ---- phase 0: input region -> split planes ------------------------------------------------------------------------
-    constexpr int C8 = K1 / 8;
-    for (int i = tid; i < MR * C8; i += NTHR) {
+    for (int it = 0; it < IT0; ++it) {
+        const int i = tid + it * NTHR;
         const int r = i / C8, c8 = i - r * C8;
         const int ry = r / RW, rx = r - ry * RW;
         const int iy = iy0 + ry, ix = ix0 + rx;
         const bool ok = r < R && (unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW;
-        pf_f32x4 v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        st[it][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        st[it][1] = st[it][0];
         if (ok && 8 * c8 < a.Cin) {
             const float* px = in + ((size_t)iy * a.inW + ix) * a.inLd + xoff + 8 * c8;
-            v0 = *reinterpret_cast<const pf_f32x4*>(px);
-            v1 = *reinterpret_cast<const pf_f32x4*>(px + 4);
+            st[it][0] = *reinterpret_cast<const pf_f32x4*>(px);
+            st[it][1] = *reinterpret_cast<const pf_f32x4*>(px + 4);
         }
-        det_park8(s_a, MR, r, c8, v0, v1, amax);
-        if (c8 == 0) s_in[r] = ok ? 1 : 0;
+    }
+    pf_half8 w1h[KS1], w1l[KS1];
+    det_wfrag<KS1>(a.w1, nt, lane, w1h, w1l);
+    const pf_f32x4 b1v = *reinterpret_cast<const pf_f32x4*>(a.b1 + nt * 16 + g4);
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int i = tid + it * NTHR;
+        if (i < MR * C8) {
+            const int r = i / C8, c8 = i - r * C8;
+            const int ry = r / RW, rx = r - ry * RW;
+            det_park8(s_a, MR, r, c8, st[it][0], st[it][1], amax);
+            if (c8 == 0) s_in[r] = (r < R && (unsigned)(iy0 + ry) < (unsigned)a.inH && (unsigned)(ix0 + rx) < (unsigned)a.inW) ? 1 : 0;
+        }
+    }
+    // the pass-through half of this wave's output tiles: in flight across GEMM 1 and the depthwise phase
+    constexpr int C4 = C / 4;
+    const int dc4 = tid % C4;
+    constexpr int MAXT = (MAXD / 16 + MG - 1) / MG;
+    pf_f32x4 evn[S == 1 ? MAXT : 1];
+    if constexpr (S == 1) {
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int p = (mg + j * MG) * 16 + (lane & 15);
+            const int py = p / a.TW, px = p - py * a.TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            evn[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < P && oy < a.outH && ox < a.outW) evn[j] = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)oy * a.inW + ox) * a.inLd + nt * 16 + g4);
+        }
     }
     __syncthreads();
     const unsigned long long t1 = prof ? pf_clock() : 0;
 
-    // ---- GEMM 1: E = silu(W1 x + b1) on every region pixel, zero outside the image -------------------------------------
-    for (int mt = wave / NTC; mt < MR / 16; mt += NW / NTC) {
-        const pf_f32x4 acc = det_tile<KS1>(s_a, MR, mt * 16, lane, w1h, w1l);
-        const int r = mt * 16 + (lane & 15);
-        pf_f32x4 v = det_silu4(acc, a.s1, b1v);
-        if (!s_in[r]) v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<pf_f32x4*>(s_e + r * ES + nt * 16 + g4) = v;
+    // ---- GEMM 1: E = silu(W1 x + b1) on every region pixel, zero outside the image; two tiles per step ----------------------
+    for (int mt = mg; mt < MR / 16; mt += 2 * MG) {
+        const bool two = mt + MG < MR / 16;
+        const pf_f32x4 acc0 = det_tile<KS1>(s_a, MR, mt * 16, lane, w1h, w1l);
+        pf_f32x4 acc1 = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (two) acc1 = det_tile<KS1>(s_a, MR, (mt + MG) * 16, lane, w1h, w1l);
+        const int r0 = mt * 16 + (lane & 15), r1 = r0 + MG * 16;
+        pf_f32x4 v0 = det_silu4(acc0, a.s1, b1v);
+        if (!s_in[r0]) v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<pf_f32x4*>(s_e + r0 * ES + nt * 16 + g4) = v0;
+        if (two) {
+            pf_f32x4 v1 = det_silu4(acc1, a.s1, b1v);
+            if (!s_in[r1]) v1 = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<pf_f32x4*>(s_e + r1 * ES + nt * 16 + g4) = v1;
+        }
     }
-    // weights of the last GEMM(s): in flight during the depthwise phase
+    if constexpr (S == 2) {
+        // branch 1: depthwise 3x3 stride 2 on the block input, read back from the X planes as hi + lo (22 significand bits: what
+        // every split-precision conv sees of its input) -> planes of their own (the X planes are still being read by GEMM 1)
+        constexpr int K4 = K1 / 4;
+        const int c4 = tid % K4;
+        pf_f32x4 w9[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w9[k] = *reinterpret_cast<const pf_f32x4*>(a.wd1 + k * K1 + 4 * c4);
+        const pf_f32x4 bb = *reinterpret_cast<const pf_f32x4*>(a.bd1 + 4 * c4);
+        const unsigned char* xp = det_plane(s_a, MR, c4 >> 3);
+        const int xo = (c4 & 1) * 8, xs = (c4 >> 1) & 3;
+        for (int p = tid / K4; p < MRD; p += NTHR / K4) {
+            pf_f32x4 sum = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p < P && 4 * c4 < a.Cin) {
+                sum = bb;
+                const int py = p / a.TW, px = p - py * a.TW;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const unsigned char* q = xp + pf_lds_chunk_off((py * 2 + ky) * RW + px * 2 + kx, xs) + xo;
+                        const pf_half4 h = *reinterpret_cast<const pf_half4*>(q), l = *reinterpret_cast<const pf_half4*>(q + (size_t)MR * 64);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] = fmaf(w9[ky * 3 + kx][r], (float)h[r] + (float)l[r], sum[r]);
+                    }
+            }
+            det_park4(s_d1, MRD, p, c4, sum, amax);
+        }
+    }
+    // depthwise weights of branch 2 (in flight across the barrier) and the weights of the last GEMM(s) (across the depthwise phase)
+    pf_f32x4 wdv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wdv[k] = *reinterpret_cast<const pf_f32x4*>(a.wd + k * C + 4 * dc4);
+    const pf_f32x4 bdv = *reinterpret_cast<const pf_f32x4*>(a.bd + 4 * dc4);
     pf_half8 w2h[KSC], w2l[KSC];
     det_wfrag<KSC>(a.w2, nt, lane, w2h, w2l);
     const pf_f32x4 b2v = *reinterpret_cast<const pf_f32x4*>(a.b2 + nt * 16 + g4);
@@ -217,8 +281,9 @@ __global__ __launch_bounds__(NTHR) void det_unit_kernel(DetUnitArgs a) {
     // ---- depthwise 3x3 (stride S) on E -> D planes (over the X planes, which nobody reads any more) ----------------------
     unsigned char* dplanes = s_a;
     for (int p = tid / C4; p < MRD; p += NTHR / C4) {
-        pf_f32x4 s = bdv;
+        pf_f32x4 sum = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         if (p < P) {
+            sum = bdv;
             const int py = p / a.TW, px = p - py * a.TW;
             const float* e0 = s_e + ((py * S) * RW + px * S) * ES + 4 * dc4;
 #pragma unroll
@@ -227,66 +292,30 @@ __global__ __launch_bounds__(NTHR) void det_unit_kernel(DetUnitArgs a) {
                 for (int kx = 0; kx < 3; ++kx) {
                     const pf_f32x4 ev = *reinterpret_cast<const pf_f32x4*>(e0 + (ky * RW + kx) * ES);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s[r] = fmaf(wdv[ky * 3 + kx][r], ev[r], s[r]);
+                    for (int r = 0; r < 4; ++r) sum[r] = fmaf(wdv[ky * 3 + kx][r], ev[r], sum[r]);
                 }
-        } else {
-            s = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        det_park4(dplanes, MRD, p, dc4, s, amax);
-    }
-    if constexpr (S == 2) {
-        // branch 1: depthwise 3x3 stride 2 straight from global memory (exact f32 input), K1 (zero padded) channels
-        unsigned char* d1planes = s_a + (size_t)KSC * 2 * MRD * 64;
-        constexpr int K4 = K1 / 4;
-        const int c4 = tid % K4;
-        const bool cok = 4 * c4 < a.Cin;
-        pf_f32x4 w9[9], bb = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 9; ++k) w9[k] = *reinterpret_cast<const pf_f32x4*>(a.wd1 + k * K1 + 4 * c4);
-        bb = *reinterpret_cast<const pf_f32x4*>(a.bd1 + 4 * c4);
-        for (int p = tid / K4; p < MRD; p += NTHR / K4) {
-            pf_f32x4 s = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-            if (p < P && cok) {
-                s = bb;
-                const int py = p / a.TW, px = p - py * a.TW;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = iy0 + py * 2 + ky;
-                    if ((unsigned)iy >= (unsigned)a.inH) continue;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = ix0 + px * 2 + kx;
-                        if ((unsigned)ix >= (unsigned)a.inW) continue;
-                        const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)iy * a.inW + ix) * a.inLd + 4 * c4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) s[r] = fmaf(w9[ky * 3 + kx][r], xv[r], s[r]);
-                    }
-                }
-            }
-            det_park4(d1planes, MRD, p, c4, s, amax);
-        }
+        det_park4(dplanes, MRD, p, dc4, sum, amax);
     }
     __syncthreads();
     const unsigned long long t3 = prof ? pf_clock() : 0;
 
     // ---- last GEMM(s) + channel shuffle + store ------------------------------------------------------------------------------
     float* out = a.out + (size_t)b * a.outH * a.outW * a.outLd;
-    for (int mt = wave / NTC; mt < MRD / 16; mt += NW / NTC) {
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int mt = mg + j * MG;
+        if (mt >= MRD / 16) break;
         const int p = mt * 16 + (lane & 15);
         const int py = p / a.TW, px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         const bool ok = p < P && oy < a.outH && ox < a.outW;
         const int n = nt * 16 + g4;
-        pf_f32x4 even = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (S == 1) {
-            if (ok) even = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)oy * a.inW + ox) * a.inLd + n);   // pass-through half
-        }
         const pf_f32x4 acc2 = det_tile<KSC>(dplanes, MRD, mt * 16, lane, w2h, w2l);
+        pf_f32x4 even;
+        if constexpr (S == 2) even = det_silu4(det_tile<KS1>(s_d1, MRD, mt * 16, lane, w3h, w3l), a.s3, b3v);
+        else even = evn[j];
         const pf_f32x4 odd = det_silu4(acc2, a.s2, b2v);
-        if constexpr (S == 2) {
-            const pf_f32x4 acc3 = det_tile<KS1>(s_a + (size_t)KSC * 2 * MRD * 64, MRD, mt * 16, lane, w3h, w3l);
-            even = det_silu4(acc3, a.s3, b3v);
-        }
         if (ok) {
             float* o = out + ((size_t)oy * a.outW + ox) * a.outLd + 2 * n;
             *reinterpret_cast<pf_f32x4*>(o) = pf_f32x4{even[0], odd[0], even[1], odd[1]};
@@ -355,26 +384,37 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
     det_wfrag<KSA>(a.wA, ntA, lane, wAh, wAl);
     const pf_f32x4 bAv = *reinterpret_cast<const pf_f32x4*>(a.bA + ntA * 16 + g4);
 
-    // ---- phase 0: concatenated input region -> split planes ------------------------------------------------------------------
+    // ---- phase 0: concatenated input region -> split planes (all loads issued before the first one is waited for) ---------------
     {
         const int hA = a.H >> a.upA, wA_ = a.W >> a.upA;
         const float* srcA = a.srcA + (size_t)b * hA * wA_ * a.ldA;
         const float* srcB = a.srcB ? a.srcB + (size_t)b * a.H * a.W * a.ldB : nullptr;
-        constexpr int C8 = CIN / 8;
-        for (int i = tid; i < MR * C8; i += NTHR) {
+        constexpr int C8 = CIN / 8, IT0 = (MAXR * C8 + NTHR - 1) / NTHR;
+        pf_f32x4 st[IT0][2];
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int i = tid + it * NTHR;
             const int r = i / C8, c8 = i - r * C8;
             const int ry = r / RW, rx = r - ry * RW;
             const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
-            const bool ok = r < R && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            pf_f32x4 v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-            if (ok) {
+            st[it][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            st[it][1] = st[it][0];
+            if (r < R && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
                 const float* px = 8 * c8 < a.CA ? srcA + ((size_t)(iy >> a.upA) * wA_ + (ix >> a.upA)) * a.ldA + 8 * c8
                                                 : srcB + ((size_t)iy * a.W + ix) * a.ldB + (8 * c8 - a.CA);
-                v0 = *reinterpret_cast<const pf_f32x4*>(px);
-                v1 = *reinterpret_cast<const pf_f32x4*>(px + 4);
+                st[it][0] = *reinterpret_cast<const pf_f32x4*>(px);
+                st[it][1] = *reinterpret_cast<const pf_f32x4*>(px + 4);
             }
-            det_park8(s_x, MR, r, c8, v0, v1, amax);
-            if (c8 == 0) s_in[r] = ok ? 1 : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int i = tid + it * NTHR;
+            if (i < MR * C8) {
+                const int r = i / C8, c8 = i - r * C8;
+                const int ry = r / RW, rx = r - ry * RW;
+                det_park8(s_x, MR, r, c8, st[it][0], st[it][1], amax);
+                if (c8 == 0) s_in[r] = (r < R && (unsigned)(oy0 - 1 + ry) < (unsigned)a.H && (unsigned)(ox0 - 1 + rx) < (unsigned)a.W) ? 1 : 0;
+            }
         }
     }
     // rows [P, MRD) of the y2 half of the cat planes are pixel padding no epilogue writes: zero them (LDS is not)
@@ -526,13 +566,19 @@ struct DetStemArgs {
     unsigned* range_slot;
 };
 
-// MAXO: largest TH * TW; the stem_1 region of such a tile has at most (2 TH + 1)(2 TW + 1) <= MAXS pixels, the image region
-// (4 TH + 3)(4 TW + 3) <= MAXI pixels
-template <int MAXO, int MAXS, int MAXI, int NTHR>
+// MAXO: largest TH * TW; the stem_1 region of such a tile has at most (2 TH + 1)(2 TW + 1) <= MAXS pixels; the image region is
+// IRH = 4 TH + 3 <= MAXIH rows of IRW = 4 TW + 3 pixels.  Image rows live in LDS as f16 (a uint8 is exact: no lo plane on that
+// path), RS halves apart, laid out so that a stem_1 pixel's nine (kx, colour) bytes of one image row are 9 consecutive halves
+// starting on a 4-byte boundary: the K axis is ordered (ky, kx * 3 + ci) -- k groups 0..2 = the first 8 of the 9 halves of
+// rows ky = 0..2 (four aligned ds_read_b32 each), group 3 = the ninth half of the three rows -- and the image reaches LDS as
+// whole 32-bit words (W % 4 == 0: a word of an image row is inside or outside the image as a whole).  The first cut gathered
+// (tap, colour) elements one ds_read_u16 at a time from bytes it had loaded one at a time behind two integer divisions each:
+// 190 us per 32 frames, instruction-issue bound (11 us of HBM traffic).
+template <int MAXO, int MAXS, int MAXIH, int RS, bool F32IN, int NTHR>
 __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     constexpr int NW = NTHR / 64;
-    __shared__ __attribute__((aligned(16))) pf_half s_ih[MAXI * 3];            // staged image, hi / lo
-    __shared__ __attribute__((aligned(16))) pf_half s_il[MAXI * 3];
+    __shared__ __attribute__((aligned(16))) pf_half s_ih[MAXIH * RS];          // staged image rows (hi)
+    __shared__ __attribute__((aligned(16))) pf_half s_il[F32IN ? MAXIH * RS : 8];   // lo halves, float input only
     __shared__ __attribute__((aligned(16))) unsigned char s_p1[MAXS * 64];     // stem_1: [row][hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] (slots rotated)
     __shared__ __attribute__((aligned(16))) unsigned char s_p2[MAXS * 32];     // stem_2a: [row][hi 0-7 | lo 0-7]
     __shared__ __attribute__((aligned(16))) unsigned char s_cat[2 * MAXO * 64];// cat(stem_2b, pool): one 32-channel chunk, hi / lo planes
@@ -550,20 +596,51 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;           // stem_1 map coordinates of stem_1-region pixel (0, 0)
     const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;           // image coordinates of image-region pixel (0, 0)
     const int frow = lane & 15, g = lane >> 4, g4 = g * 4;
+    // image byte offset (within a row) of the region's first byte: 3 * ix0 = 12 ox0 - 9 = 3 (mod 4).  LDS half index of region
+    // byte e: e + 4 (the aligned word that holds byte e = 0 starts at half 1): byte 6 rx of a row -> half 6 rx + 4, 4-byte aligned
+    const int wb = 3 * ix0 - 3;                               // image byte offset (within a row) of the first aligned word
 
-    // weights: all five sets are a few hundred bytes per lane -- requested up front
+    // weights: all four sets are a few hundred bytes per lane -- requested up front
     pf_half8 w1h[1], w1l[1], w2ah[1], w2al[1], w2bh[3], w2bl[3], w3h[1], w3l[1];
-    det_wfrag<1>(a.in_f32_nchw ? a.w1_f32 : a.w1_u8, 0, lane, w1h, w1l);
+    det_wfrag<1>(F32IN ? a.w1_f32 : a.w1_u8, 0, lane, w1h, w1l);
     det_wfrag<1>(a.w2a, 0, lane, w2ah, w2al);
     det_wfrag<3>(a.w2b, 0, lane, w2bh, w2bl);
     det_wfrag<1>(a.w3, 0, lane, w3h, w3l);
     const pf_f32x4 b1v = *reinterpret_cast<const pf_f32x4*>(a.b1 + g4), b2av = *reinterpret_cast<const pf_f32x4*>(a.b2a + g4);
     const pf_f32x4 b2bv = *reinterpret_cast<const pf_f32x4*>(a.b2b + g4), b3v = *reinterpret_cast<const pf_f32x4*>(a.b3 + g4);
-    const float s1 = a.in_f32_nchw ? a.s1_f32 : a.s1_u8;
+    const float s1 = F32IN ? a.s1_f32 : a.s1_u8;
 
-    // ---- phase 0: image region -> f16 hi / lo (zero outside the image: the conv's padding) -------------------------------
-    {
+    // ---- phase 0: image region -> f16 rows (zero outside the image: the conv's padding) ----------------------------------------
+    if constexpr (!F32IN) {
         const unsigned char* in8 = static_cast<const unsigned char*>(a.in) + (size_t)b * a.H * a.W * 3;
+        const int nwd = (IRW * 3 + 3 + 3) / 4;              // aligned words covering bytes [wb, bx0 + 3 IRW)
+        const int rowb = a.W * 3;
+        constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
+        unsigned wv[ITW];
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int i = tid + it * NTHR;
+            const int ry = i / nwd, w = i - ry * nwd;
+            const int iy = iy0 + ry, bw = wb + 4 * w;
+            wv[it] = 0u;
+            if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
+        }
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int i = tid + it * NTHR;
+            const int ry = i / nwd, w = i - ry * nwd;
+            if (ry < IRH) {
+                pf_half* q = s_ih + ry * RS + 4 * w + 1;          // halves 4 w + 1 .. 4 w + 4
+                q[0] = (pf_half)(unsigned short)(wv[it] & 0xffu);
+                pf_half2 mid;
+                mid[0] = (pf_half)(unsigned short)((wv[it] >> 8) & 0xffu);
+                mid[1] = (pf_half)(unsigned short)((wv[it] >> 16) & 0xffu);
+                *reinterpret_cast<pf_half2*>(q + 1) = mid;
+                q[3] = (pf_half)(unsigned short)(wv[it] >> 24);
+                amax = pf_amax(amax, (float)(wv[it] >> 24));       // (any byte: the guard only needs the order of magnitude, <= 255)
+            }
+        }
+    } else {
         const float* inf = static_cast<const float*>(a.in) + (size_t)b * 3 * a.H * a.W;
         const int row_elems = IRW * 3;
         for (int i = tid; i < IRH * row_elems; i += NTHR) {
@@ -571,24 +648,16 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
             const int rx = x3 / 3, ci = x3 - rx * 3;
             const int iy = iy0 + ry, ix = ix0 + rx;
             float v = 0.f;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-                v = a.in_f32_nchw ? inf[((size_t)ci * a.H + iy) * a.W + ix] : (float)in8[((size_t)iy * a.W + ix) * 3 + ci];
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = inf[((size_t)ci * a.H + iy) * a.W + ix];
             const pf_half hv = (pf_half)v;
-            s_ih[i] = hv;
-            s_il[i] = (pf_half)(v - (float)hv);
+            s_ih[ry * RS + x3 + 4] = hv;
+            s_il[ry * RS + x3 + 4] = (pf_half)(v - (float)hv);
             amax = pf_amax(amax, v);
         }
-        for (int r = tid; r < MR1; r += NTHR) {
-            const int ry = r / SRW, rx = r - ry * SRW;
-            s_ok[r] = (r < S1R && (unsigned)(sy0 + ry) < (unsigned)a.SH && (unsigned)(sx0 + rx) < (unsigned)a.SW) ? 1 : 0;
-        }
     }
-    // im2col offsets of this lane's 8 k values: k = 8 g + e = (ky * 3 + kx) * 3 + ci  ->  ((ky * IRW + kx) * 3 + ci); k >= 27: none
-    int koff[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int k = 8 * g + e, tap = k / 3, ci = k - tap * 3;
-        koff[e] = k < 27 ? ((tap / 3) * IRW + tap % 3) * 3 + ci : -1;
+    for (int r = tid; r < MR1; r += NTHR) {
+        const int ry = r / SRW, rx = r - ry * SRW;
+        s_ok[r] = (r < S1R && (unsigned)(sy0 + ry) < (unsigned)a.SH && (unsigned)(sx0 + rx) < (unsigned)a.SW) ? 1 : 0;
     }
     __syncthreads();
 
@@ -597,16 +666,27 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
         const int r = mt * 16 + frow;
         const int rc = r < S1R ? r : 0;
         const int ry = rc / SRW, rx = rc - ry * SRW;
-        const int base = ((2 * ry) * IRW + 2 * rx) * 3;
+        // this lane's 8 k values: groups 0..2 = halves 0..7 of image row 2 ry + g, group 3 = half 8 of the three rows
         pf_half8 xh, xl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            xh[e] = koff[e] >= 0 ? s_ih[base + koff[e]] : (pf_half)0;
-            xl[e] = koff[e] >= 0 ? s_il[base + koff[e]] : (pf_half)0;
+        {
+            const int base = (2 * ry + (g < 3 ? g : 0)) * RS + 6 * rx + 4;
+            if (g < 3) {
+                const unsigned* q = reinterpret_cast<const unsigned*>(s_ih + base);
+                unsigned u[4] = {q[0], q[1], q[2], q[3]};
+                memcpy(&xh, u, 16);
+                if constexpr (F32IN) {
+                    const unsigned* ql = reinterpret_cast<const unsigned*>(s_il + base);
+                    unsigned ul[4] = {ql[0], ql[1], ql[2], ql[3]};
+                    memcpy(&xl, ul, 16);
+                }
+            } else {
+                xh = pf_half8{s_ih[base + 8], s_ih[base + RS + 8], s_ih[base + 2 * RS + 8], (pf_half)0, (pf_half)0, (pf_half)0, (pf_half)0, (pf_half)0};
+                if constexpr (F32IN) xl = pf_half8{s_il[base + 8], s_il[base + RS + 8], s_il[base + 2 * RS + 8], (pf_half)0, (pf_half)0, (pf_half)0, (pf_half)0, (pf_half)0};
+            }
         }
         pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         acc = pf_mfma_16x16x32_f16(w1l[0], xh, acc);
-        acc = pf_mfma_16x16x32_f16(w1h[0], xl, acc);
+        if constexpr (F32IN) acc = pf_mfma_16x16x32_f16(w1h[0], xl, acc);
         acc = pf_mfma_16x16x32_f16(w1h[0], xh, acc);
         const pf_f32x4 v = det_silu4(acc, s1, b1v);
         pf_half4 hi, lo;

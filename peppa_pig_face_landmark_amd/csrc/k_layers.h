@@ -641,7 +641,8 @@ __global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
 // pf_common.h); at the end of EVERY forward this kernel compares the slots against [2^-10, 6e4], poisons the outputs with NaN
 // and records (op, value) on a violation -- no silent inf, no silent garbage, on any call -- and clears the slots for the next one.
 struct RangeVerdictArgs {
-    unsigned* slots;         // [n_ops][PF_RANGE_SUBSLOTS] raw bits of max |v|, 0 = not measured; cleared here
+    unsigned* slots;         // [n_ops][PF_RANGE_SUBSLOTS] raw bits of max |v|, 0 = not measured; cleared here.  Behind them: an 8-byte
+                             // verdict key (all ones = no violation) and a 4-byte arrival ticket (pf_load_program initialises both)
     int n_ops;
     float lo, hi;            // accepted range of a tensor's max |x|
     int* status;             // [4] = code (0 ok, 1 overflow, 2 underflow), op index, value bits, program slot (host-mapped)
@@ -650,38 +651,56 @@ struct RangeVerdictArgs {
     float* poison1; long long n1;
     float* poison2; long long n2;
 };
+#define PF_RANGE_TAIL_WORDS 4
 
-__global__ __launch_bounds__(256) void range_verdict_kernel(RangeVerdictArgs a) {
-    static_assert(PF_RANGE_SUBSLOTS == 256, "one word per thread");
-    __shared__ int s_code, s_op;
-    __shared__ unsigned s_val, s_part[4];
-    const int t = threadIdx.x;
-    if (t == 0) { s_code = 0; s_op = -1; s_val = 0; }
-    for (int i = 0; i < a.n_ops; ++i) {
-        unsigned m = a.slots[i * PF_RANGE_SUBSLOTS + t];
-        a.slots[i * PF_RANGE_SUBSLOTS + t] = 0;                     // cleared for the next forward
-        for (int mask = 1; mask < 64; mask <<= 1) {
-            const unsigned o = (unsigned)pf_shfl_xor_i32((int)m, mask);
-            m = o > m ? o : m;
-        }
-        __syncthreads();
-        if ((t & 63) == 0) s_part[t >> 6] = m;
-        __syncthreads();
-        if (t == 0) {
-            unsigned bits = s_part[0];
-            for (int k = 1; k < 4; ++k) bits = s_part[k] > bits ? s_part[k] : bits;
-            if (bits != 0) {                                        // 0: op not measured / all-zero tensor
-                const float v = __uint_as_float(bits);
-                if (!(v <= a.hi) && s_code != 1) { s_code = 1; s_op = i; s_val = bits; }     // NaN bits land here too
-                if (v < a.lo && s_code == 0) { s_code = 2; s_op = i; s_val = bits; }
-            }
-        }
+// One wave per op (round 4; one 256-thread workgroup used to walk all ~75 ops of the Student one after the other: 41-47 us at the end
+// of every forward, twice per pipeline call).  Each wave reduces and clears its op's words and, on a violation, lowers the
+// verdict key -- overflow (or NaN) before underflow, then program order, exactly the old kernel's choice -- with one 64-bit
+// atomicMin; the last wave to take a ticket reads the key, reports and poisons.
+__global__ __launch_bounds__(64) void range_verdict_kernel(RangeVerdictArgs a) {
+    static_assert(PF_RANGE_SUBSLOTS == 256, "four words per lane");
+    const int i = blockIdx.x, t = threadIdx.x;
+    unsigned* s = a.slots + (size_t)i * PF_RANGE_SUBSLOTS;
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned v = s[t + 64 * k];
+        s[t + 64 * k] = 0;                                           // cleared for the next forward
+        m = v > m ? v : m;
     }
-    if (t == 0 && s_code != 0 && a.status[0] == 0) { a.status[1] = s_op; a.status[2] = (int)s_val; a.status[3] = a.prog_slot; a.status[0] = s_code; }
-    __syncthreads();
-    if (s_code == 0) return;
+    for (int mask = 1; mask < 64; mask <<= 1) {
+        const unsigned o = (unsigned)pf_shfl_xor_i32((int)m, mask);
+        m = o > m ? o : m;
+    }
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(a.slots + (size_t)a.n_ops * PF_RANGE_SUBSLOTS);
+    unsigned* ticket = reinterpret_cast<unsigned*>(key + 1);
+    int last = 0;
+    if (t == 0) {
+        if (m != 0) {                                                // 0: op not measured / all-zero tensor
+            const float v = __uint_as_float(m);
+            const int code = !(v <= a.hi) ? 1 : (v < a.lo ? 2 : 0);  // NaN bits land in the first case
+            if (code) atomicMin(key, ((unsigned long long)(code == 1 ? 0 : 1) << 63) | ((unsigned long long)i << 32) | m);
+        }
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == (unsigned)(a.n_ops - 1) ? 1 : 0;
+    }
+    last = pf_shfl_i32(last, 0);
+    if (!last) return;
+    __threadfence();
+    unsigned long long k = 0;
+    if (t == 0) {
+        k = atomicMin(key, ~0ull);                                   // reads the key (device scope) without changing it
+        if (k != ~0ull) atomicMax(key, ~0ull);                       // ... and re-arms it for the next forward
+        atomicExch(ticket, 0u);
+    }
+    const unsigned klo = (unsigned)pf_shfl_i32((int)(unsigned)k, 0), khi = (unsigned)pf_shfl_i32((int)(unsigned)(k >> 32), 0);
+    if (klo == 0xffffffffu && khi == 0xffffffffu) return;
+    if (t == 0 && a.status[0] == 0) {
+        a.status[1] = (int)(khi & 0x7fffffffu); a.status[2] = (int)klo; a.status[3] = a.prog_slot;
+        a.status[0] = (khi >> 31) ? 2 : 1;
+    }
     const float nan = __builtin_nanf("");
-    for (long long i = threadIdx.x; i < a.n0; i += 256) a.poison0[i] = nan;
-    for (long long i = threadIdx.x; i < a.n1; i += 256) a.poison1[i] = nan;
-    for (long long i = threadIdx.x; i < a.n2; i += 256) a.poison2[i] = nan;
+    for (long long j = t; j < a.n0; j += 64) a.poison0[j] = nan;
+    for (long long j = t; j < a.n1; j += 64) a.poison1[j] = nan;
+    for (long long j = t; j < a.n2; j += 64) a.poison2[j] = nan;
 }

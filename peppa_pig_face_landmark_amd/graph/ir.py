@@ -382,7 +382,12 @@ class ProgramBuilder:
             m = np.zeros((n, k), np.float64)
             m[:w.shape[0], :w.shape[1]] = w
             return self._split_rows(m)
-        w1r = np.transpose(w1.astype(np.float64), (0, 2, 3, 1)).reshape(16, 27)          # k = (ky*3 + kx)*3 + ci
+        # K order of the stem_1 GEMM (csrc/k_det.h det_stem_kernel): k groups 0..2 = (ky, j = kx*3 + ci < 8), group 3 = j = 8 of ky = 0..2
+        w9 = np.transpose(w1.astype(np.float64), (0, 2, 3, 1)).reshape(16, 3, 9)
+        w1r = np.zeros((16, 32), np.float64)
+        for ky in range(3):
+            w1r[:, 8 * ky:8 * ky + 8] = w9[:, ky, :8]
+            w1r[:, 24 + ky] = w9[:, ky, 8]
         w1u, s1u = rows(w1r / 255.0, 16, 32)
         w1f, s1f = rows(w1r, 16, 32)
         wa, sa = rows(w2a.reshape(8, 16).astype(np.float64), 16, 32)

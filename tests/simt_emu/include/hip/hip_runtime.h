@@ -193,6 +193,13 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
+    unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline unsigned atomicMax(unsigned* p, unsigned v) {
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

@@ -109,7 +109,7 @@ def test_bench_shape_96_frames_3_lanes_graph_pinned_matches_oracle(hip_library, 
             err = np.abs(h_kps[f, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)
             worst = max(worst, err)
             assert err < 1e-3, (f, k, err)
-            assert np.abs(h_scores[f, k] - oscore[0])[safe].max() < 2e-3
+            assert np.abs(h_scores[f, k] - oscore[0])[safe].max() < 1e-3 * max(1.0, float(np.abs(oscore).max()))     # heat-map logits, range ~ 20
     print("bench-shape parity: 40 faces, worst landmark error %.2e of the crop" % worst)
     del C
     be.close()
