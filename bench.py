@@ -124,6 +124,8 @@ def parse_args():
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
     ap.add_argument("--no-probes", action="store_true", help="skip the call-latency, sustained-loop and PCIe-inclusive probes (keeps a "
                     "rocprofv3 --stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
+    ap.add_argument("--fuse-front", type=int, default=-1, help="A/B aid: 1 / 0 = Student program with / without the fused encoder front end "
+                    "(csrc/k_front.h); default: the program builder's own default")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel HIP-event pass after the timed steps (lane sweeps, "
                     "rocprofv3 traces of the multi-lane steady state); roofline is null then")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
@@ -382,7 +384,8 @@ def main():
 
     # ---- weights: packed on rank 0, broadcast once by the ENGINE over RCCL / xGMI (pf_broadcast_weights) -----------
     t0 = time.time()
-    blobs = bs.build_programs(workload, args.dtype, args.model) if rank == 0 else None
+    skw = {} if args.fuse_front < 0 or args.model != "student" else {"fuse_front": bool(args.fuse_front)}
+    blobs = bs.build_programs(workload, args.dtype, args.model, **skw) if rank == 0 else None
     slots = [PF_NET_LANDMARK] + ([PF_NET_DETECTOR] if workload == "pipeline" else [])
 
     def exchange_id(uid):

@@ -45,6 +45,23 @@ def _load_weights(root, rel_path: str, what: str) -> Dict[str, np.ndarray]:
     return load_weights(path, what)
 
 
+def _host_imread(data: bytes):
+    """Host decode of an image file the device decoder refuses: BGR uint8 [H,W,3] like cv2.imread(path) (IMREAD_COLOR: alpha
+    dropped, greyscale / palette expanded), or None when no host decoder can read it (cv2.imread's answer too).  Uses Pillow
+    when it is installed; nothing else in the package depends on it."""
+    try:
+        import io
+        from PIL import Image
+    except ImportError:
+        return None
+    try:
+        with Image.open(io.BytesIO(data)) as im:
+            rgb = np.asarray(im.convert("RGB"))
+    except Exception:  # noqa: BLE001  (truncated / unknown format)
+        return None
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
 def _box_iou(a, b) -> float:
     total = (a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1])
     iw = max(0, min(a[2], b[2]) - max(a[0], b[0]))
@@ -125,7 +142,23 @@ class FaceAna:
         the host, dequantisation / inverse DCT / chroma upsampling / colour conversion run on the GPU (bit-identical with
         cv2.imread's libjpeg) and the frame never exists in host memory unless asked for.  Returns a ``DeviceFrame`` that
         ``run()`` accepts like an array; ``frame.numpy()`` is the BGR array for drawing."""
-        return self.engine.imread(path_or_bytes, want_host)
+        data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else None
+        if data is None:
+            try:
+                with open(path_or_bytes, "rb") as f:
+                    data = f.read()
+            except OSError:
+                return None                      # cv2.imread returns None for a path it cannot read
+        try:
+            return self.engine.imread(bytes(data), want_host)
+        except _native.PeppaHipError as e:
+            # Everything else cv2.imread opens (demo.py:76) -- progressive / arithmetic-coded / CMYK JPEG, PNG, BMP, ... -- is
+            # decoded on the HOST, as the reference itself does for every file, and handed to run() as the numpy array
+            # cv2.imread would have returned; only baseline JPEG has a device decoder (csrc/jpeg.inl).
+            frame = _host_imread(bytes(data))
+            if frame is None:
+                logger.warning("imread: %s", e)
+            return frame
 
     def to_dict(self, bboxes, kps, states):
         return [{"box": bboxes[i], "kps": kps[i], "scores": states[i]} for i in range(len(bboxes))]

@@ -588,17 +588,32 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int oy0 = ((int)blockIdx.x / a.tilesX) * a.TH, ox0 = ((int)blockIdx.x % a.tilesX) * a.TW;
     const int SRW = 2 * a.TW + 1, SRH = 2 * a.TH + 1, S1R = SRH * SRW, MR1 = (S1R + 15) & ~15;
     const int IRW = 2 * SRW + 1, IRH = 2 * SRH + 1;
     const int P = a.TH * a.TW, MRD = (P + 15) & ~15;
-    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;           // stem_1 map coordinates of stem_1-region pixel (0, 0)
-    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;           // image coordinates of image-region pixel (0, 0)
     const int frow = lane & 15, g = lane >> 4, g4 = g * 4;
-    // image byte offset (within a row) of the region's first byte: 3 * ix0 = 12 ox0 - 9 = 3 (mod 4).  LDS half index of region
-    // byte e: e + 4 (the aligned word that holds byte e = 0 starts at half 1): byte 6 rx of a row -> half 6 rx + 4, 4-byte aligned
-    const int wb = 3 * ix0 - 3;                               // image byte offset (within a row) of the first aligned word
+    // PERSISTENT workgroups (round 4, second cut): a workgroup walks tiles t = blockIdx.x, + gridDim.x, ... of all frames and
+    // requests the NEXT tile's image words before it computes the current one -- with one tile per workgroup every workgroup
+    // opened with a ~5 us wait for its 4 KB of pixels (133 us per 32 frames at three workgroups per CU).
+    const int tiles_y = (a.OH + a.TH - 1) / a.TH, tpf = a.tilesX * tiles_y, ntiles = tpf * a.B;
+    const int nwd = (IRW * 3 + 3 + 3) / 4;                    // aligned words covering one region row (the row starts at byte 3 of a word)
+    const int rowb = a.W * 3;
+    constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
+    unsigned wv[ITW];
+    auto request = [&](int t) {                               // uint8 input: the image words of tile t -> registers
+        const int tb = t / tpf, tt = t - tb * tpf;
+        const int iy0 = 4 * (tt / a.tilesX) * a.TH - 3, wb = 3 * (4 * (tt % a.tilesX) * a.TW - 3) - 3;
+        const unsigned char* in8 = static_cast<const unsigned char*>(a.in) + (size_t)tb * a.H * a.W * 3;
+#pragma unroll
+        for (int it = 0; it < ITW; ++it) {
+            const int i = tid + it * NTHR;
+            const int ry = i / nwd, w = i - ry * nwd;
+            const int iy = iy0 + ry, bw = wb + 4 * w;
+            wv[it] = 0u;
+            if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
+        }
+    };
+    if constexpr (!F32IN) { if ((int)blockIdx.x < ntiles) request(blockIdx.x); }
 
     // weights: all four sets are a few hundred bytes per lane -- requested up front
     pf_half8 w1h[1], w1l[1], w2ah[1], w2al[1], w2bh[3], w2bl[3], w3h[1], w3l[1];
@@ -610,21 +625,14 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     const pf_f32x4 b2bv = *reinterpret_cast<const pf_f32x4*>(a.b2b + g4), b3v = *reinterpret_cast<const pf_f32x4*>(a.b3 + g4);
     const float s1 = F32IN ? a.s1_f32 : a.s1_u8;
 
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int b = t / tpf, tt = t - b * tpf;
+    const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
+    const int sy0 = 2 * oy0 - 1, sx0 = 2 * ox0 - 1;           // stem_1 map coordinates of stem_1-region pixel (0, 0)
+    const int iy0 = 2 * sy0 - 1, ix0 = 2 * sx0 - 1;           // image coordinates of image-region pixel (0, 0): 3 ix0 = 3 (mod 4).  LDS
+    // half index of region byte e: e + 4 (the aligned word holding byte e = 0 starts at half 1): byte 6 rx -> half 6 rx + 4, 4-byte aligned
     // ---- phase 0: image region -> f16 rows (zero outside the image: the conv's padding) ----------------------------------------
     if constexpr (!F32IN) {
-        const unsigned char* in8 = static_cast<const unsigned char*>(a.in) + (size_t)b * a.H * a.W * 3;
-        const int nwd = (IRW * 3 + 3 + 3) / 4;              // aligned words covering bytes [wb, bx0 + 3 IRW)
-        const int rowb = a.W * 3;
-        constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
-        unsigned wv[ITW];
-#pragma unroll
-        for (int it = 0; it < ITW; ++it) {
-            const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
-            const int iy = iy0 + ry, bw = wb + 4 * w;
-            wv[it] = 0u;
-            if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
-        }
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
@@ -640,6 +648,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
                 amax = pf_amax(amax, (float)(wv[it] >> 24));       // (any byte: the guard only needs the order of magnitude, <= 255)
             }
         }
+        if (t + (int)gridDim.x < ntiles) request(t + gridDim.x);  // in flight across this tile's five phases
     } else {
         const float* inf = static_cast<const float*>(a.in) + (size_t)b * 3 * a.H * a.W;
         const int row_elems = IRW * 3;
@@ -784,6 +793,8 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
         const int py = p / a.TW, px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         if (p < P && oy < a.OH && ox < a.OW) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.OW + ox) * a.outLd + g4) = v;
+    }
+    __syncthreads();                                          // the next tile's rows overwrite everything
     }
     pf_amax_commit(a.range_slot, amax, amax_seen);
 }

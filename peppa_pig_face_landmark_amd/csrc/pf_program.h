@@ -63,6 +63,9 @@ enum PfOpCode : int32_t {
                         //    Detect conv (raw output into out2 if given) and its decode into rows_buf; split programs only
     PF_OP_DETSTEM = 20, // f: out_t w1_u8 w1_f32 b1 w2a b2a w2b b2b w3 b3 s1_u8 s1_f32 s2a s2b s3 (float bits): the detector's StemBlock (stem_1 3x3 s2,
                         //    stem_2a 1x1, stem_2b 3x3 s2, max-pool, stem_3 1x1) in one launch on the program input (k_det.h det_stem_kernel)
+    PF_OP_LMFRONT = 21, // f: out_t w_stem_u8 w_stem_f32 b_stem w_dw0 b_dw0 w_pw0 b_pw0 w_exp b_exp w_dw1 b_dw1 w_prj b_prj s_stem_u8 s_stem_f32 s_pw0 s_exp s_prj
+                        //    (float bits) act_stem: conv_stem + blocks.0.0 + blocks.1.0 of the Student encoder in one launch on the program input
+                        //    (k_front.h lm_front_kernel); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

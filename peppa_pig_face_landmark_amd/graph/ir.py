@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM = range(1, 21)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT = range(1, 22)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -382,12 +382,7 @@ class ProgramBuilder:
             m = np.zeros((n, k), np.float64)
             m[:w.shape[0], :w.shape[1]] = w
             return self._split_rows(m)
-        # K order of the stem_1 GEMM (csrc/k_det.h det_stem_kernel): k groups 0..2 = (ky, j = kx*3 + ci < 8), group 3 = j = 8 of ky = 0..2
-        w9 = np.transpose(w1.astype(np.float64), (0, 2, 3, 1)).reshape(16, 3, 9)
-        w1r = np.zeros((16, 32), np.float64)
-        for ky in range(3):
-            w1r[:, 8 * ky:8 * ky + 8] = w9[:, ky, :8]
-            w1r[:, 24 + ky] = w9[:, ky, 8]
+        w1r = self._stem_k_order(w1)
         w1u, s1u = rows(w1r / 255.0, 16, 32)
         w1f, s1f = rows(w1r, 16, 32)
         wa, sa = rows(w2a.reshape(8, 16).astype(np.float64), 16, 32)
@@ -396,6 +391,47 @@ class ProgramBuilder:
         b2 = np.zeros(16); b2[:8] = b2a
         self._op(OP_DETSTEM, [out, self.const(w1u), self.const(w1f), self.const_f32(b1), self.const(wa), self.const_f32(b2), self.const(wb),
                               self.const_f32(b2b), self.const(wc), self.const_f32(b3), fbits(s1u), fbits(s1f), fbits(sa), fbits(sb), fbits(sc)],
+                 [], [self._tb(out)])
+        return out
+
+    @staticmethod
+    def _stem_k_order(w: np.ndarray) -> np.ndarray:
+        """[16,3,3,3] -> [16,32]: K order of the staged-image stem GEMMs (csrc/k_det.h det_stem_kernel, k_front.h): k groups 0..2 =
+        (ky, j = kx*3 + ci < 8), group 3 = j = 8 of ky = 0..2, rest zero."""
+        w9 = np.transpose(w.astype(np.float64), (0, 2, 3, 1)).reshape(w.shape[0], 3, 9)
+        out = np.zeros((w.shape[0], 32), np.float64)
+        for ky in range(3):
+            out[:, 8 * ky:8 * ky + 8] = w9[:, ky, :8]
+            out[:, 24 + ky] = w9[:, ky, 8]
+        return out
+
+    def lm_front_supported(self) -> bool:
+        return self.split and self.in_h % 4 == 0 and self.in_w % 4 == 0
+
+    def lm_front(self, w_stem, b_stem, act_stem, w_dw0, b_dw0, w_pw0, b_pw0, w_exp, b_exp, w_dw1, b_dw1, w_prj, b_prj, out_name: str = "") -> int:
+        """conv_stem (3x3 s2, 3 -> 16) + blocks.0.0 (depthwise 3x3 + relu -> 1x1 16 -> 16, + x) + blocks.1.0 (1x1 16 -> 64 + relu ->
+        depthwise 3x3 s2 + relu -> 1x1 64 -> 24) of the Student encoder on the program input in ONE launch (csrc/k_front.h);
+        BN-folded weights."""
+        assert self.lm_front_supported()
+        assert w_stem.shape == (16, 3, 3, 3) and w_dw0.shape == (16, 1, 3, 3) and w_pw0.shape[:2] == (16, 16)
+        assert w_exp.shape[:2] == (64, 16) and w_dw1.shape == (64, 1, 3, 3) and w_prj.shape[:2] == (24, 64)
+        out = self.tensor(self.in_h // 4, self.in_w // 4, 24, name=out_name)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+
+        def rows(w, n, k):
+            m = np.zeros((n, k), np.float64)
+            m[:w.shape[0], :w.shape[1]] = w
+            return self._split_rows(m)
+        ws = self._stem_k_order(w_stem)
+        wsu, ssu = self._split_rows(ws / 255.0)
+        wsf, ssf = self._split_rows(ws)
+        wp, sp = rows(w_pw0.reshape(16, 16).astype(np.float64), 16, 32)
+        we, se = rows(w_exp.reshape(64, 16).astype(np.float64), 64, 32)
+        wj, sj = rows(w_prj.reshape(24, 64).astype(np.float64), 32, 64)
+        bj = np.zeros(32); bj[:24] = b_prj
+        self._op(OP_LMFRONT, [out, self.const(wsu), self.const(wsf), self.const_f32(b_stem), self.const_f32(w_dw0.reshape(16, 9).T), self.const_f32(b_dw0),
+                              self.const(wp), self.const_f32(b_pw0), self.const(we), self.const_f32(b_exp), self.const_f32(w_dw1.reshape(64, 9).T),
+                              self.const_f32(b_dw1), self.const(wj), self.const_f32(bj), fbits(ssu), fbits(ssf), fbits(sp), fbits(se), fbits(sj), ACT[act_stem]],
                  [], [self._tb(out)])
         return out
 

@@ -98,19 +98,30 @@ def test_bench_shape_96_frames_3_lanes_graph_pinned_matches_oracle(hip_library, 
     for f in range(F):
         kept = pp.detector_postprocess(rows[f], info, 0.3, 0.5)
         assert np.array_equal(h_boxes[f], pp.sort_and_filter(kept, 1600.0, K)[:, :4]), f
-    worst = 0.0
+    worst, n_safe, n_moved, worst_score = 0.0, 0, 0, 0.0
     for f in list(range(0, F, 12)) + [31, 63]:           # lanes 0, 1 and 2 (frames 0-31 / 32-63 / 64-95)
         for k in range(0, K, 2):
             ci = pp.landmark_crop_box(h_boxes[f, k], H, W)
             crop = pp.landmark_crop(np.asarray(frames[f]), ci, (256, 256))
             oloc, oscore, taps = helpers.oracle_student(student_weights, crop[None])
             ref = pp.landmark_backproject(oloc[0], ci)
-            safe = helpers.heat_margins(taps)[0] > 2e-3
-            err = np.abs(h_kps[f, k] - ref)[safe].max() / max(ci.w_crop, ci.h_crop)
-            worst = max(worst, err)
-            assert err < 1e-3, (f, k, err)
-            assert np.abs(h_scores[f, k] - oscore[0])[safe].max() < 1e-3 * max(1.0, float(np.abs(oscore).max()))     # heat-map logits, range ~ 20
-    print("bench-shape parity: 40 faces, worst landmark error %.2e of the crop" % worst)
+            margin = helpers.heat_margins(taps)[0]
+            safe = margin > 2e-3
+            err = np.abs(h_kps[f, k] - ref).max(1) / max(ci.w_crop, ci.h_crop)
+            serr = np.abs(h_scores[f, k] - oscore[0])
+            # a landmark may only leave the 1e-3 bound by picking the other of two near-equal heat-map cells: the oracle's
+            # top-1 / top-2 margin must then be of the size of the heat-map error itself (logits of range ~ 20)
+            moved = err > 1e-3
+            assert (margin[moved] < 0.05).all(), (f, k, margin[moved], err[moved])
+            n_safe += int(safe.sum())
+            n_moved += int((moved & safe).sum())
+            worst = max(worst, float(err[safe & ~moved].max()))
+            worst_score = max(worst_score, float(serr[~moved].max()))
+    assert n_moved <= 0.005 * n_safe + 1, (n_moved, n_safe)           # same flip bound as tests/test_gpu_landmark.py
+    assert worst < 1e-3
+    assert worst_score < 2e-2                                          # heat-map logits, range ~ 20: 1e-3 relative
+    print("bench-shape parity: 40 faces, %d landmarks, %d near-tie flips, worst landmark error %.2e of the crop, worst score error %.2e"
+          % (n_safe, n_moved, worst, worst_score))
     del C
     be.close()
 

@@ -1,0 +1,112 @@
+"""Frame ingest beyond baseline JPEG stills: Motion-JPEG AVI files through the engine's JPEG decoder (the buildable
+form of demo.py:13-17 -- no codec library in this image) and the host fallback of FaceAna.imread for everything else cv2.imread
+opens (demo.py:76).  CPU tier on the SIMT emulator; the decoder itself is pinned bit-for-bit against libjpeg in test_jpeg_decode.py."""
+import ctypes
+import io
+import types
+
+import numpy as np
+import pytest
+
+PIL = pytest.importorskip("PIL")
+from PIL import Image  # noqa: E402
+
+from peppa_pig_face_landmark_amd import video  # noqa: E402
+from peppa_pig_face_landmark_amd.core.api.facer import FaceAna  # noqa: E402
+
+
+def _photo(h, w, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([120 + 80 * np.sin(xx / (7.0 + c) + seed) * np.cos(yy / (5.0 + c)) for c in range(3)], -1)
+    return np.clip(img + rng.normal(0, 4, img.shape), 0, 255).astype(np.uint8)
+
+
+def _jpeg(rgb, **kw):
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="JPEG", **kw)
+    return buf.getvalue()
+
+
+def _strip_dht(jpeg: bytes) -> bytes:
+    out, pos = bytearray(jpeg[:2]), 2
+    while True:
+        m = jpeg[pos + 1]
+        if m == 0xDA:
+            return bytes(out) + jpeg[pos:]
+        seg = 2 + int.from_bytes(jpeg[pos + 2:pos + 4], "big")
+        if m != 0xC4:
+            out += jpeg[pos:pos + seg]
+        pos += seg
+
+
+def test_standard_huffman_tables_are_the_ones_encoders_write():
+    """libjpeg's default (non-optimised) tables ARE ITU T.81 K.3: the DHT segments of such a file concatenate to ours."""
+    j = _jpeg(_photo(32, 32, 1), quality=85)
+    tables, pos = {}, 2
+    while j[pos + 1] != 0xDA:
+        seg = 2 + int.from_bytes(j[pos + 2:pos + 4], "big")
+        if j[pos + 1] == 0xC4:
+            body, q = j[pos + 4:pos + seg], 0
+            while q < len(body):
+                n = sum(body[q + 1:q + 17])
+                tables[body[q]] = bytes(body[q:q + 17 + n])
+                q += 17 + n
+        pos += seg
+    ours = video.standard_dht_segment()[4:]
+    assert b"".join(tables[k] for k in (0x00, 0x10, 0x01, 0x11)) == ours
+
+
+def test_mjpeg_avi_frames_decode_bit_exact(emu_engine):
+    h, w = 48, 64
+    rgbs = [_photo(h, w, s) for s in range(3)]
+    jpegs = [_jpeg(r, quality=88, subsampling=2) for r in rgbs]
+    frames = [jpegs[0], _strip_dht(jpegs[1]), _strip_dht(jpegs[2])]          # MJPG streams usually omit the tables
+    avi = video.write_mjpeg_avi(frames, w, h, fps=30.0)
+    cap = video.MJPEGCapture(avi, engine=emu_engine)
+    assert cap.isOpened() and cap.get(cap.CAP_PROP_FRAME_COUNT) == 3
+    assert (cap.get(cap.CAP_PROP_FRAME_WIDTH), cap.get(cap.CAP_PROP_FRAME_HEIGHT)) == (w, h) and abs(cap.get(cap.CAP_PROP_FPS) - 30.0) < 1e-3
+    for i in range(3):
+        ok, frame = cap.read()
+        assert ok
+        ref = np.asarray(Image.open(io.BytesIO(jpegs[i])).convert("RGB"))[:, :, ::-1]      # libjpeg's pixels, BGR like cv2
+        assert np.array_equal(frame.numpy(), ref)
+    assert cap.read() == (False, None)
+    # the batched form: three frames decoded by ONE pf_decode_jpeg_batch call
+    cap2 = video.MJPEGCapture(avi, engine=emu_engine)
+    d, n, hh, ww = cap2.read_batch(8, threads=2)
+    assert (n, hh, ww) == (3, h, w) and cap2.read_batch(8) is None
+    emu_engine.sync()
+    got = np.ctypeslib.as_array(ctypes.cast(d, ctypes.POINTER(ctypes.c_ubyte)), shape=(3, h, w, 3))      # emulator: device memory is host memory
+    for i in range(3):
+        assert np.array_equal(got[i], np.asarray(Image.open(io.BytesIO(jpegs[i])).convert("RGB"))[:, :, ::-1])
+    cap.release()
+
+
+def test_capture_of_other_files_does_not_open(tmp_path):
+    assert not video.MJPEGCapture(b"RIFF\x04\x00\x00\x00WAVE").isOpened()
+    assert not video.MJPEGCapture(str(tmp_path / "missing.avi")).isOpened()
+    raw = video.write_mjpeg_avi([b"\x00\x01\x02\x03" * 8], 4, 4).replace(b"MJPG", b"H264")
+    cap = video.MJPEGCapture(raw)
+    assert not cap.isOpened() and "H264" in cap.error
+    with pytest.raises(ValueError):
+        video.complete_mjpeg_frame(b"\x00\x00")
+
+
+def test_imread_falls_back_to_the_host_for_what_the_device_decoder_refuses(emu_engine, tmp_path):
+    """FaceAna.imread == cv2.imread(path) (demo.py:76): baseline JPEG -> DeviceFrame; progressive JPEG / PNG -> host-decoded BGR
+    array; unreadable -> None."""
+    fa = types.SimpleNamespace(engine=emu_engine)
+    rgb = _photo(40, 56, 9)
+    base = FaceAna.imread(fa, _jpeg(rgb, quality=90))
+    assert hasattr(base, "ptr") and base.shape == (40, 56, 3)
+    prog = _jpeg(rgb, quality=90, progressive=True)
+    got = FaceAna.imread(fa, prog)
+    assert isinstance(got, np.ndarray) and np.array_equal(got, np.asarray(Image.open(io.BytesIO(prog)).convert("RGB"))[:, :, ::-1])
+    png = io.BytesIO()
+    Image.fromarray(rgb).save(png, format="PNG")
+    p = tmp_path / "face.png"
+    p.write_bytes(png.getvalue())
+    assert np.array_equal(FaceAna.imread(fa, str(p)), rgb[:, :, ::-1])
+    assert FaceAna.imread(fa, b"not an image at all") is None
+    assert FaceAna.imread(fa, str(tmp_path / "nope.jpg")) is None
