@@ -167,11 +167,11 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
  * device stages run once over the whole batch.  Files that carry restart markers (one interleaved scan, table ids 0 / 1) in batches
  * of >= 4096 restart intervals skip the host Huffman loop: one device thread per interval decodes the stream, and only the
  * compressed scan crosses PCIe; files WITHOUT restart markers always take the device's sub-sequence decoder
- * (PEPPA_JPEG_ENTROPY=host|device overrides either choice).  If that decoder does not settle, this asynchronous call cannot decode
+ * (pf_set_option(PF_OPT_JPEG_ENTROPY, 1 | 2) overrides either choice).  If that decoder does not settle, this asynchronous call cannot decode
  * again by itself: the next synchronising call on the handle fails with "did not synchronise" and the batch has to be resubmitted
- * with PEPPA_JPEG_ENTROPY=host (ordinary photographs settle in the first rounds; PEPPA_JPEG_ROUNDS=1..10 queues fewer rounds than
- * the default 10 -- it can only make the decoder give up sooner, i.e. fall back or report, never return different pixels; the tests
- * use it to reach the fallback).  Asynchronous like pf_run_frames: the frames are valid in the order of the
+ * after pf_set_option(PF_OPT_JPEG_ENTROPY, 1) (ordinary photographs settle in the first rounds; PF_OPT_JPEG_SYNC_ROUNDS queues fewer
+ * rounds than the default 10 -- that can only make the decoder give up sooner, i.e. fall back or report, never return different
+ * pixels).  Asynchronous like pf_run_frames: the frames are valid in the order of the
  * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets
  * alternate, so the pointer of call k stays valid until call k + 2 and the host work of call k + 1 overlaps the pipeline still
  * running on the frames of call k. */
@@ -262,7 +262,14 @@ enum { PF_OPT_HIP_GRAPH = 1,
         * synchronising entry point (pf_sync, any call with host outputs) fail with a message naming the op -- never silent
         * inf or garbage.  The remedy is to load the program with PF_DTYPE_F32 (exact f32 MFMA), which the Python facade does
         * on its own. */
-       PF_OPT_RANGE_CHECK = 2 };
+       PF_OPT_RANGE_CHECK = 2,
+       /* Where pf_decode_jpeg* decodes the Huffman stream: 0 = automatic (device for files without restart markers and for
+        * batches that offer >= 4096 restart intervals, host threads otherwise), 1 = host, 2 = device. */
+       PF_OPT_JPEG_ENTROPY = 3,
+       /* Synchronisation rounds queued by the self-synchronising sub-sequence decoder (1 .. 10; 0 = all 10).  Fewer rounds save
+        * empty launches on ordinary photographs; a stream that needs more is decoded again on the host (synchronous call) or
+        * reported at the next synchronisation (pf_decode_jpeg_batch) -- never passed on. */
+       PF_OPT_JPEG_SYNC_ROUNDS = 4 };
 int pf_set_option(pf_handle* h, int option, int value);
 
 /* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream

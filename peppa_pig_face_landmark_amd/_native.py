@@ -17,6 +17,7 @@ PF_NET_LANDMARK, PF_NET_DETECTOR = 0, 1
 PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 PF_OPT_HIP_GRAPH = 1
 PF_OPT_RANGE_CHECK = 2
+PF_OPT_JPEG_ENTROPY, PF_OPT_JPEG_SYNC_ROUNDS = 3, 4       # entropy decoding: 0 automatic / 1 host / 2 device; sync rounds 1..10 (0 = all)
 PF_COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

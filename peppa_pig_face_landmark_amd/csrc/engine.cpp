@@ -94,6 +94,8 @@ struct pf_handle {
     // f32s range guard (pf_common.h pf_amax, k_layers.h range_verdict_kernel): on for every forward unless switched off with
     // PF_OPT_RANGE_CHECK = 0; the slots live with each program
     int range_every = 1;
+    int jpeg_entropy = 0;               // PF_OPT_JPEG_ENTROPY: 0 automatic, 1 host, 2 device (jpeg.inl)
+    int jpeg_rounds = 0;                // PF_OPT_JPEG_SYNC_ROUNDS: 0 = all PF_JPEG_SYNC_ROUNDS
     unsigned long long n_calls = 0;
     int* h_status = nullptr;            // page-locked, device-visible: {code, op, value bits, program slot}
     // RCCL communicator for pf_broadcast_weights (comm.inl); created lazily, one per handle
@@ -911,7 +913,7 @@ static int check_numerics(pf_handle* h) {
     h->h_status[0] = 0;
     if (code == 3)
         PF_FAIL(h, "pf_decode_jpeg_batch: the parallel entropy decoder did not synchronise (%d sub-sequence records still changing "
-                   "after the last round): the frames of that batch are invalid; decode it again with PEPPA_JPEG_ENTROPY=host", op);
+                   "after the last round): the frames of that batch are invalid; decode it again with pf_set_option(PF_OPT_JPEG_ENTROPY, 1)", op);
     PF_FAIL(h, "activation range check failed: input of op %d of program %d has max |x| = %g, %s the range [9.8e-4, 6e4] the "
                "split-precision (f32s) convolutions can represent (outputs were set to NaN); rebuild the program with dtype 'f32'",
             op, slot, (double)v, code == 1 ? "above" : "below");

@@ -534,7 +534,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
     std::vector<JpegFrameDesc> descs((size_t)n);
     // Where the Huffman stream is decoded.  A restart interval is one GPU thread, and a GPU thread is slow (a 120-MCU interval of a
     // 1080p file takes ~7 ms): the device wins when the batch offers thousands of intervals (96 files x 68: 11.8 k files/s against
-    // 3.6-5.2 k on 16-96 host threads), a single file is faster on one host core (4 ms).  PEPPA_JPEG_ENTROPY=host|device overrides.
+    // 3.6-5.2 k on 16-96 host threads), a single file is faster on one host core (4 ms).  PF_OPT_JPEG_ENTROPY overrides.
     // A file without restart markers is cut into 1024-bit sub-sequences that synchronise themselves (k_jpeg.h jpeg_sync_kernel): a
     // 1080p file offers ~3 500 of them, so that path goes to the device for any batch size.
     bool device_entropy = hd.restart <= 0;
@@ -542,10 +542,10 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         const long long intervals = (long long)n * ((hd.mcux * hd.mcuy + hd.restart - 1) / hd.restart);
         device_entropy = intervals >= 4096;
     }
-    if (const char* e = getenv("PEPPA_JPEG_ENTROPY")) device_entropy = e[0] == 'd';
+    if (h->jpeg_entropy != 0) device_entropy = h->jpeg_entropy == 2;          // PF_OPT_JPEG_ENTROPY: 1 host, 2 device
     if (force_host) device_entropy = false;
     int rounds = PF_JPEG_SYNC_ROUNDS;
-    if (const char* e = getenv("PEPPA_JPEG_ROUNDS")) rounds = std::max(1, std::min(PF_JPEG_SYNC_ROUNDS, atoi(e)));      // (tests: force the fallback)
+    if (h->jpeg_rounds > 0) rounds = std::min(PF_JPEG_SYNC_ROUNDS, h->jpeg_rounds);                                    // PF_OPT_JPEG_SYNC_ROUNDS
     std::vector<std::atomic<int>> done((size_t)n);
     for (auto& d : done) d.store(0, std::memory_order_relaxed);
     // workers are pure CPU (a HIP call from a fresh thread pays the runtime's per-thread set-up under its global lock: 60 ms
@@ -708,7 +708,7 @@ static int jpeg_decode_batch(pf_handle* h, int n, const uint8_t* const* jpegs, c
         }
         if (check_numerics(h)) return 1;
     }
-    if (getenv("PEPPA_JPEG_TIMING")) {
+    if (PF_ABLATE != 0 && getenv("PEPPA_JPEG_TIMING")) {      // tool build only (tools/jpeg_profile.py)
         const auto t_end = std::chrono::steady_clock::now();
         size_t up = 0;
         for (int f = 0; f < n; ++f) up += used[f];

@@ -392,6 +392,16 @@ int pf_set_option(pf_handle* h, int option, int value) {
         h->range_every = value;                                        // 0 = off, anything else = every forward
         return 0;
     }
+    if (option == PF_OPT_JPEG_ENTROPY) {
+        if (value < 0 || value > 2) PF_FAIL(h, "PF_OPT_JPEG_ENTROPY: 0 (automatic), 1 (host) or 2 (device)");
+        h->jpeg_entropy = value;
+        return 0;
+    }
+    if (option == PF_OPT_JPEG_SYNC_ROUNDS) {
+        if (value < 0) PF_FAIL(h, "PF_OPT_JPEG_SYNC_ROUNDS: value must be >= 0");
+        h->jpeg_rounds = value;
+        return 0;
+    }
     PF_FAIL(h, "unknown option %d", option);
 }
 

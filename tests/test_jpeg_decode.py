@@ -87,7 +87,7 @@ def _check_cases(eng):
         eng.decode_jpeg_batch([files[0], _encode(_image(48, 56, seed=1), quality=80, subsampling=2)])
     # files with restart markers: the Huffman stream itself can be decoded on the device (one thread per restart interval; chosen
     # automatically for big batches, forced here)
-    os.environ["PEPPA_JPEG_ENTROPY"] = "device"
+    eng.set_option(_native.PF_OPT_JPEG_ENTROPY, 2)
     eng.profile_enable(True)
     for (h, w), kw in (((67, 101), dict(subsampling=2, restart_marker_blocks=2)), ((64, 96), dict(subsampling=0, restart_marker_rows=1)),
                        ((35, 53), dict(subsampling=1, restart_marker_blocks=5)), ((50, 70), dict(subsampling=2, restart_marker_blocks=1, optimize=True)),
@@ -106,7 +106,7 @@ def _check_cases(eng):
     # files WITHOUT restart markers (what cameras write): the stream is cut into 1024-bit sub-sequences that synchronise themselves
     # on the device (csrc/k_jpeg.h jpeg_sync_kernel); quality 100 noise has 64-coefficient blocks without end-of-block codes, the
     # slowest case to synchronise (threads walk on through the following sub-sequences)
-    os.environ.pop("PEPPA_JPEG_ENTROPY", None)
+    eng.set_option(_native.PF_OPT_JPEG_ENTROPY, 0)
     eng.profile_enable(True)
     eng.profile_fetch()
     for (h, w), kw in (((120, 160), dict(quality=100, subsampling=2)), ((64, 64), dict(quality=100, subsampling=0)),
@@ -122,7 +122,7 @@ def _check_cases(eng):
     names = list(eng.profile_fetch())
     assert "jpeg_subseq" in names and "jpeg_unpack" not in names, names
     # a stream that needs more rounds than were queued is NOT passed on: the synchronous call falls back to the host decoder
-    os.environ["PEPPA_JPEG_ROUNDS"] = "1"
+    eng.set_option(_native.PF_OPT_JPEG_SYNC_ROUNDS, 1)
     data = _encode(_image(120, 160, seed=520), quality=100, subsampling=2)
     _, _, _, got = eng.decode_jpeg(data)
     assert np.array_equal(got, _pil_decode(data))
@@ -131,9 +131,9 @@ def _check_cases(eng):
     eng.decode_jpeg_batch([data, data], threads=1)
     with pytest.raises(_native.PeppaHipError, match="did not synchronise"):
         eng.sync()
-    os.environ.pop("PEPPA_JPEG_ROUNDS", None)
+    eng.set_option(_native.PF_OPT_JPEG_SYNC_ROUNDS, 0)
     eng.profile_enable(False)
-    os.environ["PEPPA_JPEG_ENTROPY"] = "device"
+    eng.set_option(_native.PF_OPT_JPEG_ENTROPY, 2)
     # a batch that mixes both kinds: each file takes its own route
     imgs = [_image(48, 80, seed=60 + i) for i in range(4)]
     files = [_encode(im, quality=85, subsampling=2, **(dict(restart_marker_rows=1) if i % 2 else {})) for i, im in enumerate(imgs)]
@@ -142,7 +142,7 @@ def _check_cases(eng):
     for i, ref in enumerate(refs):
         got = eng.letterbox(_native.DeviceFrame(d + i * hh * ww * 3, hh, ww), (48, 80))
         assert np.array_equal(got[0], eng.letterbox(ref, (48, 80))[0]), i
-    os.environ.pop("PEPPA_JPEG_ENTROPY", None)
+    eng.set_option(_native.PF_OPT_JPEG_ENTROPY, 0)
     # refused, not approximated
     with pytest.raises(_native.PeppaHipError, match="progressive"):
         eng.decode_jpeg(_encode(img, quality=85, progressive=True))
@@ -297,7 +297,7 @@ def _malformed(library, trials):
                 i = int(rng.integers(2, min(len(data), 600)))
                 data[i] = int(rng.integers(0, 256))
                 data = data[:int(rng.integers(len(data) // 2, len(data) + 1))]
-            os.environ["PEPPA_JPEG_ENTROPY"] = "device" if trial % 2 else "host"
+            eng.set_option(_native.PF_OPT_JPEG_ENTROPY, 2 if trial % 2 else 1)
             try:
                 _, h, w, got = eng.decode_jpeg(bytes(data))
                 assert got.shape == (h, w, 3)
@@ -305,7 +305,6 @@ def _malformed(library, trials):
             except _native.PeppaHipError:
                 outcomes["error"] += 1
     finally:
-        os.environ.pop("PEPPA_JPEG_ENTROPY", None)
         eng.close()
     assert outcomes["ok"] > trials // 12 and outcomes["error"] > trials // 12, outcomes
 
