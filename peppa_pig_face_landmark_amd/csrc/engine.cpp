@@ -29,7 +29,10 @@
 
 namespace {
 
-const int kNumCUs = 256;   // MI355X: 8 XCDs x 32 CUs; persistent kernels launch one workgroup per CU
+// Compute units of the device the process runs on: 256 on MI355X (8 XCDs x 32 CUs), queried at pf_create.  Persistent kernels size
+// their grids with it and the tile pickers count rounds of workgroups over the chip with it; correctness never depends on it (tiles
+// are strided over gridDim).  The blockIdx & 7 == XCD affinity of the sepup kernels is an MI355X speed assumption only.
+int kNumCUs = 256;
 // workgroups per CU x CUs of the tile-walking kernels (k_det.h det_stem_kernel, k_front.h): the CPU emulator flavour caps the grid
 // at 5 workgroups so that its small test images still make every workgroup walk several tiles
 #ifdef PF_SIMT_EMULATION
@@ -165,9 +168,14 @@ struct ProfScope {
 // ((TH-1)*S+3) x ((TW-1)*S+3) fits the kernel's MAXR LDS rows.  Cost model: launches of these kernels are chains of a few
 // phases (~3 us of fixed latency = ~768 rows' worth of work), so fewer rounds of workgroups over the chip come first, then
 // the smaller tile; the halo rows every extra tile re-computes count with the chip's width.
+static int g_det_tile_th = 0, g_det_tile_tw = 0;     // ablation build only: PEPPA_DET_TILE=th,tw forces the tile wherever it fits (tile sweeps)
 static void det_pick_tile(int outH, int outW, int S, int max_rows, int B, int wg_per_cu, int* TH, int* TW) {
     double best = 1e30;
     *TH = 1; *TW = 1;
+    if (PF_ABLATE != 0 && g_det_tile_th > 0 && ((g_det_tile_th - 1) * S + 3) * ((g_det_tile_tw - 1) * S + 3) <= max_rows) {
+        *TH = std::min(g_det_tile_th, outH); *TW = std::min(g_det_tile_tw, outW);
+        return;
+    }
     for (int div = 1; div <= 16; ++div) {
         const int tw = (outW + div - 1) / div;
         if (div > 1 && tw == (outW + div - 2) / (div - 1)) continue;
@@ -952,12 +960,31 @@ int pf_create(int device_id, pf_handle** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device visible (the engine has no CPU fallback)"; return 1; }
     if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return 1; }
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return 1; }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus >= 8) kNumCUs = cus;
+    }
     pf_handle* h = new pf_handle();
     h->device = device_id;
     if constexpr (PF_ABLATE != 0) {      // ablation build only (libpeppa_hip_ablate.so): ablated kernels compute garbage, so the guard is off
         if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) h->range_every = 0; }
+        if (const char* v = getenv("PEPPA_DET_TILE")) { if (sscanf(v, "%d,%d", &g_det_tile_th, &g_det_tile_tw) != 2) g_det_tile_th = g_det_tile_tw = 0; }
     }
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+    bool masked = false;
+    if constexpr (PF_ABLATE != 0) {      // experiment: every handle of the process on its own share of the CUs (PEPPA_CU_PARTITION=parts,mode)
+        static int s_lane = 0;
+        int parts = 0, mode = 1;
+        if (const char* v = getenv("PEPPA_CU_PARTITION")) (void)sscanf(v, "%d,%d", &parts, &mode);
+        if (parts > 1) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const int lane = s_lane++ % parts, per = kNumCUs / parts;
+            for (int c = 0; c < kNumCUs; ++c)
+                if ((mode == 1 && c % parts == lane) || (mode == 2 && c / per == lane) || (mode == 3 && (c / 8) % parts == lane)) mask[c >> 5] |= 1u << (c & 31);
+            masked = hipExtStreamCreateWithCUMask(&h->stream, 8, mask) == hipSuccess;
+            fprintf(stderr, "[peppa-hip] handle %d: CU partition %d/%d mode %d: %s\n", s_lane - 1, lane, parts, mode, masked ? "ok" : "FAILED");
+        }
+    }
+    if ((!masked && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) ||
         hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
         g_create_error = "stream/event creation failed";
         delete h;

@@ -4,8 +4,12 @@ import csv, glob, json, os, subprocess, sys, collections
 sub = sys.argv[1]
 args = sys.argv[2:]
 counters = None
-if args and args[0].startswith("--counters="):      # one rocprofv3 pass per listed counter (e.g. FETCH_SIZE,WRITE_SIZE)
-    counters = args.pop(0).split("=", 1)[1].split(",")
+out_name = None
+while args and (args[0].startswith("--counters=") or args[0].startswith("--out=")):
+    if args[0].startswith("--out="):                 # gpurun_out/<name>.json instead of pmc_<substring>.json
+        out_name = args.pop(0).split("=", 1)[1]
+    else:                                            # one rocprofv3 pass per listed counter (e.g. FETCH_SIZE,WRITE_SIZE)
+        counters = args.pop(0).split("=", 1)[1].split(",")
 bench_args = args or ["--workload", "landmark", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--lanes", "1"]
 GROUPS = [["SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS"],
           ["SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_MFMA", "SQ_INSTS_SMEM"],
@@ -35,4 +39,4 @@ for k, cs in out.items():
     for c, v in cs.items():
         print(f"   {c:24s} {v:16.0f}")
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open(f"gpurun_out/pmc_{sub.replace('<','_').replace(',','_').replace(' ','')[:40]}.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/%s.json" % (out_name or "pmc_" + sub.replace('<', '_').replace(',', '_').replace(' ', '')[:40]), "w"), indent=1)
