@@ -20,6 +20,7 @@
 #include "k_chain.h"
 #include "k_det.h"
 #include "k_front.h"
+#include "k_hrb.h"
 #include "k_sepup.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
@@ -330,6 +331,28 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 if (to.C % 16) PF_FAIL(h, "stem conv needs a multiple of 16 output channels, got %d", to.C);
                 if (a.act != PF_ACT_NONE && a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH && a.act != PF_ACT_SILU) PF_FAIL(h, "stem conv: unsupported activation %d", a.act);
                 ProfScope ps(h, "stem_conv");
+                if constexpr (SPLIT) {
+                    // f32s programs whose packer provided MFMA weights: the staged-image matrix-core kernel (k_front.h)
+                    if (f[0] < 0 && f[6] >= 0 && (to.C == 16 || to.C == 64) && (p.hdr.in_w & 3) == 0 && ((size_t)d_input & 3) == 0 && to.H == p.hdr.in_h / 2) {
+                        StemMfmaArgs s{};
+                        s.in = d_input; s.out = (float*)p.tensor_ptr(f[1]); s.outLd = to.ld;
+                        s.w_u8 = (const pf_half*)p.cptr(f[6]); s.w_f32 = (const pf_half*)p.cptr(f[7]); s.bias = (const float*)p.cptr(f[3]);
+                        memcpy(&s.s_u8, &f[8], 4); memcpy(&s.s_f32, &f[9], 4);
+                        s.B = B; s.H = p.hdr.in_h; s.W = p.hdr.in_w; s.OH = to.H; s.OW = to.W; s.act = a.act;
+                        s.TH = 8; s.TW = 32; s.tilesX = pf_div_up(to.W, s.TW);
+                        s.range_slot = slot_of(oi);
+                        const dim3 sg(s.tilesX * pf_div_up(to.H, s.TH), B);
+                        // tile 8 x 32 output pixels: image region 17 rows x 65 pixels (200 halves per LDS row)
+                        if (to.C == 16) {
+                            if (a.in_f32_nchw) PF_LAUNCH((stem_mfma_kernel<1, 256, 17, 200, true>), sg, dim3(256), h->stream, s);
+                            else PF_LAUNCH((stem_mfma_kernel<1, 256, 17, 200, false>), sg, dim3(256), h->stream, s);
+                        } else {
+                            if (a.in_f32_nchw) PF_LAUNCH((stem_mfma_kernel<4, 256, 17, 200, true>), sg, dim3(256), h->stream, s);
+                            else PF_LAUNCH((stem_mfma_kernel<4, 256, 17, 200, false>), sg, dim3(256), h->stream, s);
+                        }
+                        break;
+                    }
+                }
                 PF_LAUNCH((stem_conv_kernel<T>), dim3(pf_div_up(B * to.H * to.W, 256), to.C / 16), dim3(256), h->stream, a);
                 break;
             }
@@ -547,6 +570,40 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     const dim3 sg(persistent_grid(a.tilesX * pf_div_up(a.OH, a.TH) * B, 3));     // persistent: three workgroups per CU walk the tiles
                     if (a.in_f32_nchw) PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, true, 256>), sg, dim3(256), h->stream, a);
                     else PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, false, 256>), sg, dim3(256), h->stream, a);
+                }
+                break;
+            }
+            case PF_OP_HRB: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused Bottleneck op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    HrbArgs a{};
+                    a.x = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.w1 = (const pf_half*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]);
+                    a.w2 = (const pf_half*)p.cptr(f[4]); a.b2 = (const float*)p.cptr(f[5]);
+                    a.w3 = (const pf_half*)p.cptr(f[6]); a.b3 = (const float*)p.cptr(f[7]);
+                    a.wd = (const pf_half*)p.cptr(f[8]); a.bd = (const float*)p.cptr(f[9]);
+                    memcpy(&a.s1, &f[10], 4); memcpy(&a.s2, &f[11], 4); memcpy(&a.s3, &f[12], 4); memcpy(&a.sd, &f[13], 4);
+                    const int CIN = f[14];
+                    a.B = B; a.H = ti.H; a.W = ti.W; a.xLd = ti.ld; a.outLd = to.ld;
+                    if (ti.C != CIN || to.C != 256 || to.H != ti.H || to.W != ti.W || 3 * (ti.W + 2) > 272 || (CIN == 64) != (a.wd != nullptr))
+                        PF_FAIL(h, "hrb: inconsistent shapes");
+                    a.TR = std::min(ti.H, 272 / (ti.W + 2) - 2);
+                    a.tiles_y = pf_div_up(ti.H, a.TR);
+                    a.range_slot = slot_of(oi);
+                    if (host_dbg(h) & 4096) {
+                        if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
+                        a.prof = h->d_dbg + 144 + (CIN == 64 ? 0 : 4);
+                    }
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "bottleneck_c%d_%dx%d", CIN, ti.H, ti.W);
+                    ProfScope ps(h, tagbuf);
+                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272>), dim3(a.tiles_y, B), dim3(1024), h->stream, a);
+                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272>), dim3(a.tiles_y, B), dim3(1024), h->stream, a);
+                    else PF_FAIL(h, "hrb: no kernel for %d input channels", CIN);
                 }
                 break;
             }
@@ -1023,6 +1080,12 @@ void pf_destroy(pf_handle* h) {
                         k % 3 == 0 ? 32 : (k % 3 == 1 ? 64 : 128), k / 3 + 1, q[0] / n, q[1] / n, q[2] / n, q[3] / n, n);
             }
         }
+        unsigned long long hb[8];
+        if (hipMemcpy(hb, h->d_dbg + 144, sizeof(hb), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < 2; ++k)
+                if (hb[4 * k + 3])
+                    fprintf(stderr, "[det_hr_bottleneck CIN=%d] per workgroup (cycles): conv1 %.0f | conv2 %.0f | conv3+store %.0f  (%.0f workgroups)\n", k ? 256 : 64,
+                            hb[4 * k] / (double)hb[4 * k + 3], hb[4 * k + 1] / (double)hb[4 * k + 3], hb[4 * k + 2] / (double)hb[4 * k + 3], (double)hb[4 * k + 3]);
         unsigned long long w9[9];
         if (hipMemcpy(w9, h->d_dbg + 128, sizeof(w9), hipMemcpyDeviceToHost) == hipSuccess && w9[8]) {
             const double n = (double)w9[8];

@@ -1,0 +1,263 @@
+// HRNet Bottleneck (timm hrnet.py Bottleneck; TeacherNet encoder layer1, model.py:306-311; oracle/teacher_net.py::_bottleneck) in
+// ONE launch (round 4):   out = relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(relu(bn1(conv1_1x1(x)))))))) + shortcut(x))
+// with mid = 64 channels, 256 out; shortcut = x (256 channels) or a 1x1 conv + bn of x (the first block: 64 channels in).
+// Layer by layer the four blocks of layer1 were 13 launches and 5.5 of the Teacher's 23.9 ms per 256 crops, bandwidth-bound: the
+// 256-channel 64 x 64 map (4 MB per face) crossed HBM three times per block.  Here it is read once (its halo rows twice) and
+// written once per block.  A workgroup (16 waves) owns TR whole rows of one face's map:
+//   conv1   K loop over 32-channel chunks of x: the chunk of the (TR + 2) x (W + 2) region for step c + 1 is loaded to registers
+//           while the MFMAs of step c run on the planes in LDS (two buffers), accumulators (<= 5 tiles per wave) in registers;
+//           relu, zero outside the image (conv2 pads ITS input) -> mid1 planes
+//   conv2   3x3 as nine shifted fragment reads of the mid1 planes, the next tap's weight fragments requested before the
+//           current tap's MFMAs; result parked over mid1 after a barrier
+//   conv3   wave = one 16-channel tile of the 256 outputs, walks the tile's pixel sub-tiles; the stride-... first block's
+//           shortcut conv runs beside it on the x planes that are still resident (64 input channels = 2 chunks = both buffers);
+//           the identity shortcut is re-read from L2 (the K loop has just streamed it)
+// Split precision (3 x v_mfma_f32_16x16x32_f16 per 32 k), range guard like every other splitting kernel.
+#pragma once
+#include "k_det.h"
+
+struct HrbArgs {
+    const float* x;       // [B][H][W][xLd], CIN channels
+    float* out;           // [B][H][W][outLd], 256 channels
+    const pf_half* w1; const float* b1;     // [64][CIN/32][64]
+    const pf_half* w2; const float* b2;     // [64][9][2][64]
+    const pf_half* w3; const float* b3;     // [256][2][64]
+    const pf_half* wd; const float* bd;     // downsample [256][2][64] (CIN == 64 blocks only) or nullptr
+    float s1, s2, s3, sd;
+    int B, H, W, xLd, outLd, TR, tiles_y;
+    unsigned* range_slot;
+    unsigned long long* prof;   // ablation build only (PEPPA_DBG & 4096): cycles of conv1 / conv2 / conv3 [3], workgroups
+};
+
+template <int CIN, bool DS, int MAXR>
+__global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
+    constexpr int NTHR = 1024, NW = 16, KSA = CIN / 32;
+    constexpr int PL = 2 * MAXR * 64;                               // one 32-channel chunk: hi + lo planes
+    static_assert(!DS || CIN == 64, "the shortcut conv reads both resident chunks of a 64-channel input");
+    __shared__ __attribute__((aligned(16))) unsigned char s_x[2 * PL];      // x chunk planes, two buffers
+    __shared__ __attribute__((aligned(16))) unsigned char s_m[2 * PL];      // mid1 planes (region rows); later mid2 (tile rows)
+    __shared__ unsigned char s_in[MAXR];
+    PF_EMU_POISON(s_x); PF_EMU_POISON(s_m); PF_EMU_POISON(s_in);
+
+    unsigned amax = 0;
+    const unsigned amax_seen = pf_amax_seen(a.range_slot);
+    const bool prof = PF_ABLATE != 0 && a.prof != nullptr;
+    const unsigned long long t0 = prof ? pf_clock() : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, oy0 = (int)blockIdx.x * a.TR;
+    const int RW = a.W + 2, R = (a.TR + 2) * RW, MR = (R + 15) & ~15;
+    const int P = a.TR * a.W, MRD = (P + 15) & ~15;
+    const int g = lane >> 4, g4 = g * 4;
+    const float* x = a.x + (size_t)b * a.H * a.W * a.xLd;
+
+    // ---- conv1: K loop over the chunks of x ------------------------------------------------------------------------------------------
+    constexpr int ITX = (MAXR * 4 + NTHR - 1) / NTHR;               // (region row, 8-channel unit) pairs per thread and chunk
+    pf_f32x4 st[ITX][2];
+    int xo[ITX];                                                    // element offset of this thread's units (-1: outside the image / region)
+#pragma unroll
+    for (int it = 0; it < ITX; ++it) {
+        const int i = tid + it * NTHR;
+        const int r = i >> 2;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int iy = oy0 - 1 + ry, ix = rx - 1;
+        const bool ok = r < R && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        xo[it] = ok ? (iy * a.W + ix) * a.xLd + (i & 3) * 8 : -1;
+        if ((i & 3) == 0 && r < MR) s_in[r] = ok ? 1 : 0;
+    }
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            st[it][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            st[it][1] = st[it][0];
+            if (xo[it] >= 0) {
+                st[it][0] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32);
+                st[it][1] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32 + 4);
+            }
+        }
+    };
+    auto park_x = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            const int i = tid + it * NTHR;
+            if ((i >> 2) < MR) det_park8(s_x + buf * PL, MR, i >> 2, i & 3, st[it][0], st[it][1], amax);
+        }
+    };
+    const int ntA = wave & 3, mgA = wave >> 2;                      // conv1 / conv2: 4 channel tiles x 4 groups of pixel tiles
+    constexpr int MAXTA = (MAXR / 16 + 3) / 4;
+    pf_f32x4 accA[MAXTA];
+#pragma unroll
+    for (int j = 0; j < MAXTA; ++j) accA[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+    load_x(0);
+    pf_half8 wh[1], wl[1], wnh[1], wnl[1];                          // conv1 weight fragments: this step's and the next one's
+    const pf_half* w1p = a.w1 + ((size_t)(ntA * 16 + (lane & 15)) * KSA) * 64 + g * 8;
+    wh[0] = *reinterpret_cast<const pf_half8*>(w1p);
+    wl[0] = *reinterpret_cast<const pf_half8*>(w1p + 32);
+    park_x(0);
+    __syncthreads();
+#pragma unroll 1
+    for (int c = 0; c < KSA; ++c) {
+        if (c + 1 < KSA) {                                          // next step's pixels and weights: in flight across this step's MFMAs
+            load_x(c + 1);
+            wnh[0] = *reinterpret_cast<const pf_half8*>(w1p + (c + 1) * 64);
+            wnl[0] = *reinterpret_cast<const pf_half8*>(w1p + (c + 1) * 64 + 32);
+        }
+        const unsigned char* xb = s_x + (c & 1) * PL;
+#pragma unroll
+        for (int j = 0; j < MAXTA; ++j) {
+            const int mt = mgA + 4 * j;
+            if (mt < MR / 16) {
+                pf_half8 xh, xl;
+                det_frag(xb, MR, 0, mt * 16 + (lane & 15), g, xh, xl);
+                accA[j] = pf_mfma_16x16x32_f16(wl[0], xh, accA[j]);
+                accA[j] = pf_mfma_16x16x32_f16(wh[0], xl, accA[j]);
+                accA[j] = pf_mfma_16x16x32_f16(wh[0], xh, accA[j]);
+            }
+        }
+        if (c + 1 < KSA) {
+            park_x((c + 1) & 1);                                    // the other buffer: nobody reads it during this step
+            wh[0] = wnh[0]; wl[0] = wnl[0];
+            __syncthreads();
+        }
+    }
+    {
+        const pf_f32x4 b1v = *reinterpret_cast<const pf_f32x4*>(a.b1 + ntA * 16 + g4);
+#pragma unroll
+        for (int j = 0; j < MAXTA; ++j) {
+            const int mt = mgA + 4 * j;
+            if (mt < MR / 16) {
+                const int r = mt * 16 + (lane & 15);
+                pf_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = fmaf(accA[j][e], a.s1, b1v[e]); v[e] = v[e] > 0.f ? v[e] : 0.f; }
+                if (!s_in[r]) v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                det_park4(s_m, MR, r, ntA * 4 + g, v, amax);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long t1 = prof ? pf_clock() : 0;
+
+    // ---- conv2: 3x3 on the mid1 planes -----------------------------------------------------------------------------------------------
+    constexpr int MAXTB = (MAXR / 16 + 3) / 4;                      // (tile rows <= region rows)
+    pf_f32x4 accB[MAXTB];
+    int rowB[MAXTB];
+#pragma unroll
+    for (int j = 0; j < MAXTB; ++j) {
+        accB[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        const int p = (mgA + 4 * j) * 16 + (lane & 15);
+        const int pc = p < P ? p : 0;
+        const int py = pc / a.W, px = pc - py * a.W;
+        rowB[j] = py * RW + px;                                     // region row of tap (0, 0)
+    }
+    auto w2frag = [&](int tap, pf_half8 (&h)[2], pf_half8 (&l)[2]) {
+        const pf_half* p = a.w2 + (((size_t)(ntA * 16 + (lane & 15)) * 9 + tap) * 2) * 64 + g * 8;
+        h[0] = *reinterpret_cast<const pf_half8*>(p); l[0] = *reinterpret_cast<const pf_half8*>(p + 32);
+        h[1] = *reinterpret_cast<const pf_half8*>(p + 64); l[1] = *reinterpret_cast<const pf_half8*>(p + 96);
+    };
+    pf_half8 wch[2], wcl[2], w2nh[2], w2nl[2];
+    w2frag(0, wch, wcl);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) w2frag(tap + 1, w2nh, w2nl);
+        const int shift = (tap / 3) * RW + tap % 3;
+#pragma unroll
+        for (int j = 0; j < MAXTB; ++j) {
+            if (mgA + 4 * j < MRD / 16) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    pf_half8 zh, zl;
+                    det_frag(s_m, MR, ks, rowB[j] + shift, g, zh, zl);
+                    accB[j] = pf_mfma_16x16x32_f16(wcl[ks], zh, accB[j]);
+                    accB[j] = pf_mfma_16x16x32_f16(wch[ks], zl, accB[j]);
+                    accB[j] = pf_mfma_16x16x32_f16(wch[ks], zh, accB[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { wch[ks] = w2nh[ks]; wcl[ks] = w2nl[ks]; }
+    }
+    // weights of conv3 (and of the shortcut conv): in flight across the two barriers
+    const int ntC = wave;                                          // conv3: wave = one of the 16 channel tiles
+    pf_half8 w3h[2], w3l[2], wdh[DS ? 2 : 1], wdl[DS ? 2 : 1];
+    det_wfrag<2>(a.w3, ntC, lane, w3h, w3l);
+    pf_f32x4 b3v = *reinterpret_cast<const pf_f32x4*>(a.b3 + ntC * 16 + g4);
+    if constexpr (DS) {
+        det_wfrag<2>(a.wd, ntC, lane, wdh, wdl);
+        const pf_f32x4 bdv = *reinterpret_cast<const pf_f32x4*>(a.bd + ntC * 16 + g4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b3v[e] += bdv[e];
+    }
+    __syncthreads();                                                // every wave is done reading mid1
+    {
+        const pf_f32x4 b2v = *reinterpret_cast<const pf_f32x4*>(a.b2 + ntA * 16 + g4);
+#pragma unroll
+        for (int j = 0; j < MAXTB; ++j) {
+            const int mt = mgA + 4 * j;
+            if (mt < MRD / 16) {
+                const int p = mt * 16 + (lane & 15);
+                pf_f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = fmaf(accB[j][e], a.s2, b2v[e]); v[e] = v[e] > 0.f ? v[e] : 0.f; }
+                if (p >= P) v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                det_park4(s_m, MRD, p, ntA * 4 + g, v, amax);
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long t2 = prof ? pf_clock() : 0;
+
+    // ---- conv3 (+ shortcut) + relu -> global -------------------------------------------------------------------------------------------
+    float* out = a.out + (size_t)b * a.H * a.W * a.outLd;
+    const int n = ntC * 16 + g4;
+#pragma unroll 1
+    for (int mt0 = 0; mt0 < MRD / 16; mt0 += 4) {
+        // the identity shortcut of four pixel sub-tiles at a time: one exposed L2 round trip per four tiles, not per tile (the first
+        // cut loaded each tile's residual right in front of its use: ~3 k cycles x 8 per workgroup)
+        pf_f32x4 res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            res[q] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (!DS) {
+                const int p = (mt0 + q) * 16 + (lane & 15);
+                const int py = p / a.W, px = p - py * a.W;
+                if (p < P && oy0 + py < a.H) res[q] = *reinterpret_cast<const pf_f32x4*>(x + ((size_t)(oy0 + py) * a.W + px) * a.xLd + n);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int mt = mt0 + q;
+            if (mt >= MRD / 16) break;
+            const int p = mt * 16 + (lane & 15);
+            const int pc = p < P ? p : 0;
+            const int py = pc / a.W, px = pc - py * a.W;
+            const int oy = oy0 + py;
+            const bool ok = p < P && oy < a.H;
+            const pf_f32x4 acc3 = det_tile<2>(s_m, MRD, mt * 16, lane, w3h, w3l);
+            pf_f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(acc3[e], a.s3, b3v[e]) + res[q][e];
+            if constexpr (DS) {
+                pf_f32x4 accd = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+                const int row = (py + 1) * RW + px + 1;             // the pixel's row in the x planes (both chunks still resident)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    pf_half8 xh, xl;
+                    det_frag(s_x + ks * PL, MR, 0, row, g, xh, xl);
+                    accd = pf_mfma_16x16x32_f16(wdl[ks], xh, accd);
+                    accd = pf_mfma_16x16x32_f16(wdh[ks], xl, accd);
+                    accd = pf_mfma_16x16x32_f16(wdh[ks], xh, accd);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(accd[e], a.sd, v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            if (ok) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.W + px) * a.outLd + n) = v;
+        }
+    }
+    pf_amax_commit(a.range_slot, amax, amax_seen);
+    if (prof && tid == 0) {
+        const unsigned long long t3 = pf_clock();
+        atomicAdd(a.prof + 0, t1 - t0); atomicAdd(a.prof + 1, t2 - t1); atomicAdd(a.prof + 2, t3 - t2); atomicAdd(a.prof + 3, 1ull);
+    }
+}

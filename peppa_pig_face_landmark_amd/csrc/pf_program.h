@@ -66,6 +66,8 @@ enum PfOpCode : int32_t {
     PF_OP_LMFRONT = 21, // f: out_t w_stem_u8 w_stem_f32 b_stem w_dw0 b_dw0 w_pw0 b_pw0 w_exp b_exp w_dw1 b_dw1 w_prj b_prj s_stem_u8 s_stem_f32 s_pw0 s_exp s_prj
                         //    (float bits) act_stem: conv_stem + blocks.0.0 + blocks.1.0 of the Student encoder in one launch on the program input
                         //    (k_front.h lm_front_kernel); split programs only
+    PF_OP_HRB = 22,     // f: in_t out_t w1 b1 w2 b2 w3 b3 wd(-1) bd(-1) s1 s2 s3 sd (float bits) CIN: an HRNet Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut, mid 64,
+                        //    out 256; wd / bd = the first block's shortcut conv) in one launch (k_hrb.h hr_bottleneck_kernel); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

@@ -24,7 +24,7 @@ DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT = range(1, 22)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT, OP_HRB = range(1, 23)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -165,7 +165,15 @@ class ProgramBuilder:
         off_u8 = self.const_f32(w / 255.0)
         off_f32 = self.const_f32(w)
         off_b = self.const_f32(bias)
-        self._op(OP_STEM, [-1, out, off_u8, off_b, ACT[act], off_f32], [], [self._tb(out)])
+        f = [-1, out, off_u8, off_b, ACT[act], off_f32, -1, -1, 0, 0]
+        if self.split and co in (16, 64) and self.in_w % 4 == 0 and self.in_h % 2 == 0:
+            # f32s programs: the same conv as a split-precision MFMA GEMM on the staged image (csrc/k_front.h stem_mfma_kernel)
+            ws = self._stem_k_order(weight)
+            wu, su = self._split_rows(ws / 255.0)
+            wf, sf = self._split_rows(ws)
+            fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+            f[6:10] = [self.const(wu), self.const(wf), fbits(su), fbits(sf)]
+        self._op(OP_STEM, f, [], [self._tb(out)])
         return out
 
     SPLIT_MIN_CIN = 64       # pointwise convs below this are bandwidth-bound: the exact-f32 direct kernel is as fast
@@ -392,6 +400,36 @@ class ProgramBuilder:
         self._op(OP_DETSTEM, [out, self.const(w1u), self.const(w1f), self.const_f32(b1), self.const(wa), self.const_f32(b2), self.const(wb),
                               self.const_f32(b2b), self.const(wc), self.const_f32(b3), fbits(s1u), fbits(s1f), fbits(sa), fbits(sb), fbits(sc)],
                  [], [self._tb(out)])
+        return out
+
+    def hr_bottleneck_supported(self, x: int, mid: int, cout: int, has_ds: bool) -> bool:
+        ti = self.tensors[x]
+        return (self.split and mid == 64 and cout == 256 and ti.C == ti.real_c and ti.W <= 64 and 3 * (ti.W + 2) <= 272
+                and ((ti.C == 64 and has_ds) or (ti.C == 256 and not has_ds)))
+
+    def hr_bottleneck(self, x: int, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out_name: str = "") -> int:
+        """HRNet Bottleneck (timm hrnet.py; oracle/teacher_net.py::_bottleneck) in ONE launch (csrc/k_hrb.h): relu(conv3(relu(conv2_3x3(
+        relu(conv1(x))))) + shortcut(x)), BN-folded weights; shortcut = x, or the 1x1 conv (wd, bd) of the first block of layer1."""
+        ti = self.tensors[x]
+        cin, mid, cout = ti.C, w1.shape[0], w3.shape[0]
+        assert self.hr_bottleneck_supported(x, mid, cout, wd is not None)
+        assert w1.shape[:2] == (mid, cin) and w2.shape == (mid, mid, 3, 3) and w3.shape[:2] == (cout, mid)
+        out = self.tensor(ti.H, ti.W, cout, name=out_name)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        w1s, s1 = self._split_rows(w1.reshape(mid, cin).astype(np.float64))
+        w2off, npad, cpad, s2, _ = self.pack_conv_weight(w2, force_split=True)
+        assert (npad, cpad) == (64, 64)
+        w3s, s3 = self._split_rows(w3.reshape(cout, mid).astype(np.float64))
+        f = [x, out, self.const(w1s), self.const_f32(b1), w2off, self.const_f32(b2), self.const(w3s), self.const_f32(b3)]
+        sd = 1.0
+        if wd is not None:
+            assert wd.shape[:2] == (cout, cin)
+            wds, sd = self._split_rows(wd.reshape(cout, cin).astype(np.float64))
+            f += [self.const(wds), self.const_f32(bd)]
+        else:
+            f += [-1, -1]
+        f += [fbits(s1), fbits(s2), fbits(s3), fbits(sd), cin]
+        self._op(OP_HRB, f, [self._tb(x)], [self._tb(out)])
         return out
 
     @staticmethod

@@ -57,6 +57,11 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
         return w1, b1, w2, b2
 
     def bottleneck(x, p, name=""):
+        has_ds = f"{p}.downsample.0.weight" in w
+        if fuse_chains and pb.hr_bottleneck_supported(x, w[f"{p}.conv1.weight"].shape[0], w[f"{p}.conv3.weight"].shape[0], has_ds):
+            f = lambda c, bn: ir.fold_bn(w[f"{p}.{c}.weight"], None, _bn(w, f"{p}.{bn}"))     # the whole block in one launch (csrc/k_hrb.h)
+            ds = f("downsample.0", "downsample.1") if has_ds else (None, None)
+            return pb.hr_bottleneck(x, *f("conv1", "bn1"), *f("conv2", "bn2"), *f("conv3", "bn3"), *ds, out_name=name)
         sc = cb(x, f"{p}.downsample.0", f"{p}.downsample.1", "none") if f"{p}.downsample.0.weight" in w else x
         y = cb(x, f"{p}.conv1", f"{p}.bn1", "relu")
         y = cb(y, f"{p}.conv2", f"{p}.bn2", "relu")
