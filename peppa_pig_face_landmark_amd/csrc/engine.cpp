@@ -1187,6 +1187,12 @@ static int net_forward_common(pf_handle* h, int slot, const void* input, int inp
         if (ensure_stage(h, in_item_bytes * batch)) return 1;
         PF_HIP(h, hipMemcpyAsync(h->d_stage, input, in_item_bytes * batch, hipMemcpyHostToDevice, h->stream));
         d_in = h->d_stage;
+    } else if ((size_t)input & 3) {
+        // the staged-image kernels (k_det.h det_stem_kernel, k_front.h) fetch the uint8 image as 32-bit words: a device pointer that is
+        // not 4-byte aligned (a view into somebody else's buffer) goes through the aligned staging buffer first
+        if (ensure_stage(h, in_item_bytes * batch)) return 1;
+        PF_HIP(h, hipMemcpyAsync(h->d_stage, input, in_item_bytes * batch, hipMemcpyDeviceToDevice, h->stream));
+        d_in = h->d_stage;
     }
     return run_program(h, slot, d_in, input_kind, batch);
 }

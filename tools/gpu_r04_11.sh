@@ -2,7 +2,7 @@
 # round 4, GPU session 11: the whole GPU test tier, the default bench, rocprofv3 kernel stats (1 lane), counters of the hero and of the new detector kernels
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-T=${1:-r04_run11}
+T=${1:-r04_run15}
 ( timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -12 ) | tee gpurun_out/${T}_pytest_gpu.log
 timeout 600 python bench.py --steps 20 --warmup 3 --dump-profile gpurun_out/${T}_kernel_table.json > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 tail -c 300 gpurun_out/${T}_bench.err
