@@ -533,8 +533,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
 #define PF_DETUNIT_CASE(CC, KK, SS, MAXR, NTHR, PERCU)                                                             \
     if (C == CC && K1 == KK && S == SS) {                                                                          \
         det_pick_tile(to.H, to.W, SS, MAXR, B, PERCU, &a.TH, &a.TW);                                               \
-        a.tilesX = pf_div_up(to.W, a.TW);                                                                          \
-        PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR, PERCU * NTHR / 256>), dim3(a.tilesX * pf_div_up(to.H, a.TH), B), dim3(NTHR), h->stream, a); \
+        a.tilesX = pf_div_up(to.W, a.TW); a.tpf = a.tilesX * pf_div_up(to.H, a.TH);                                 \
+        PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR, PERCU * NTHR / 256>), dim3(a.tpf * B), dim3(NTHR), h->stream, a); \
     } else
                     PF_DETUNIT_CASE(32, 32, 1, 256, 512, 2)
                     PF_DETUNIT_CASE(64, 64, 1, 128, 512, 2)
@@ -601,8 +601,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "bottleneck_c%d_%dx%d", CIN, ti.H, ti.W);
                     ProfScope ps(h, tagbuf);
-                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272>), dim3(a.tiles_y, B), dim3(1024), h->stream, a);
-                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272>), dim3(a.tiles_y, B), dim3(1024), h->stream, a);
+                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
+                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
                     else PF_FAIL(h, "hrb: no kernel for %d input channels", CIN);
                 }
                 break;
@@ -675,8 +675,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
 #define PF_DETC3_CASE(CC, TT, MAXR, NTHR)                                                                          \
     if (CIN == CC && tail == TT) {                                                                                 \
         det_pick_tile(a.H, a.W, 1, MAXR, B, 1, &a.TH, &a.TW);                                                      \
-        a.tilesX = pf_div_up(a.W, a.TW);                                                                           \
-        PF_LAUNCH((det_c3_kernel<CC, TT, MAXR, NTHR>), dim3(a.tilesX * pf_div_up(a.H, a.TH), B), dim3(NTHR), h->stream, a); \
+        a.tilesX = pf_div_up(a.W, a.TW); a.tpf = a.tilesX * pf_div_up(a.H, a.TH);                                   \
+        PF_LAUNCH((det_c3_kernel<CC, TT, MAXR, NTHR>), dim3(a.tpf * B), dim3(NTHR), h->stream, a); \
     } else
                     PF_DETC3_CASE(192, 1, 128, 512)
                     PF_DETC3_CASE(128, 2, 176, 512)

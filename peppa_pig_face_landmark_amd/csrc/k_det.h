@@ -132,7 +132,7 @@ struct DetUnitArgs {
     const pf_half* w3;    // stride 2: branch1 1x1  [C][K1/32][64]
     const float* b3;
     float s1, s2, s3;     // 2^-s of the three weight sets
-    int B, inH, inW, inLd, Cin, outH, outW, outLd, TH, TW, tilesX;
+    int B, inH, inW, inLd, Cin, outH, outW, outLd, TH, TW, tilesX, tpf;     // tpf: tiles per frame
     unsigned* range_slot;
     unsigned long long* prof;   // ablation build only (PEPPA_DBG & 4096): [5] cycles of phase 0 / GEMM 1 / depthwise / last GEMMs, workgroups
 };
@@ -156,8 +156,12 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
     const bool prof = PF_ABLATE != 0 && a.prof != nullptr;             // constant false in the production library
     const unsigned long long t0 = prof ? pf_clock() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int oy0 = ((int)blockIdx.x / a.tilesX) * a.TH, ox0 = ((int)blockIdx.x % a.tilesX) * a.TW;
+    // XCD-aware tile order (workgroup i runs on XCD i % 8): an XCD walks a contiguous run of (frame, tile) pairs, so the halo its
+    // tiles share is served by its own L2 instead of crossing the fabric once per neighbour
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int b = tile / a.tpf, tt = tile - b * a.tpf;
+    const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
     const int RW = (a.TW - 1) * S + 3, RH = (a.TH - 1) * S + 3, R = RH * RW, MR = (R + 15) & ~15;
     const int P = a.TH * a.TW, MRD = (P + 15) & ~15;
     const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
@@ -350,7 +354,7 @@ struct DetC3Args {
     const pf_half* wE; const float* bE;     // tail         [64 | 48][2][64]
     const float* anchors;                   // TAIL 2: [3][2]
     float sA, sB, sC, sD, sE, det_stride;
-    int B, H, W, CA, upA, ldA, ldB, outLd, out2Ld, TH, TW, tilesX, row0, nrows_total;
+    int B, H, W, CA, upA, ldA, ldB, outLd, out2Ld, TH, TW, tilesX, tpf, row0, nrows_total;
     unsigned* range_slot;
 };
 
@@ -370,8 +374,10 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int oy0 = ((int)blockIdx.x / a.tilesX) * a.TH, ox0 = ((int)blockIdx.x % a.tilesX) * a.TW;
+    int tile = blockIdx.x;                                           // XCD-aware tile order, see det_unit_kernel
+    if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int b = tile / a.tpf, tt = tile - b * a.tpf;
+    const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
     const int RW = a.TW + 2, R = (a.TH + 2) * RW, MR = (R + 15) & ~15;
     const int P = a.TH * a.TW, MRD = (P + 15) & ~15;
     const int g4 = (lane >> 4) * 4;

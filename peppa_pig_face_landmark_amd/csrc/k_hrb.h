@@ -44,7 +44,12 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
     const bool prof = PF_ABLATE != 0 && a.prof != nullptr;
     const unsigned long long t0 = prof ? pf_clock() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, oy0 = (int)blockIdx.x * a.TR;
+    // XCD-aware tile order (workgroup i runs on XCD i % 8): XCD x walks a contiguous run of (face, row-tile) pairs, so the two halo
+    // rows a tile shares with its neighbours are in THAT XCD's L2 when the neighbour asks for them -- in dispatch order every tile's
+    // neighbours sit on other XCDs and the 2 x (TR + 2) / TR read amplification of the input goes all the way to HBM
+    int tile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int b = tile / a.tiles_y, oy0 = (tile - b * a.tiles_y) * a.TR;
     const int RW = a.W + 2, R = (a.TR + 2) * RW, MR = (R + 15) & ~15;
     const int P = a.TR * a.W, MRD = (P + 15) & ~15;
     const int g = lane >> 4, g4 = g * 4;

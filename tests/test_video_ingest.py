@@ -110,3 +110,44 @@ def test_imread_falls_back_to_the_host_for_what_the_device_decoder_refuses(emu_e
     assert np.array_equal(FaceAna.imread(fa, str(p)), rgb[:, :, ::-1])
     assert FaceAna.imread(fa, b"not an image at all") is None
     assert FaceAna.imread(fa, str(tmp_path / "nope.jpg")) is None
+
+
+@pytest.mark.gpu
+def test_mjpeg_avi_through_faceana_on_the_gpu(hip_library, student_weights, detector_weights):
+    """demo.py:13-17 with the engine's ingest: every frame of a Motion-JPEG AVI decoded on the GPU (read() and read_batch()) is
+    bit-identical with libjpeg's pixels, and FaceAna.run(frame) on the DeviceFrame equals FaceAna.run on the decoded array."""
+    from peppa_pig_face_landmark_amd.core.api.facer import get_cfg
+    from peppa_pig_face_landmark_amd.synth import make_frame
+    h, w = 544, 960
+    rgbs = [np.ascontiguousarray(make_frame(h, w, 3, seed=70 + i)[0][:, :, ::-1]) for i in range(4)]
+    jpegs = [_jpeg(r, quality=90, subsampling=2) for r in rgbs]
+    avi = video.write_mjpeg_avi([jpegs[0]] + [_strip_dht(j) for j in jpegs[1:]], w, h, fps=25.0)
+    cfg = get_cfg()
+    fa = FaceAna(cfg=cfg, weights={"detector": detector_weights, "keypoints": student_weights}, library=hip_library)
+    cap = video.MJPEGCapture(avi, engine=fa.engine)
+    assert cap.isOpened() and int(cap.get(cap.CAP_PROP_FRAME_COUNT)) == 4
+    for i in range(4):
+        ok, frame = cap.read()
+        assert ok
+        ref = np.asarray(Image.open(io.BytesIO(jpegs[i])).convert("RGB"))[:, :, ::-1]
+        assert np.array_equal(frame.numpy(), ref), i
+        fa.reset()
+        got = fa.run(frame)
+        fa.reset()
+        want = fa.run(np.ascontiguousarray(ref))
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a["box"], b["box"]) and np.array_equal(a["kps"], b["kps"])
+    cap2 = video.MJPEGCapture(avi, engine=fa.engine, want_host=False)
+    d, n, hh, ww = cap2.read_batch(4, threads=2)
+    assert (n, hh, ww) == (4, h, w)
+    for i in range(4):
+        ref = np.asarray(Image.open(io.BytesIO(jpegs[i])).convert("RGB"))[:, :, ::-1]
+        got = fa.engine.letterbox(_native_frame(d + i * h * w * 3, h, w), (384, 640))[0]
+        assert np.array_equal(got, fa.engine.letterbox(np.ascontiguousarray(ref), (384, 640))[0]), i
+    fa.engine.close()
+
+
+def _native_frame(ptr, h, w):
+    from peppa_pig_face_landmark_amd import _native
+    return _native.DeviceFrame(ptr, h, w)
