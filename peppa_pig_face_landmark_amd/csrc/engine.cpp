@@ -590,8 +590,9 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.B = B; a.H = ti.H; a.W = ti.W; a.xLd = ti.ld; a.outLd = to.ld;
                     if (ti.C != CIN || to.C != 256 || to.H != ti.H || to.W != ti.W || 3 * (ti.W + 2) > 272 || (CIN == 64) != (a.wd != nullptr))
                         PF_FAIL(h, "hrb: inconsistent shapes");
-                    a.TR = std::min(ti.H, 272 / (ti.W + 2) - 2);
+                    a.TR = std::min(std::min(ti.H, 272 / (ti.W + 2) - 2), 128 / ti.W);       // region rows <= MAXR, tile pixels <= MAXP
                     a.tiles_y = pf_div_up(ti.H, a.TR);
+                    if (a.TR < 1 || (a.TR + 2) * ti.W * 4 > 1024) PF_FAIL(h, "hrb: a tile's pixels exceed one load item per thread");
                     a.range_slot = slot_of(oi);
                     if (host_dbg(h) & 4096) {
                         if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
@@ -601,8 +602,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "bottleneck_c%d_%dx%d", CIN, ti.H, ti.W);
                     ProfScope ps(h, tagbuf);
-                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
-                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
+                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272, 128, 1>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
+                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272, 128, 1>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
                     else PF_FAIL(h, "hrb: no kernel for %d input channels", CIN);
                 }
                 break;

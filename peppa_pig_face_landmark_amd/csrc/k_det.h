@@ -156,10 +156,10 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
     const bool prof = PF_ABLATE != 0 && a.prof != nullptr;             // constant false in the production library
     const unsigned long long t0 = prof ? pf_clock() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order (workgroup i runs on XCD i % 8): an XCD walks a contiguous run of (frame, tile) pairs, so the halo its
-    // tiles share is served by its own L2 instead of crossing the fabric once per neighbour
-    int tile = blockIdx.x;
-    if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    // dispatch order (tiles of a frame on consecutive workgroups = on different XCDs).  Giving each XCD a contiguous run of tiles, so
+    // that shared halo rows hit its own L2, measured 3-15 % SLOWER per launch (profiles/r04_run16_*): these launches are
+    // latency-bound, not fabric-bound
+    const int tile = blockIdx.x;
     const int b = tile / a.tpf, tt = tile - b * a.tpf;
     const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
     const int RW = (a.TW - 1) * S + 3, RH = (a.TH - 1) * S + 3, R = RH * RW, MR = (R + 15) & ~15;
@@ -374,8 +374,7 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int tile = blockIdx.x;                                           // XCD-aware tile order, see det_unit_kernel
-    if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
+    const int tile = blockIdx.x;                                     // dispatch order, see det_unit_kernel
     const int b = tile / a.tpf, tt = tile - b * a.tpf;
     const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
     const int RW = a.TW + 2, R = (a.TH + 2) * RW, MR = (R + 15) & ~15;

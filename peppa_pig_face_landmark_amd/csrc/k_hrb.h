@@ -4,14 +4,17 @@
 // Layer by layer the four blocks of layer1 were 13 launches and 5.5 of the Teacher's 23.9 ms per 256 crops, bandwidth-bound: the
 // 256-channel 64 x 64 map (4 MB per face) crossed HBM three times per block.  Here it is read once (its halo rows twice) and
 // written once per block.  A workgroup (16 waves) owns TR whole rows of one face's map:
-//   conv1   K loop over 32-channel chunks of x: the chunk of the (TR + 2) x (W + 2) region for step c + 1 is loaded to registers
-//           while the MFMAs of step c run on the planes in LDS (two buffers), accumulators (<= 5 tiles per wave) in registers;
-//           relu, zero outside the image (conv2 pads ITS input) -> mid1 planes
-//   conv2   3x3 as nine shifted fragment reads of the mid1 planes, the next tap's weight fragments requested before the
-//           current tap's MFMAs; result parked over mid1 after a barrier
-//   conv3   wave = one 16-channel tile of the 256 outputs, walks the tile's pixel sub-tiles; the stride-... first block's
-//           shortcut conv runs beside it on the x planes that are still resident (64 input channels = 2 chunks = both buffers);
-//           the identity shortcut is re-read from L2 (the K loop has just streamed it)
+//   conv1   K loop over 32-channel chunks of x: the chunks of the (TR + 2) x W pixels for steps c + 1 and c + 2 are in flight
+//           (registers) while the MFMAs of step c run on the planes in LDS (two buffers); accumulators (<= 5 tiles per wave) in
+//           registers; relu, zero outside the image (conv2 pads ITS input) -> mid1 planes.  The first block's shortcut conv
+//           (64 input channels = both buffers resident) runs right behind the loop, its accumulators wait in registers
+//   conv2   3x3 as nine shifted fragment reads of the mid1 planes; the tap's weights come from a ring of four 16 KB slots in the
+//           x buffers (free by now), filled four taps ahead with one 16-byte piece per thread; result parked over mid1
+//   conv3   wave = one 16-channel tile of the 256 outputs, walks the tile's pixel sub-tiles; the identity shortcut is re-read
+//           from L2 (the K loop has just streamed it), four sub-tiles per round trip
+// Barriers retire LDS traffic only (pf_wait_vm_barrier<63>): __syncthreads() would drain the look-ahead loads at every step.
+// Round-4 history (per workgroup, cycles, profiles/r04_run13/17_*): conv1 47 k -> 34 k (now at ~4 TB/s of x, halo rows included),
+// conv2 44 k -> 20 k, conv3 14 k; 1.50 -> 1.0 ms per block of 256 faces.
 // Split precision (3 x v_mfma_f32_16x16x32_f16 per 32 k), range guard like every other splitting kernel.
 #pragma once
 #include "k_det.h"
@@ -29,7 +32,7 @@ struct HrbArgs {
     unsigned long long* prof;   // ablation build only (PEPPA_DBG & 4096): cycles of conv1 / conv2 / conv3 [3], workgroups
 };
 
-template <int CIN, bool DS, int MAXR>
+template <int CIN, bool DS, int MAXR, int MAXP, int ITX>
 __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
     constexpr int NTHR = 1024, NW = 16, KSA = CIN / 32;
     constexpr int PL = 2 * MAXR * 64;                               // one 32-channel chunk: hi + lo planes
@@ -56,55 +59,72 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
     const float* x = a.x + (size_t)b * a.H * a.W * a.xLd;
 
     // ---- conv1: K loop over the chunks of x ------------------------------------------------------------------------------------------
-    constexpr int ITX = (MAXR * 4 + NTHR - 1) / NTHR;               // (region row, 8-channel unit) pairs per thread and chunk
-    pf_f32x4 st[ITX][2];
-    int xo[ITX];                                                    // element offset of this thread's units (-1: outside the image / region)
-#pragma unroll
-    for (int it = 0; it < ITX; ++it) {
-        const int i = tid + it * NTHR;
-        const int r = i >> 2;
-        const int ry = r / RW, rx = r - ry * RW;
-        const int iy = oy0 - 1 + ry, ix = rx - 1;
-        const bool ok = r < R && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        xo[it] = ok ? (iy * a.W + ix) * a.xLd + (i & 3) * 8 : -1;
-        if ((i & 3) == 0 && r < MR) s_in[r] = ok ? 1 : 0;
-    }
-    auto load_x = [&](int c) {
-#pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            st[it][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-            st[it][1] = st[it][0];
-            if (xo[it] >= 0) {
-                st[it][0] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32);
-                st[it][1] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32 + 4);
-            }
-        }
-    };
-    auto park_x = [&](int buf) {
+    // Only the pixels are loaded ((TR + 2) x W x four 8-channel units: one per thread and chunk at 64 x 64); the padding columns and
+    // the rows beyond the region are zeroed once in both buffers.  Chunks c + 1 AND c + 2 are in flight while the MFMAs of chunk c
+    // run: with one step of look-ahead the ~1 k cycles of a step's MFMAs did not cover a loaded-memory round trip (a step took
+    // 5.9 k cycles), and __syncthreads() would drain vmcnt at every step -- the barriers below only retire the LDS writes.
+    int xo[ITX], xr[ITX];                                           // element offset (-1: row outside the image), region row (-1: no item)
+    {
+        const int rowItems = a.W * 4, items = (a.TR + 2) * rowItems;
 #pragma unroll
         for (int it = 0; it < ITX; ++it) {
             const int i = tid + it * NTHR;
-            if ((i >> 2) < MR) det_park8(s_x + buf * PL, MR, i >> 2, i & 3, st[it][0], st[it][1], amax);
+            const int ry = i / rowItems, px = (i - ry * rowItems) >> 2;
+            const int iy = oy0 - 1 + ry;
+            xr[it] = i < items ? ry * RW + px + 1 : -1;
+            xo[it] = (i < items && (unsigned)iy < (unsigned)a.H) ? (iy * a.W + px) * a.xLd + (i & 3) * 8 : -1;
         }
+    }
+    auto load_x = [&](int c, pf_f32x4 (&s)[ITX][2]) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it) {
+            s[it][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            s[it][1] = s[it][0];
+            if (xo[it] >= 0) {
+                s[it][0] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32);
+                s[it][1] = *reinterpret_cast<const pf_f32x4*>(x + xo[it] + c * 32 + 4);
+            }
+        }
+    };
+    auto park_x = [&](int buf, const pf_f32x4 (&s)[ITX][2]) {
+#pragma unroll
+        for (int it = 0; it < ITX; ++it)
+            if (xr[it] >= 0) det_park8(s_x + buf * PL, MR, xr[it], (tid + it * NTHR) & 3, s[it][0], s[it][1], amax);
     };
     const int ntA = wave & 3, mgA = wave >> 2;                      // conv1 / conv2: 4 channel tiles x 4 groups of pixel tiles
     constexpr int MAXTA = (MAXR / 16 + 3) / 4;
     pf_f32x4 accA[MAXTA];
 #pragma unroll
     for (int j = 0; j < MAXTA; ++j) accA[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-    load_x(0);
-    pf_half8 wh[1], wl[1], wnh[1], wnl[1];                          // conv1 weight fragments: this step's and the next one's
+    constexpr int DEPTH = 3;                                        // register sets: chunk c (being parked / read), c + 1, c + 2
+    pf_f32x4 st[DEPTH][ITX][2];
+    pf_half8 wq[DEPTH][2];                                          // conv1 weight fragments (hi, lo) of the same chunks
     const pf_half* w1p = a.w1 + ((size_t)(ntA * 16 + (lane & 15)) * KSA) * 64 + g * 8;
-    wh[0] = *reinterpret_cast<const pf_half8*>(w1p);
-    wl[0] = *reinterpret_cast<const pf_half8*>(w1p + 32);
-    park_x(0);
-    __syncthreads();
-#pragma unroll 1
+#pragma unroll
+    for (int c = 0; c < 2 && c < KSA; ++c) {
+        load_x(c, st[c]);
+        wq[c][0] = *reinterpret_cast<const pf_half8*>(w1p + c * 64);
+        wq[c][1] = *reinterpret_cast<const pf_half8*>(w1p + c * 64 + 32);
+    }
+    for (int i = tid; i < MR * 4; i += NTHR) {                      // padding of both buffers, and the in-image flags of the region rows
+        const int r = i >> 2;
+        const int ry = r / RW, rx = r - ry * RW;
+        const bool pad = r >= R || rx == 0 || rx == RW - 1;
+        if (pad) {
+            const pf_f32x4 z = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            det_park8(s_x, MR, r, i & 3, z, z, amax);
+            det_park8(s_x + PL, MR, r, i & 3, z, z, amax);
+        }
+        if ((i & 3) == 0) s_in[r] = (!pad && (unsigned)(oy0 - 1 + ry) < (unsigned)a.H) ? 1 : 0;
+    }
+    park_x(0, st[0]);
+    pf_wait_vm_barrier<63>();
+#pragma unroll
     for (int c = 0; c < KSA; ++c) {
-        if (c + 1 < KSA) {                                          // next step's pixels and weights: in flight across this step's MFMAs
-            load_x(c + 1);
-            wnh[0] = *reinterpret_cast<const pf_half8*>(w1p + (c + 1) * 64);
-            wnl[0] = *reinterpret_cast<const pf_half8*>(w1p + (c + 1) * 64 + 32);
+        if (c + 2 < KSA) {
+            load_x(c + 2, st[(c + 2) % DEPTH]);
+            wq[(c + 2) % DEPTH][0] = *reinterpret_cast<const pf_half8*>(w1p + (c + 2) * 64);
+            wq[(c + 2) % DEPTH][1] = *reinterpret_cast<const pf_half8*>(w1p + (c + 2) * 64 + 32);
         }
         const unsigned char* xb = s_x + (c & 1) * PL;
 #pragma unroll
@@ -113,17 +133,53 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             if (mt < MR / 16) {
                 pf_half8 xh, xl;
                 det_frag(xb, MR, 0, mt * 16 + (lane & 15), g, xh, xl);
-                accA[j] = pf_mfma_16x16x32_f16(wl[0], xh, accA[j]);
-                accA[j] = pf_mfma_16x16x32_f16(wh[0], xl, accA[j]);
-                accA[j] = pf_mfma_16x16x32_f16(wh[0], xh, accA[j]);
+                accA[j] = pf_mfma_16x16x32_f16(wq[c % DEPTH][1], xh, accA[j]);
+                accA[j] = pf_mfma_16x16x32_f16(wq[c % DEPTH][0], xl, accA[j]);
+                accA[j] = pf_mfma_16x16x32_f16(wq[c % DEPTH][0], xh, accA[j]);
             }
         }
         if (c + 1 < KSA) {
-            park_x((c + 1) & 1);                                    // the other buffer: nobody reads it during this step
-            wh[0] = wnh[0]; wl[0] = wnl[0];
-            __syncthreads();
+            park_x((c + 1) & 1, st[(c + 1) % DEPTH]);               // the other buffer: nobody reads it during this step
+            pf_wait_vm_barrier<63>();
         }
     }
+    // The shortcut conv of the first block (64 input channels = both x buffers resident): run NOW, wave = one 16-channel tile of
+    // the 256 outputs x every pixel tile, accumulators held in registers until conv3's epilogue -- so that the x buffers are free for
+    // conv2's weight slots in both variants.
+    const int ntC = wave;
+    constexpr int MAXTC = MAXP / 16;
+    pf_f32x4 accd[DS ? MAXTC : 1];
+    if constexpr (DS) {
+        pf_half8 wdh[2], wdl[2];
+        det_wfrag<2>(a.wd, ntC, lane, wdh, wdl);
+#pragma unroll
+        for (int mt = 0; mt < MAXTC; ++mt) {
+            accd[mt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            const int p = mt * 16 + (lane & 15);
+            const int pc = p < P ? p : 0;
+            const int py = pc / a.W, px = pc - py * a.W;
+            const int row = (py + 1) * RW + px + 1;                 // the pixel's row in the x planes
+            if (mt < MRD / 16) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    pf_half8 xh, xl;
+                    det_frag(s_x + ks * PL, MR, 0, row, g, xh, xl);
+                    accd[mt] = pf_mfma_16x16x32_f16(wdl[ks], xh, accd[mt]);
+                    accd[mt] = pf_mfma_16x16x32_f16(wdh[ks], xl, accd[mt]);
+                    accd[mt] = pf_mfma_16x16x32_f16(wdh[ks], xh, accd[mt]);
+                }
+            }
+        }
+    }
+    // conv2's weights go through LDS (the x buffers are free once conv1 and the shortcut conv are done): four 16 KB tap slots
+    // [ks][hi | lo][64 rows][64 B] in s_x, every thread moves one 16-byte piece per tap, requested four taps ahead.  Per-wave fragment
+    // loads from L2 with one tap of look-ahead cost a loaded L2 round trip per tap (44 k cycles for 7 k cycles of MFMAs; 19.7 k now).
+    static_assert(2 * PL >= 4 * 16384, "four tap slots in the x buffers");
+    const pf_half* w2src = a.w2 + ((size_t)(tid >> 4) * 9 * 2 + ((tid >> 3) & 1)) * 64 + ((tid >> 2) & 1) * 32 + (tid & 3) * 8;   // + tap * 128
+    const int w2dst = (((tid >> 3) & 1) * 2 + ((tid >> 2) & 1)) * 4096 + pf_lds_chunk_off(tid >> 4, tid & 3);                       // + slot * 16384
+    pf_half8 w2p[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w2p[t] = *reinterpret_cast<const pf_half8*>(w2src + t * 128);
     {
         const pf_f32x4 b1v = *reinterpret_cast<const pf_f32x4*>(a.b1 + ntA * 16 + g4);
 #pragma unroll
@@ -139,11 +195,11 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             }
         }
     }
-    __syncthreads();
+    pf_wait_vm_barrier<63>();                                       // mid1 is complete; every wave is done reading the x buffers
     const unsigned long long t1 = prof ? pf_clock() : 0;
 
     // ---- conv2: 3x3 on the mid1 planes -----------------------------------------------------------------------------------------------
-    constexpr int MAXTB = (MAXR / 16 + 3) / 4;                      // (tile rows <= region rows)
+    constexpr int MAXTB = (MAXP / 16 + 3) / 4;                      // tile pixels: TR * W <= MAXP
     pf_f32x4 accB[MAXTB];
     int rowB[MAXTB];
 #pragma unroll
@@ -154,40 +210,48 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
         const int py = pc / a.W, px = pc - py * a.W;
         rowB[j] = py * RW + px;                                     // region row of tap (0, 0)
     }
-    auto w2frag = [&](int tap, pf_half8 (&h)[2], pf_half8 (&l)[2]) {
-        const pf_half* p = a.w2 + (((size_t)(ntA * 16 + (lane & 15)) * 9 + tap) * 2) * 64 + g * 8;
-        h[0] = *reinterpret_cast<const pf_half8*>(p); l[0] = *reinterpret_cast<const pf_half8*>(p + 32);
-        h[1] = *reinterpret_cast<const pf_half8*>(p + 64); l[1] = *reinterpret_cast<const pf_half8*>(p + 96);
-    };
-    pf_half8 wch[2], wcl[2], w2nh[2], w2nl[2];
-    w2frag(0, wch, wcl);
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) w2frag(tap + 1, w2nh, w2nl);
-        const int shift = (tap / 3) * RW + tap % 3;
+    {
+        pf_half8 w2q[2];                                            // pieces of taps t + 3 and t + 4, by tap parity
 #pragma unroll
-        for (int j = 0; j < MAXTB; ++j) {
-            if (mgA + 4 * j < MRD / 16) {
+        for (int t = 0; t < 3; ++t) *reinterpret_cast<pf_half8*>(s_x + t * 16384 + w2dst) = w2p[t];
+        w2q[1] = w2p[3];
+        pf_wait_vm_barrier<63>();
+        const int wrow = pf_lds_chunk_off(ntA * 16 + (lane & 15), g);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    pf_half8 zh, zl;
-                    det_frag(s_m, MR, ks, rowB[j] + shift, g, zh, zl);
-                    accB[j] = pf_mfma_16x16x32_f16(wcl[ks], zh, accB[j]);
-                    accB[j] = pf_mfma_16x16x32_f16(wch[ks], zl, accB[j]);
-                    accB[j] = pf_mfma_16x16x32_f16(wch[ks], zh, accB[j]);
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 4 < 9) w2q[tap & 1] = *reinterpret_cast<const pf_half8*>(w2src + (tap + 4) * 128);
+            const unsigned char* wb = s_x + (tap & 3) * 16384 + wrow;
+            pf_half8 wch[2], wcl[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                wch[ks] = *reinterpret_cast<const pf_half8*>(wb + (ks * 2) * 4096);
+                wcl[ks] = *reinterpret_cast<const pf_half8*>(wb + (ks * 2 + 1) * 4096);
+            }
+            const int shift = (tap / 3) * RW + tap % 3;
+#pragma unroll
+            for (int j = 0; j < MAXTB; ++j) {
+                if (mgA + 4 * j < MRD / 16) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        pf_half8 zh, zl;
+                        det_frag(s_m, MR, ks, rowB[j] + shift, g, zh, zl);
+                        accB[j] = pf_mfma_16x16x32_f16(wcl[ks], zh, accB[j]);
+                        accB[j] = pf_mfma_16x16x32_f16(wch[ks], zl, accB[j]);
+                        accB[j] = pf_mfma_16x16x32_f16(wch[ks], zh, accB[j]);
+                    }
                 }
             }
+            if (tap + 3 < 9) {                                      // slot (tap + 3) & 3 was last read during tap - 1: behind the previous barrier
+                *reinterpret_cast<pf_half8*>(s_x + ((tap + 3) & 3) * 16384 + w2dst) = w2q[(tap + 3) & 1];
+                pf_wait_vm_barrier<63>();
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { wch[ks] = w2nh[ks]; wcl[ks] = w2nl[ks]; }
     }
-    // weights of conv3 (and of the shortcut conv): in flight across the two barriers
-    const int ntC = wave;                                          // conv3: wave = one of the 16 channel tiles
-    pf_half8 w3h[2], w3l[2], wdh[DS ? 2 : 1], wdl[DS ? 2 : 1];
+    // weights of conv3: in flight across the two barriers
+    pf_half8 w3h[2], w3l[2];
     det_wfrag<2>(a.w3, ntC, lane, w3h, w3l);
     pf_f32x4 b3v = *reinterpret_cast<const pf_f32x4*>(a.b3 + ntC * 16 + g4);
     if constexpr (DS) {
-        det_wfrag<2>(a.wd, ntC, lane, wdh, wdl);
         const pf_f32x4 bdv = *reinterpret_cast<const pf_f32x4*>(a.bd + ntC * 16 + g4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) b3v[e] += bdv[e];
@@ -214,8 +278,9 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
     // ---- conv3 (+ shortcut) + relu -> global -------------------------------------------------------------------------------------------
     float* out = a.out + (size_t)b * a.H * a.W * a.outLd;
     const int n = ntC * 16 + g4;
-#pragma unroll 1
-    for (int mt0 = 0; mt0 < MRD / 16; mt0 += 4) {
+#pragma unroll
+    for (int mt0 = 0; mt0 < MAXTC; mt0 += 4) {
+        if (mt0 >= MRD / 16) break;
         // the identity shortcut of four pixel sub-tiles at a time: one exposed L2 round trip per four tiles, not per tile (the first
         // cut loaded each tile's residual right in front of its use: ~3 k cycles x 8 per workgroup)
         pf_f32x4 res[4];
@@ -242,18 +307,8 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaf(acc3[e], a.s3, b3v[e]) + res[q][e];
             if constexpr (DS) {
-                pf_f32x4 accd = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                const int row = (py + 1) * RW + px + 1;             // the pixel's row in the x planes (both chunks still resident)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    pf_half8 xh, xl;
-                    det_frag(s_x + ks * PL, MR, 0, row, g, xh, xl);
-                    accd = pf_mfma_16x16x32_f16(wdl[ks], xh, accd);
-                    accd = pf_mfma_16x16x32_f16(wdh[ks], xl, accd);
-                    accd = pf_mfma_16x16x32_f16(wdh[ks], xh, accd);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaf(accd[e], a.sd, v[e]);
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(accd[mt0 + q][e], a.sd, v[e]);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
