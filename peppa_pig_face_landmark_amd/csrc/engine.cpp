@@ -588,11 +588,22 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     memcpy(&a.s1, &f[10], 4); memcpy(&a.s2, &f[11], 4); memcpy(&a.s3, &f[12], 4); memcpy(&a.sd, &f[13], 4);
                     const int CIN = f[14];
                     a.B = B; a.H = ti.H; a.W = ti.W; a.xLd = ti.ld; a.outLd = to.ld;
-                    if (ti.C != CIN || to.C != 256 || to.H != ti.H || to.W != ti.W || 3 * (ti.W + 2) > 272 || (CIN == 64) != (a.wd != nullptr))
+                    if (ti.C != CIN || to.C != 256 || to.H != ti.H || to.W != ti.W || (CIN == 64) != (a.wd != nullptr))
                         PF_FAIL(h, "hrb: inconsistent shapes");
-                    a.TR = std::min(std::min(ti.H, 272 / (ti.W + 2) - 2), 128 / ti.W);       // region rows <= MAXR, tile pixels <= MAXP
-                    a.tiles_y = pf_div_up(ti.H, a.TR);
-                    if (a.TR < 1 || (a.TR + 2) * ti.W * 4 > 1024) PF_FAIL(h, "hrb: a tile's pixels exceed one load item per thread");
+                    {   // tile: <= 128 pixels (MAXP), region <= 256 pixels (one load item per thread and chunk); least halo'd pixels in total
+                        long best = -1;
+                        for (int tw = 128; tw >= 8; tw /= 2) {
+                            const int th = 128 / tw;
+                            const int twc = std::min(tw, (int)ti.W), thc = std::min(th, (int)ti.H);
+                            const int region = (thc + 2) * (twc + 2);
+                            if (region > 256 || thc < 1) continue;
+                            const long cost = (long)pf_div_up(ti.H, thc) * pf_div_up(ti.W, twc) * (region + 64);
+                            if (best < 0 || cost < best) { best = cost; a.TR = thc; a.TW = twc; }
+                        }
+                        if (best < 0) PF_FAIL(h, "hrb: no tile shape for a %d x %d map", ti.H, ti.W);
+                    }
+                    a.tiles_x = pf_div_up(ti.W, a.TW);
+                    a.tpf = a.tiles_x * pf_div_up(ti.H, a.TR);
                     a.range_slot = slot_of(oi);
                     if (host_dbg(h) & 4096) {
                         if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
@@ -602,8 +613,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "bottleneck_c%d_%dx%d", CIN, ti.H, ti.W);
                     ProfScope ps(h, tagbuf);
-                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272, 128, 1>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
-                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272, 128, 1>), dim3(a.tiles_y * B), dim3(1024), h->stream, a);
+                    if (CIN == 64) PF_LAUNCH((hr_bottleneck_kernel<64, true, 272, 128, 1>), dim3(a.tpf * B), dim3(1024), h->stream, a);
+                    else if (CIN == 256) PF_LAUNCH((hr_bottleneck_kernel<256, false, 272, 128, 1>), dim3(a.tpf * B), dim3(1024), h->stream, a);
                     else PF_FAIL(h, "hrb: no kernel for %d input channels", CIN);
                 }
                 break;

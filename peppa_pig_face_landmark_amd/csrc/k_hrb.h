@@ -3,7 +3,7 @@
 // with mid = 64 channels, 256 out; shortcut = x (256 channels) or a 1x1 conv + bn of x (the first block: 64 channels in).
 // Layer by layer the four blocks of layer1 were 13 launches and 5.5 of the Teacher's 23.9 ms per 256 crops, bandwidth-bound: the
 // 256-channel 64 x 64 map (4 MB per face) crossed HBM three times per block.  Here it is read once (its halo rows twice) and
-// written once per block.  A workgroup (16 waves) owns TR whole rows of one face's map:
+// written once per block.  A workgroup (16 waves) owns a TR x TW tile of one face's map (8 x 16 at 64 x 64: 1.41 x halo):
 //   conv1   K loop over 32-channel chunks of x: the chunks of the (TR + 2) x W pixels for steps c + 1 and c + 2 are in flight
 //           (registers) while the MFMAs of step c run on the planes in LDS (two buffers); accumulators (<= 5 tiles per wave) in
 //           registers; relu, zero outside the image (conv2 pads ITS input) -> mid1 planes.  The first block's shortcut conv
@@ -27,7 +27,7 @@ struct HrbArgs {
     const pf_half* w3; const float* b3;     // [256][2][64]
     const pf_half* wd; const float* bd;     // downsample [256][2][64] (CIN == 64 blocks only) or nullptr
     float s1, s2, s3, sd;
-    int B, H, W, xLd, outLd, TR, tiles_y;
+    int B, H, W, xLd, outLd, TR, TW, tiles_x, tpf;      // tile = TR rows x TW columns; tpf = tiles per face
     unsigned* range_slot;
     unsigned long long* prof;   // ablation build only (PEPPA_DBG & 4096): cycles of conv1 / conv2 / conv3 [3], workgroups
 };
@@ -52,28 +52,27 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
     // neighbours sit on other XCDs and the 2 x (TR + 2) / TR read amplification of the input goes all the way to HBM
     int tile = blockIdx.x;
     if ((gridDim.x & 7) == 0) tile = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);
-    const int b = tile / a.tiles_y, oy0 = (tile - b * a.tiles_y) * a.TR;
-    const int RW = a.W + 2, R = (a.TR + 2) * RW, MR = (R + 15) & ~15;
-    const int P = a.TR * a.W, MRD = (P + 15) & ~15;
+    const int b = tile / a.tpf, tt = tile - b * a.tpf;
+    const int oy0 = (tt / a.tiles_x) * a.TR, ox0 = (tt % a.tiles_x) * a.TW;
+    const int RW = a.TW + 2, R = (a.TR + 2) * RW, MR = (R + 15) & ~15;
+    const int P = a.TR * a.TW, MRD = (P + 15) & ~15;
     const int g = lane >> 4, g4 = g * 4;
     const float* x = a.x + (size_t)b * a.H * a.W * a.xLd;
 
     // ---- conv1: K loop over the chunks of x ------------------------------------------------------------------------------------------
-    // Only the pixels are loaded ((TR + 2) x W x four 8-channel units: one per thread and chunk at 64 x 64); the padding columns and
-    // the rows beyond the region are zeroed once in both buffers.  Chunks c + 1 AND c + 2 are in flight while the MFMAs of chunk c
-    // run: with one step of look-ahead the ~1 k cycles of a step's MFMAs did not cover a loaded-memory round trip (a step took
-    // 5.9 k cycles), and __syncthreads() would drain vmcnt at every step -- the barriers below only retire the LDS writes.
-    int xo[ITX], xr[ITX];                                           // element offset (-1: row outside the image), region row (-1: no item)
-    {
-        const int rowItems = a.W * 4, items = (a.TR + 2) * rowItems;
+    // One (region pixel, 8-channel unit) item per thread and chunk (host: (TR + 2) x (TW + 2) x 4 <= ITX x 1024); the rows beyond the
+    // region are zeroed once in both buffers.  Chunks c + 1 AND c + 2 are in flight while the MFMAs of chunk c run: with one step of
+    // look-ahead the ~1 k cycles of a step's MFMAs did not cover a loaded-memory round trip (a step took 5.9 k cycles), and
+    // __syncthreads() would drain vmcnt at every step -- the barriers below only retire the LDS writes.
+    int xo[ITX], xr[ITX];                                           // element offset (-1: pixel outside the image), region row (-1: no item)
 #pragma unroll
-        for (int it = 0; it < ITX; ++it) {
-            const int i = tid + it * NTHR;
-            const int ry = i / rowItems, px = (i - ry * rowItems) >> 2;
-            const int iy = oy0 - 1 + ry;
-            xr[it] = i < items ? ry * RW + px + 1 : -1;
-            xo[it] = (i < items && (unsigned)iy < (unsigned)a.H) ? (iy * a.W + px) * a.xLd + (i & 3) * 8 : -1;
-        }
+    for (int it = 0; it < ITX; ++it) {
+        const int i = tid + it * NTHR;
+        const int r = i >> 2;
+        const int ry = r / RW, rx = r - ry * RW;
+        const int iy = oy0 - 1 + ry, ix = ox0 - 1 + rx;
+        xr[it] = r < R ? r : -1;
+        xo[it] = (r < R && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (iy * a.W + ix) * a.xLd + (i & 3) * 8 : -1;
     }
     auto load_x = [&](int c, pf_f32x4 (&s)[ITX][2]) {
 #pragma unroll
@@ -106,16 +105,15 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
         wq[c][0] = *reinterpret_cast<const pf_half8*>(w1p + c * 64);
         wq[c][1] = *reinterpret_cast<const pf_half8*>(w1p + c * 64 + 32);
     }
-    for (int i = tid; i < MR * 4; i += NTHR) {                      // padding of both buffers, and the in-image flags of the region rows
+    for (int i = tid; i < MR * 4; i += NTHR) {                      // rows beyond the region in both buffers, and the in-image flags
         const int r = i >> 2;
         const int ry = r / RW, rx = r - ry * RW;
-        const bool pad = r >= R || rx == 0 || rx == RW - 1;
-        if (pad) {
+        if (r >= R) {
             const pf_f32x4 z = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             det_park8(s_x, MR, r, i & 3, z, z, amax);
             det_park8(s_x + PL, MR, r, i & 3, z, z, amax);
         }
-        if ((i & 3) == 0) s_in[r] = (!pad && (unsigned)(oy0 - 1 + ry) < (unsigned)a.H) ? 1 : 0;
+        if ((i & 3) == 0) s_in[r] = (r < R && (unsigned)(oy0 - 1 + ry) < (unsigned)a.H && (unsigned)(ox0 - 1 + rx) < (unsigned)a.W) ? 1 : 0;
     }
     park_x(0, st[0]);
     pf_wait_vm_barrier<63>();
@@ -157,7 +155,7 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             accd[mt] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             const int p = mt * 16 + (lane & 15);
             const int pc = p < P ? p : 0;
-            const int py = pc / a.W, px = pc - py * a.W;
+            const int py = pc / a.TW, px = pc - py * a.TW;
             const int row = (py + 1) * RW + px + 1;                 // the pixel's row in the x planes
             if (mt < MRD / 16) {
 #pragma unroll
@@ -207,7 +205,7 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
         accB[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         const int p = (mgA + 4 * j) * 16 + (lane & 15);
         const int pc = p < P ? p : 0;
-        const int py = pc / a.W, px = pc - py * a.W;
+        const int py = pc / a.TW, px = pc - py * a.TW;
         rowB[j] = py * RW + px;                                     // region row of tap (0, 0)
     }
     {
@@ -289,8 +287,8 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             res[q] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (!DS) {
                 const int p = (mt0 + q) * 16 + (lane & 15);
-                const int py = p / a.W, px = p - py * a.W;
-                if (p < P && oy0 + py < a.H) res[q] = *reinterpret_cast<const pf_f32x4*>(x + ((size_t)(oy0 + py) * a.W + px) * a.xLd + n);
+                const int py = p / a.TW, px = p - py * a.TW;
+                if (p < P && oy0 + py < a.H && ox0 + px < a.W) res[q] = *reinterpret_cast<const pf_f32x4*>(x + ((size_t)(oy0 + py) * a.W + ox0 + px) * a.xLd + n);
             }
         }
 #pragma unroll
@@ -299,9 +297,9 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             if (mt >= MRD / 16) break;
             const int p = mt * 16 + (lane & 15);
             const int pc = p < P ? p : 0;
-            const int py = pc / a.W, px = pc - py * a.W;
-            const int oy = oy0 + py;
-            const bool ok = p < P && oy < a.H;
+            const int py = pc / a.TW, px = pc - py * a.TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            const bool ok = p < P && oy < a.H && ox < a.W;
             const pf_f32x4 acc3 = det_tile<2>(s_m, MRD, mt * 16, lane, w3h, w3l);
             pf_f32x4 v;
 #pragma unroll
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(1024) void hr_bottleneck_kernel(HrbArgs a) {
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-            if (ok) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.W + px) * a.outLd + n) = v;
+            if (ok) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.W + ox) * a.outLd + n) = v;
         }
     }
     pf_amax_commit(a.range_slot, amax, amax_seen);

@@ -404,7 +404,7 @@ class ProgramBuilder:
 
     def hr_bottleneck_supported(self, x: int, mid: int, cout: int, has_ds: bool) -> bool:
         ti = self.tensors[x]
-        return (self.split and mid == 64 and cout == 256 and ti.C == ti.real_c and ti.W <= 64 and 3 * (ti.W + 2) <= 272
+        return (self.split and mid == 64 and cout == 256 and ti.C == ti.real_c
                 and ((ti.C == 64 and has_ds) or (ti.C == 256 and not has_ds)))
 
     def hr_bottleneck(self, x: int, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out_name: str = "") -> int:

@@ -124,3 +124,48 @@ def test_block_equals_separate_convs_emu(emu_engine, c, hw, batch, n_blocks):
 @pytest.mark.parametrize("c,hw,batch,n_blocks", [(18, 64, 5, 4), (36, 32, 7, 4), (18, 16, 9, 2), (18, 64, 130, 1)])
 def test_block_equals_separate_convs_gpu(gpu_engine, c, hw, batch, n_blocks):
     _block_case(gpu_engine, c, hw, batch, n_blocks, seed=600 + c + hw)
+
+
+def _bottleneck_case(eng, h, w, batch, seed):
+    """PF_OP_HRB (csrc/k_hrb.h: an HRNet Bottleneck in one launch; timm hrnet.py Bottleneck, TeacherNet layer1,
+    TRAIN/face_landmark/lib/core/base_trainer/model.py:306-311) against the same convs as separate launches: the first block
+    (64 channels in, 1x1 shortcut conv) followed by an identity-shortcut block, on a rectangular map whose 8 x 16 tiles are ragged
+    in both directions (border tiles, halo pixels outside the image, tiles_x > 1)."""
+    rng = np.random.default_rng(seed)
+    pb = ir.ProgramBuilder("f32s", 2 * h, 2 * w, keep_all=True)
+    f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+    x = pb.conv(f0, rng.normal(0, 0.35, (64, 16, 1, 1)), rng.normal(0, 0.2, 64), "relu", out_name="x")
+    y = r = x
+    cin = 64
+    for i in range(2):
+        w1, b1 = rng.normal(0, np.sqrt(2.0 / cin), (64, cin, 1, 1)), rng.normal(0, 0.05, 64)
+        w2, b2 = rng.normal(0, np.sqrt(2.0 / 576), (64, 64, 3, 3)), rng.normal(0, 0.05, 64)
+        w3, b3 = rng.normal(0, 0.5 * np.sqrt(2.0 / 64), (256, 64, 1, 1)), rng.normal(0, 0.05, 256)
+        wd, bd = (rng.normal(0, np.sqrt(1.0 / cin), (256, cin, 1, 1)), rng.normal(0, 0.05, 256)) if i == 0 else (None, None)
+        assert pb.hr_bottleneck_supported(y, 64, 256, wd is not None)
+        y = pb.hr_bottleneck(y, w1, b1, w2, b2, w3, b3, wd, bd, out_name=f"fused.block{i}")
+        m = pb.conv(r, w1, b1, "relu")
+        m = pb.conv(m, w2, b2, "relu", pad=1)
+        sc = pb.conv(r, wd, bd, "none") if wd is not None else r
+        r = pb.conv(m, w3, b3, "relu", res=sc, out_name=f"ref.block{i}")
+        cin = 256
+    blob = pb.finish([pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")])
+    eng.load_program(0, blob, batch)
+    eng.landmark_forward(rng.integers(0, 256, (batch, 2 * h, 2 * w, 3), dtype=np.uint8))
+    for i in range(2):
+        got = eng.read_tensor(0, pb.tensor_names[f"fused.block{i}"], batch, (h, w, 256))
+        ref = eng.read_tensor(0, pb.tensor_names[f"ref.block{i}"], batch, (h, w, 256))
+        assert np.isfinite(ref).all() and np.abs(ref).max() > 0.1
+        rel = np.abs(got - ref).max() / np.abs(ref).max()
+        assert rel < 1e-5, (h, w, i, rel)
+
+
+@pytest.mark.parametrize("h,w,batch", [(20, 40, 2), (8, 8, 1)])
+def test_bottleneck_equals_separate_convs_emu(emu_engine, h, w, batch):
+    _bottleneck_case(emu_engine, h, w, batch, seed=700 + h + w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,batch", [(64, 64, 5), (20, 40, 9), (36, 24, 3)])
+def test_bottleneck_equals_separate_convs_gpu(gpu_engine, h, w, batch):
+    _bottleneck_case(gpu_engine, h, w, batch, seed=800 + h + w)
