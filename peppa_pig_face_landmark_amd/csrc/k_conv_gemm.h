@@ -56,7 +56,8 @@ struct ConvGemmArgs {
     // timing ablations of conv3x3_halo_split_kernel (PEPPA_DBG bit mask, 0 in production; results are WRONG when set):
     // 1 = weights fetched for the first K step only, 16 = no MFMAs, 32 = no output stores, 64 = input patch staged for the
     // first channel chunk only, 128 = no per-tap barrier; conv_gemm_split_kernel: 16 as above, 256 = operands (pixels AND weights)
-    // fetched for the first K step only, 512 = no split / LDS store of the pixel operand.  Tables: profiles/r02_*ablations.md.
+    // fetched for the first K step only, 512 = no split / LDS store of the pixel operand, 1024 = no depthwise taps in the fused
+    // expand + depthwise epilogue.  Tables: profiles/r02_*ablations.md.
     int dbg;
 };
 
@@ -91,12 +92,29 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
     const int crow = (lane >> 4) * 4;  // first of the 4 channels this lane owns
     const bool want_amax = a.amax_val != nullptr;
 
+    // every bias of this lane in one round trip (Npad is a multiple of 16: a lane's four channels are inside or outside together)
+    pf_f32x4 bvv[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + crow;
+        bvv[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n + 3 < a.Npad) bvv[j] = *reinterpret_cast<const pf_f32x4*>(a.bias + n);
+    }
+    const bool res_vec = res != nullptr && sizeof(T) == 4 && (a.resLd & 3) == 0;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn * WN + j * 16 + crow;
         float bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = (n + r < a.Npad) ? a.bias[n + r] : 0.f;
+        for (int r = 0; r < 4; ++r) bv[r] = bvv[j][r];
+        // the residual vectors of this channel tile's MT pixel sub-tiles: one round trip per channel tile, not one per sub-tile
+        pf_f32x4 rvv[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * WM + i * 16 + pcol;
+            rvv[i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (res_vec && m < M && n + 3 < a.N) rvv[i] = *reinterpret_cast<const pf_f32x4*>(reinterpret_cast<const float*>(res) + (size_t)m * a.resLd + n);
+        }
         float best_v[4];
         int best_i[4];
 #pragma unroll
@@ -115,10 +133,9 @@ __device__ __forceinline__ void conv_gemm_epilogue(const ConvGemmArgs& a, pf_f32
                     if (n + r < a.Npad) v[r] += a.fbias[(size_t)b * a.Npad + n + r];
             }
             if (res && mok) {
-                if (sizeof(T) == 4 && n + 3 < a.N && (a.resLd & 3) == 0) {      // one 16-byte load (views start on vector boundaries)
-                    const pf_f32x4 rv = *reinterpret_cast<const pf_f32x4*>(reinterpret_cast<const float*>(res) + (size_t)m * a.resLd + n);
+                if (res_vec && n + 3 < a.N) {      // one 16-byte load (views start on vector boundaries), requested above
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    for (int r = 0; r < 4; ++r) v[r] += rvv[i][r];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
@@ -430,6 +447,84 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
             *reinterpret_cast<pf_f32x4*>(es + (wm * WM + i * 16 + pcol) * ES + nl) = v;
         }
     }
+    if constexpr (WS == 16 && BM == 256 && BN == 64 && NTHR == 512) {
+        // One 16 x 16 image per workgroup: thread = (channel PAIR, image row).  Two adjacent channels of a pixel are one aligned
+        // 8-byte LDS word, so every tap is a v_pk_fma_f32 on a ds_read_b64 operand -- half the VALU and LDS instructions of the
+        // one-channel-per-thread form below (the launch is VALU-bound: 57 % VALU busy against 12 % matrix pipe).  The filter taps
+        // sit in LDS (6.4 KB at 5 x 5) instead of 2 x 25 registers.  Same fma order per output as the generic path.
+        constexpr int KK = K * K;
+        float* wks = sums + 16 * BN;                     // [K * K][BN]
+        static_assert((BM * ES + 16 * BN + KK * BN) * 4 <= 80 * 1024, "E tile + row sums + taps: two workgroups per CU");
+        {
+            float wv[(KK * BN + NTHR - 1) / NTHR];
+#pragma unroll
+            for (int i = 0; i < (KK * BN + NTHR - 1) / NTHR; ++i) {
+                const int id = t + i * NTHR;
+                const int k = id / BN, cc = id - k * BN;
+                wv[i] = (id < KK * BN && n0 + cc < a.N) ? a.dw_w2[(size_t)k * a.N + n0 + cc] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < (KK * BN + NTHR - 1) / NTHR; ++i)
+                if (t + i * NTHR < KK * BN) wks[t + i * NTHR] = wv[i];
+        }
+        const int c2 = (t & 31) * 2, row = t >> 5;
+        const int n2 = n0 + c2;
+        pf_f32x2 bd2;
+        bd2[0] = n2 < a.N ? a.dw_b[n2] : 0.f;
+        bd2[1] = n2 + 1 < a.N ? a.dw_b[n2 + 1] : 0.f;
+        __syncthreads();
+        pf_f32x2 o[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) o[x] = bd2;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = row + ky * DIL - PAD;
+            if ((unsigned)yy >= 16u || (pf_dbg(a) & 1024)) continue;
+            const float* erow = es + (yy * 16) * ES + c2;
+            pf_f32x2 in[16];
+#pragma unroll
+            for (int x = 0; x < 16; ++x) in[x] = *reinterpret_cast<const pf_f32x2*>(erow + x * ES);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const pf_f32x2 w = *reinterpret_cast<const pf_f32x2*>(wks + (ky * K + kx) * BN + c2);
+#pragma unroll
+                for (int x = 0; x < 16; ++x) {
+                    const int xx = x + kx * DIL - PAD;       // compile-time register index
+                    if (xx >= 0 && xx < 16) o[x] = __builtin_elementwise_fma(w, in[xx], o[x]);
+                }
+            }
+            asm volatile("" ::: "memory");       // one filter row's LDS reads in flight at a time (register footprint)
+        }
+        float of[32];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { of[2 * x] = o[x][0]; of[2 * x + 1] = o[x][1]; }
+        pf_act_rh<32>(of, a.act);
+        const int m = m0 + row * 16;
+        pf_f32x2 rs = pf_f32x2{0.f, 0.f};
+        float* out = static_cast<float*>(a.out);
+        if (m < M && !(pf_dbg(a) & 32)) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                float* po = out + (size_t)(m + x) * a.outLd + n2;
+                if (n2 + 1 < a.N) *reinterpret_cast<pf_f32x2*>(po) = pf_f32x2{of[2 * x], of[2 * x + 1]};
+                else if (n2 < a.N) po[0] = of[2 * x];
+                rs[0] += of[2 * x];
+                rs[1] += of[2 * x + 1];
+            }
+        }
+        if (a.gap_out) {
+            *reinterpret_cast<pf_f32x2*>(sums + row * BN + c2) = rs;
+            __syncthreads();
+            if (t < BN && n0 + t < a.N) {
+                float tot = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tot += sums[r * BN + t];
+                const int b = m0 / 256;
+                if (b < a.B) a.gap_out[(size_t)b * a.N + n0 + t] = tot / 256.f;
+            }
+        }
+        return;
+    }
     float wk[K * K];                           // requested before the barrier (accumulators are dead by now)
 #pragma unroll
     for (int k = 0; k < K * K; ++k) wk[k] = cok ? a.dw_w2[(size_t)k * a.N + n] : 0.f;
@@ -560,15 +655,29 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
         const int oy = rem / a.outW;
         const int ox = rem - oy * a.outW;
         xb[u] = b;
-        xiy0[u] = KS == 1 ? oy : oy * a.stride - a.pad;
-        xix0[u] = KS == 1 ? ox : ox * a.stride - a.pad;
+        // plain pointwise (stride 1, no padding): the input pixel IS output pixel m
+        xiy0[u] = (KS == 1 && STAGE == 0) ? mm : (KS == 1 ? oy : oy * a.stride - a.pad);
+        xix0[u] = (KS == 1 && STAGE == 0) ? 0 : (KS == 1 ? ox : ox * a.stride - a.pad);
     }
     const int taps = KS == 1 ? 1 : a.KH * a.KW;
     const int cblocks = a.Cpad / 32;
     const int nk = taps * cblocks;
     const size_t wrow_bytes = (size_t)taps * cblocks * 128;
 
-    pf_f32x4 xreg[XUNITS][2];
+    constexpr bool PW2 = KS == 1 && STAGE == 0;                       // plain pointwise conv: leaner operand staging (below)
+    constexpr bool GATED = PW2 && EPI_K == 0;                         // ... which may carry an SE gate on its input channels
+    pf_f32x4 xreg[1][XUNITS][2];
+    // The gate vector of the tile's face sits in LDS when the tile lies inside one face (every gated layer of the Student at
+    // 256 x 256); otherwise each unit fetches its gate values when it is split (correct, no look-ahead: small crops only).
+    // Multiplying right behind the pixel load put an s_waitcnt vmcnt(0) behind each of a K step's loads.
+    // It gets its own 4 KB where two workgroups still fit a CU with it, else the tail of weight stage 0 that no row uses (W_BYTES
+    // is rounded up to whole 512-slot DMA passes; load_w skips the slots beyond row BN - 1).
+    constexpr int W_USED = BN * 128;
+    constexpr bool GATE_SEP = 2 * STAGE_BYTES + 4096 <= 80 * 1024;
+    constexpr int GATE_CAP = !GATED ? 0 : (GATE_SEP ? 1024 : (W_BYTES - W_USED) / 4);
+    __shared__ __attribute__((aligned(16))) float sgate_sep[GATED && GATE_SEP ? 1024 : 4];
+    float* sgate = GATE_SEP ? sgate_sep : reinterpret_cast<float*>(smem + 2 * PLANE_X + W_USED);
+    const bool gate_lds = GATED && a.gate != nullptr && (OHW % BM) == 0 && a.Cpad <= GATE_CAP;
     unsigned amax = 0;                                 // range guard (pf_common.h)
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
 
@@ -576,6 +685,20 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
     // LDS-path cycles per 16 bytes against 4 for a read).  LDS slot s (16 B, lane-linear as the DMA requires) is
     // (plane, row, position) with the row's four chunks rotated; the rotation is applied to the SOURCE address.
     // Rows past Npad re-read the last row (their outputs are never stored); slots past the planes land in padding.
+    auto load_w = [&](int tap, int cb, int stage) {
+        unsigned char* wdst = smem + stage * STAGE_BYTES + 2 * PLANE_X;
+#pragma unroll
+        for (int c = 0; c < WCHUNKS; ++c) {
+            const int sl = t + NTHR * c;
+            const int plane = sl >= BN * 4 ? 1 : 0;
+            const int r = (sl - plane * BN * 4) >> 2;
+            const int row = r < BN ? r : BN - 1;
+            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
+            const int n = min(n0 + row, a.Npad - 1);
+            const unsigned char* src = wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + plane * 64 + chunk * 16;
+            if constexpr (PW2) { if (sl < BN * 8) pf_glds16(src, wdst + sl * 16); } else pf_glds16(src, wdst + sl * 16);   // (the tail may hold the gate)
+        }
+    };
     auto load_tile = [&](int tap, int cb, int stage) {
         const int ky = KS == 1 ? 0 : tap / a.KW;
         const int kx = KS == 1 ? 0 : tap - ky * a.KW;
@@ -643,7 +766,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xreg[u][e >> 2][e & 3] = o[e];
+                for (int e = 0; e < 8; ++e) xreg[0][u][e >> 2][e & 3] = o[e];
             }
         } else {
 #pragma unroll
@@ -651,7 +774,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             const int iy = KS == 1 ? xiy0[u] : xiy0[u] + ky * a.dil;
             const int ix = KS == 1 ? xix0[u] : xix0[u] + kx * a.dil;
             const bool pok = xvalid[u] && (KS == 1 || ((unsigned)iy < (unsigned)a.inH && (unsigned)ix < (unsigned)a.inW));
-            const size_t off = ((size_t)(xb[u] * a.inH + iy) * a.inW + ix) * a.inLd + kelem;
+            const size_t off = KS == 1 ? (size_t)iy * a.inLd + kelem : ((size_t)(xb[u] * a.inH + iy) * a.inW + ix) * a.inLd + kelem;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -663,31 +786,49 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                         for (int e = 0; e < 4; ++e) v[e] *= g[e];
                     }
                 }
-                xreg[u][h] = v;
+                xreg[0][u][h] = v;
             }
         }
         }
-        unsigned char* wdst = smem + stage * STAGE_BYTES + 2 * PLANE_X;
-#pragma unroll
-        for (int c = 0; c < WCHUNKS; ++c) {
-            const int sl = t + NTHR * c;
-            const int plane = sl >= BN * 4 ? 1 : 0;
-            const int r = (sl - plane * BN * 4) >> 2;
-            const int row = r < BN ? r : BN - 1;
-            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-            const int n = min(n0 + row, a.Npad - 1);
-            pf_glds16(wt + (size_t)n * wrow_bytes + ((size_t)tap * cblocks + cb) * 128 + plane * 64 + chunk * 16, wdst + sl * 16);
-        }
+        load_w(tap, cb, stage);
     };
-    auto store_tile = [&](int stage) {
+    // plain pointwise path: this thread's pixel units of K step cb, requested and nothing else (out-of-range units read element 0
+    // and are zeroed when they are split; the SE gate is applied there too: multiplying on the spot put an s_waitcnt vmcnt(0)
+    // behind each of a K step's loads)
+    auto load_x = [&](int cb, pf_f32x4 (&xr)[XUNITS][2]) {
+        const int kelem = cb * 32 + xc * 8;
+#pragma unroll
+        for (int u = 0; u < XUNITS; ++u)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool ok = xvalid[u] && kelem + 4 * h < a.inC;
+                xr[u][h] = *reinterpret_cast<const pf_f32x4*>(in + (ok ? (size_t)xiy0[u] * a.inLd + kelem + 4 * h : (size_t)0));
+            }
+    };
+    auto store_tile = [&](int stage, int cb, const pf_f32x4 (&xr)[XUNITS][2]) {
         unsigned char* xh = smem + stage * STAGE_BYTES;
         unsigned char* xl = xh + PLANE_X;
 #pragma unroll
         for (int u = 0; u < XUNITS; ++u) {
+            pf_f32x4 xv[2] = {xr[u][0], xr[u][1]};
+            if constexpr (GATED) {
+                // the gate is applied INSIDE each branch: a value loaded in the fall-back branch and used behind the join would make
+                // the compiler wait for vmcnt(0) on every path, i.e. for the look-ahead loads too
+                const int kelem = cb * 32 + xc * 8;
+                if (gate_lds) {
+                    xv[0] *= *reinterpret_cast<const pf_f32x4*>(sgate + kelem);
+                    xv[1] *= *reinterpret_cast<const pf_f32x4*>(sgate + kelem + 4);
+                } else if (a.gate) {
+                    const float* g = a.gate + (size_t)xb[u] * a.inC + kelem;
+                    if (xvalid[u] && kelem < a.inC) xv[0] *= *reinterpret_cast<const pf_f32x4*>(g);
+                    if (xvalid[u] && kelem + 4 < a.inC) xv[1] *= *reinterpret_cast<const pf_f32x4*>(g + 4);
+                }
+            }
             pf_half8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float v = xreg[u][e >> 2][e & 3];
+                float v = xv[e >> 2][e & 3];
+                if constexpr (PW2) { if (!(xvalid[u] && cb * 32 + xc * 8 + (e & 4) < a.inC)) v = 0.f; }
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
                 lo[e] = (pf_half)(v - (float)hv);
@@ -705,22 +846,37 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int tap = 0, cb = 0;
-    load_tile(tap, cb, 0);
-    store_tile(0);
-    __syncthreads();
     const int frow = lane & 15, fchunk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            if (++tap == taps) { tap = 0; ++cb; }
-            if (!(pf_dbg(a) & 256)) load_tile(tap, cb, cur ^ 1);
-        }
+    auto mma_stage = [&](int cur) {
         const unsigned char* xh = smem + cur * STAGE_BYTES;
         const unsigned char* xl = xh + PLANE_X;
         const unsigned char* wh = xl + PLANE_X;
         const unsigned char* wl = wh + PLANE_W;
+        if constexpr (MT == 2 && NT >= 4) {
+            // wide-N tiles: the two pixel fragments stay live and the weight fragments come one 16-channel tile at a time -- 24
+            // fragment registers instead of 8 NT + 8 (same products in the same order per accumulator)
+            if (!(pf_dbg(a) & 16)) {
+                pf_half8 xhf[MT], xlf[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
+                    xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
+                    xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
+                    const pf_half8 whj = *reinterpret_cast<const pf_half8*>(wh + off);
+                    const pf_half8 wlj = *reinterpret_cast<const pf_half8*>(wl + off);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlj, xhf[i], acc[j][i]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whj, xlf[i], acc[j][i]);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whj, xhf[i], acc[j][i]);
+                }
+            }
+        } else {
         pf_half8 whf[NT], wlf[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -742,8 +898,49 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[j][i] = pf_mfma_16x16x32_f16(whf[j], xhf, acc[j][i]);
         }
-        if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1);
+        }
+    };
+    if constexpr (PW2) {
+        // Plain pointwise convs.  Same schedule as the general loop below (operands of step kt + 1 requested before step kt's MFMAs);
+        // the pixel loads are unconditional (masked when split) and the SE gate comes from LDS, so nothing waits between a step's
+        // requests.  Two steps of look-ahead were tried this round (second register set): asm-issued loads are unsafe -- the
+        // register allocator copies / reuses destination registers of loads it cannot see -- and compiler-visible ones get an
+        // s_waitcnt vmcnt(0) at the loop head because the in-flight set is loop-carried.
+        load_w(0, 0, 0);
+        load_x(0, xreg[0]);
+        if constexpr (GATED) {
+            if (gate_lds) {                                         // behind the first operand requests: its round trip overlaps theirs
+                const float* g = a.gate + (size_t)(m0 / OHW) * a.inC;
+                for (int i = t; i < a.Cpad; i += NTHR) sgate[i] = i < a.inC ? g[i] : 0.f;
+                __syncthreads();
+            }
+        }
+        store_tile(0, 0, xreg[0]);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more && !(pf_dbg(a) & 256)) { load_x(kt + 1, xreg[0]); load_w(0, kt + 1, cur ^ 1); }
+            mma_stage(cur);
+            if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1, kt + 1, xreg[0]);
+            __syncthreads();
+        }
+    } else {
+    int tap = 0, cb = 0;
+    load_tile(tap, cb, 0);
+    store_tile(0, 0, xreg[0]);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) {
+            if (++tap == taps) { tap = 0; ++cb; }
+            if (!(pf_dbg(a) & 256)) load_tile(tap, cb, cur ^ 1);
+        }
+        mma_stage(cur);
+        if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1, cb, xreg[0]);
+        __syncthreads();
+    }
     }
     pf_amax_commit(a.range_slot, amax, amax_seen);
     if constexpr (EPI_K < 0) {
