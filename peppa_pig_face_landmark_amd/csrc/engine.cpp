@@ -285,6 +285,23 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
             return 0;
         }
     }
+    // plain pointwise convs whose K depth has an unrolled instance (two K steps of look-ahead, k_conv_gemm.h): the Student's
+    // stage-3 to stage-5 projections at 256 x 256 and a few neighbours; every other depth takes the rolled loop of the same kernel
+    if constexpr (SPLIT) {
+        if (use_split && pointwise && !a.amax_val) {
+            const int nk = a.Cpad / 32;
+#define PF_PW_NK(CFG, BM_, BN_, WM_, WN_, NK_)                                                                        \
+            if (cfg == CFG && nk == NK_) {                                                                            \
+                PF_LAUNCH((conv_gemm_split_kernel<BM_, BN_, WM_, WN_, 1, 0, 0, 1, 0, NK_>), grid, dim3(512), h->stream, a); \
+                return 0;                                                                                             \
+            }
+            // measured (profiles/r04_run25 vs run23): 960 -> 160 0.204 -> 0.175 ms per 256 faces, 480 -> 112 -10 %; the shallow ones
+            // (K <= 224, and the expand + depthwise launches) did not move and keep the rolled loop
+            PF_PW_NK(8, 128, 160, 4, 2, 30) PF_PW_NK(8, 128, 160, 4, 2, 21)
+            PF_PW_NK(6, 128, 112, 8, 1, 21) PF_PW_NK(6, 128, 112, 8, 1, 15)
+#undef PF_PW_NK
+        }
+    }
     if (cfg == 8) {
         if constexpr (SPLIT) {
             PF_LAUNCH((conv_gemm_split_kernel<128, 160, 4, 2, 1>), grid, dim3(512), h->stream, a);
@@ -1179,8 +1196,8 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipMemcpy(p.d_const, src + off, hd.const_bytes, hipMemcpyHostToDevice));
     p.max_batch = max_batch;
     p.arena_bytes = (size_t)hd.arena_units_per_item * 256 * (size_t)max_batch;
-    PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes));
-    PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes));
+    PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes + 256));          // + slack: masked pixel-operand units may read up to 124 bytes behind a tensor
+    PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes + 256));
     if (hd.dtype == PF_DTYPE_F32_SPLIT) {
         const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);
         PF_HIP(h, hipMalloc((void**)&p.d_range, rb + PF_RANGE_TAIL_WORDS * sizeof(unsigned)));

@@ -21,6 +21,8 @@
 // running arg-max for the heat-map head (COTRAIN.postp, model.py:520-522).
 #pragma once
 #include "pf_common.h"
+#include <type_traits>
+#include <utility>
 
 struct ConvGemmArgs {
     const void* in;
@@ -608,7 +610,14 @@ __device__ __forceinline__ void expdw_epilogue(const ConvGemmArgs& a, pf_f32x4 (
 // fly -- bilinear x2 upsample of up_lo / pass-through of up_skip, depthwise 3x3 (+bias) -- so the
 // concatenated and the depthwise tensors never exist in HBM.
 // EPI_K != 0 (pointwise only): the epilogue is the fused depthwise EPI_K x EPI_K conv (dilation EPI_DIL) above.
-template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1, int EPI_W = 0>
+// NK > 0 (plain pointwise convs only; host: Cpad == 32 NK): the K loop is unrolled completely and runs TWO steps ahead -- see the
+// PW2 path in the body.
+template <int N, typename F, int... I> __device__ __forceinline__ void pf_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void pf_static_for(F&& f) { pf_static_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int KS, int STAGE = 0, int EPI_K = 0, int EPI_DIL = 1, int EPI_W = 0, int NK = 0>
 __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS_N / 4 : WARPS_M * WARPS_N / 2) void conv_gemm_split_kernel(ConvGemmArgs a) {
     // second launch bound = waves per SIMD for two resident workgroups per CU (<= 128 VGPRs at 8 waves);
     // 256-channel tiles hold 64 accumulators + 64 weight-fragment registers and run one workgroup per CU;
@@ -666,7 +675,8 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 
     constexpr bool PW2 = KS == 1 && STAGE == 0;                       // plain pointwise conv: leaner operand staging (below)
     constexpr bool GATED = PW2 && EPI_K == 0;                         // ... which may carry an SE gate on its input channels
-    pf_f32x4 xreg[1][XUNITS][2];
+    static_assert(NK == 0 || (KS == 1 && STAGE == 0), "unrolled K loop: plain pointwise convs");
+    pf_f32x4 xreg[NK > 1 ? 2 : 1][XUNITS][2];
     // The gate vector of the tile's face sits in LDS when the tile lies inside one face (every gated layer of the Student at
     // 256 x 256); otherwise each unit fetches its gate values when it is split (correct, no look-ahead: small crops only).
     // Multiplying right behind the pixel load put an s_waitcnt vmcnt(0) behind each of a K step's loads.
@@ -863,17 +873,29 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                     xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
                     xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
                 }
+                // weight fragments of tile j + 1 are requested in front of tile j's MFMAs and no further ahead (the compiler fence):
+                // left alone, the scheduler of the unrolled instances hoists every tile's reads and spills
+                pf_half8 wq[2][2];
+                {
+                    const int off = pf_lds_chunk_off(wn * WN + frow, fchunk);
+                    wq[0][0] = *reinterpret_cast<const pf_half8*>(wh + off);
+                    wq[0][1] = *reinterpret_cast<const pf_half8*>(wl + off);
+                }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-                    const pf_half8 whj = *reinterpret_cast<const pf_half8*>(wh + off);
-                    const pf_half8 wlj = *reinterpret_cast<const pf_half8*>(wl + off);
+                    if (j + 1 < NT) {
+                        const int off = pf_lds_chunk_off(wn * WN + (j + 1) * 16 + frow, fchunk);
+                        wq[(j + 1) & 1][0] = *reinterpret_cast<const pf_half8*>(wh + off);
+                        wq[(j + 1) & 1][1] = *reinterpret_cast<const pf_half8*>(wl + off);
+                    }
+                    const pf_half8 whj = wq[j & 1][0], wlj = wq[j & 1][1];
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlj, xhf[i], acc[j][i]);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whj, xlf[i], acc[j][i]);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whj, xhf[i], acc[j][i]);
+                    asm volatile("" ::: "memory");
                 }
             }
         } else {
@@ -915,6 +937,60 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                 __syncthreads();
             }
         }
+        if constexpr (NK > 0) {
+            // One base pointer per pixel unit / weight slot for ALL steps, the step in the instruction's immediate offset: computed per
+            // step, the unrolled loop's 30 x 5 addresses are hoisted to its head and spill.  Rows / channels outside the tensor read
+            // inside it or at most 124 bytes behind it (the arena carries that slack) and are zeroed when they are split.
+            const float* xbase[XUNITS];
+#pragma unroll
+            for (int u = 0; u < XUNITS; ++u) xbase[u] = in + (xvalid[u] ? (size_t)xiy0[u] * a.inLd : (size_t)0) + xc * 8;
+            const unsigned char* wsrc[WCHUNKS];
+#pragma unroll
+            for (int c = 0; c < WCHUNKS; ++c) {
+                const int sl = t + NTHR * c;
+                const int plane = sl >= BN * 4 ? 1 : 0;
+                const int r = (sl - plane * BN * 4) >> 2;
+                const int row = r < BN ? r : BN - 1;
+                const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
+                wsrc[c] = wt + (size_t)min(n0 + row, a.Npad - 1) * wrow_bytes + plane * 64 + chunk * 16;
+            }
+            auto load_x_at = [&](auto cb_tag, pf_f32x4 (&xr)[XUNITS][2]) {
+                constexpr int cb = decltype(cb_tag)::value;
+#pragma unroll
+                for (int u = 0; u < XUNITS; ++u) {
+                    xr[u][0] = *reinterpret_cast<const pf_f32x4*>(xbase[u] + cb * 32);
+                    xr[u][1] = *reinterpret_cast<const pf_f32x4*>(xbase[u] + cb * 32 + 4);
+                }
+            };
+            auto load_w_at = [&](auto cb_tag, int stage) {
+                constexpr int cb = decltype(cb_tag)::value;
+                unsigned char* wdst = smem + stage * STAGE_BYTES + 2 * PLANE_X;
+#pragma unroll
+                for (int c = 0; c < WCHUNKS; ++c)
+                    if (t + NTHR * c < BN * 8) pf_glds16_raw_off<cb * 128>(wsrc[c], wdst + (t + NTHR * c) * 16);
+            };
+            // Unrolled: the pixel operands of steps kt + 1 AND kt + 2 are in flight (two register sets, no loop-carried value, so the
+            // compiler's own vmcnt counting is exact) while step kt's MFMAs run; the weights of step kt + 1 by asm-issued LDS-DMA,
+            // requested BEFORE the newest pixels: vmcnt retires in order, so "all but the 2 XUNITS youngest" at the barrier = the
+            // weights of the next step have landed, the newest pixels have not.  With one step of look-ahead and __syncthreads()
+            // (which drains vmcnt) a K step of conv1x1 960 -> 160 was 8.3 k cycles against 1.9 k of MFMA issue.
+            if constexpr (NK > 1) load_x_at(std::integral_constant<int, 1>{}, xreg[1]);
+            store_tile(0, 0, xreg[0]);
+            if constexpr (NK > 1) pf_wait_vm_barrier<2 * XUNITS>(); else pf_wait_vm_barrier<0>();
+            pf_sched_fence();
+            pf_static_for<NK>([&](auto kt_tag) {
+                constexpr int kt = decltype(kt_tag)::value;
+                constexpr int cur = kt & 1;
+                if constexpr (kt + 1 < NK) { if (!(pf_dbg(a) & 256)) load_w_at(std::integral_constant<int, kt + 1>{}, cur ^ 1); }
+                if constexpr (kt + 2 < NK) { if (!(pf_dbg(a) & 256)) load_x_at(std::integral_constant<int, kt + 2>{}, xreg[cur]); }
+                mma_stage(cur);
+                if constexpr (kt + 1 < NK) { if (!(pf_dbg(a) & 512)) store_tile(cur ^ 1, kt + 1, xreg[cur ^ 1]); }
+                pf_pin(amax);       // the range guard's running maximum is due NOW: left alone, the compiler keeps every step's eight
+                                    // values (in scratch) and folds them at the end of the unrolled loop
+                if constexpr (kt + 2 < NK) pf_wait_vm_barrier<2 * XUNITS>(); else pf_wait_vm_barrier<0>();
+                pf_sched_fence();
+            });
+        } else {
         store_tile(0, 0, xreg[0]);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
@@ -924,6 +1000,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             mma_stage(cur);
             if (more && !(pf_dbg(a) & 512)) store_tile(cur ^ 1, kt + 1, xreg[0]);
             __syncthreads();
+        }
         }
     } else {
     int tap = 0, cb = 0;

@@ -70,6 +70,17 @@ __device__ __forceinline__ void pf_glds16_raw(const void* gsrc, void* lds_lane_p
                  : "=&s"(keep) : "v"(gsrc), "s"(base) : "memory");
 }
 
+// ... with a compile-time byte offset in the instruction (unrolled loops: one base pointer for every step instead of one per step).
+// The instruction's offset is added to BOTH addresses, the global one and the LDS one (LLVM's llvm.amdgcn.global.load.lds: "imm
+// offset, applied to both global and LDS address"): the LDS base handed to M0 is moved back by it.
+template <int OFF> __device__ __forceinline__ void pf_glds16_raw_off(const void* gsrc, void* lds_lane_ptr) {
+    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed instruction offset");
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_lane_ptr) - (unsigned)OFF;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(base), "n"(OFF) : "memory");
+}
+
 // Workgroup barrier that leaves the wave's N youngest VMEM operations (LDS-DMA requests, global loads) in flight:
 // "s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier".  __syncthreads() drains vmcnt to 0, which ends every software-pipeline
 // stage with a full global-memory latency; LDS-DMA stays in flight across s_barrier (MI355X_MICROARCH.md).
@@ -80,6 +91,13 @@ template <int N> __device__ __forceinline__ void pf_wait_vm_barrier() {
     // LDS / global accesses across it, lgkmcnt(0) retires this wave's own LDS writes before the rendezvous
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
 }
+
+// Nothing is scheduled across this point (machine scheduler only): the steps of a completely unrolled K loop are one basic block,
+// and without fences the scheduler drags address arithmetic and epilogue set-up of later steps to the front until registers spill.
+__device__ __forceinline__ void pf_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// the value must be in its register here (ends the compiler's freedom to postpone the arithmetic that produces it)
+__device__ __forceinline__ void pf_pin(unsigned& v) { asm volatile("" : "+v"(v)); }
 
 // shader clock (s_memtime), for the per-wave time accounting of the ablation build
 __device__ __forceinline__ unsigned long long pf_clock() { return __builtin_amdgcn_s_memtime(); }
