@@ -940,6 +940,37 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 PF_LAUNCH((add_upsample_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), h->stream, a);
                 break;
             }
+            case PF_OP_FUSEUP: {
+                if constexpr (sizeof(T) != 4) {
+                    PF_FAIL(h, "fused HRNet fuse sum needs f32 tensors");
+                } else {
+                    const PfTensorRec& ty = p.tens[f[0]];
+                    const PfTensorRec& to = p.tens[f[1]];
+                    FuseUpArgs a{};
+                    a.y = (const float*)p.tensor_ptr(f[0]); a.out = (float*)p.tensor_ptr(f[1]);
+                    a.B = B; a.H = ty.H; a.W = ty.W; a.Cs = ty.C; a.C = f[4 + 12]; a.yLd = ty.ld; a.outLd = to.ld; a.act = f[2]; a.nsrc = f[3];
+                    if (a.nsrc < 1 || a.nsrc > 3 || to.H != ty.H || to.W != ty.W || to.C != ty.C || (ty.C & 3) || a.C > a.Cs) PF_FAIL(h, "fuseup: inconsistent shapes");
+                    int need = 0;
+                    for (int s = 0; s < a.nsrc; ++s) {
+                        const PfTensorRec& ts = p.tens[f[4 + 4 * s]];
+                        a.src[s] = (const float*)p.tensor_ptr(f[4 + 4 * s]); a.wt[s] = (const float*)p.cptr(f[5 + 4 * s]); a.bias[s] = (const float*)p.cptr(f[6 + 4 * s]);
+                        a.shift[s] = f[7 + 4 * s]; a.srcLd[s] = ts.ld; a.srcC[s] = ts.C;
+                        if (a.shift[s] < 1 || a.shift[s] > 3 || (ts.H << a.shift[s]) != ty.H || (ts.W << a.shift[s]) != ty.W || (ts.C & 3))
+                            PF_FAIL(h, "fuseup: source %d does not match the output", s);
+                        const int r = std::max(1, 16 >> a.shift[s]);
+                        need += ts.C * a.Cs + r * r * (ts.C + a.Cs);
+                    }
+                    ProfScope ps(h, "fuse_up");
+                    const int ntiles = B * pf_div_up(ty.H, 16) * pf_div_up(ty.W, 16);
+                    // (512-thread workgroups with y requested at the head of a tile and an 80 KB middle tier: 1.59 ms for the Teacher's 18
+                    // launches against 1.18 ms in this form, profiles/r04_run29 / r04_run30)
+                    if (need <= 12288) PF_LAUNCH((fuse_up_kernel<12288>), dim3(persistent_grid(ntiles, 3)), dim3(256), h->stream, a);        // 48 KB: three per CU
+                    else if (need <= 20480) PF_LAUNCH((fuse_up_kernel<20480>), dim3(persistent_grid(ntiles, 2)), dim3(256), h->stream, a);   // 80 KB: two
+                    else if (need <= 24576) PF_LAUNCH((fuse_up_kernel<24576>), dim3(persistent_grid(ntiles, 1)), dim3(256), h->stream, a);
+                    else PF_FAIL(h, "fuseup: %d floats of LDS needed", need);
+                }
+                break;
+            }
             case PF_OP_MAXPOOL: {
                 const PfTensorRec& ti = p.tens[f[0]];
                 const PfTensorRec& to = p.tens[f[1]];

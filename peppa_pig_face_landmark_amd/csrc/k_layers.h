@@ -634,6 +634,106 @@ __global__ __launch_bounds__(256) void add_upsample_kernel(AddUpArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// The whole fuse sum of a HighResolutionModule towards one of its higher-resolution branches in ONE launch (round 4):
+//   out = act(y + sum over the lower branches s of nearest_upsample(bn(conv1x1_s(x_s)), 2^shift_s))
+// (timm hrnet.py HighResolutionModule.forward / fuse_layers[i][j > i]; Teacher encoder, model.py:306-311).  As separate launches
+// the 64 x 64 x 18 branch was read and written once per term (three add_upsample launches of 34 us for 168 MB each, plus three
+// small 1x1 convs): here a workgroup owns a 16 x 16 tile of the output, computes the 1x1 convs of the (8 x 8, 4 x 4, 2 x 2) low-
+// resolution pixels under it in plain f32 FMAs from LDS (84 pixels x 18 channels x <= 144 deep: nothing next to the tile's
+// 40 KB of traffic), and adds them to y on the way through.  y may already hold the module's strided-conv terms (residual
+// epilogues of those convs).  Terms are added in branch order, like the launches this replaces.
+struct FuseUpArgs {
+    const float* y;      // [B][H][W][yLd]
+    float* out;          // [B][H][W][outLd]
+    int B, H, W, C, Cs, yLd, outLd, act, nsrc;     // C real channels, Cs = C rounded up to 4 (vector padding, written as zeros)
+    const float* src[3]; // [B][H >> shift][W >> shift][srcLd]
+    const float* wt[3];  // [srcC][Cs]
+    const float* bias[3];// [Cs]
+    int srcLd[3], srcC[3], shift[3];
+};
+
+template <int CAP>       // floats of LDS: weights + source patches + low-resolution results of one tile
+__global__ __launch_bounds__(256) void fuse_up_kernel(FuseUpArgs a) {
+    constexpr int T = 16, NTHR = 256;
+    __shared__ __attribute__((aligned(16))) float smem[CAP];
+    const int t = threadIdx.x;
+    const int tilesX = (a.W + T - 1) / T, tilesY = (a.H + T - 1) / T;
+    const int ntiles = a.B * tilesX * tilesY;
+    const int Q = a.Cs / 4;
+    // LDS layout: [weights srcC x Cs of every source][per source: patch R x R x srcC, results R x R x Cs] with R = 16 >> shift
+    int woff[3], xoff[3], loff[3];
+    int off = 0;
+    for (int s = 0; s < a.nsrc; ++s) { woff[s] = off; off += a.srcC[s] * a.Cs; }
+    for (int s = 0; s < a.nsrc; ++s) {
+        const int R = max(1, T >> a.shift[s]);
+        xoff[s] = off; off += R * R * a.srcC[s];
+        loff[s] = off; off += R * R * a.Cs;
+    }
+    // the weights once per workgroup: it walks tiles blockIdx.x, + gridDim.x, ... (one per tile, the 20-41 KB of weights doubled the
+    // launch's traffic: 132 us per launch against 72 us for the launches this kernel replaces)
+    for (int s = 0; s < a.nsrc; ++s) {
+        const int nw4 = a.srcC[s] * a.Cs / 4;
+        for (int i = t; i < nw4; i += NTHR) *reinterpret_cast<pf_f32x4*>(smem + woff[s] + 4 * i) = *reinterpret_cast<const pf_f32x4*>(a.wt[s] + 4 * i);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = tile / (tilesX * tilesY), tt = tile - b * tilesX * tilesY;
+        const int ty0 = (tt / tilesX) * T, tx0 = (tt % tilesX) * T;
+        const int th = min(T, a.H - ty0), tw = min(T, a.W - tx0);
+        int rh[3], rw[3];
+        for (int s = 0; s < a.nsrc; ++s) {
+            const int sh = a.shift[s], K = a.srcC[s];
+            rh[s] = (th + (1 << sh) - 1) >> sh; rw[s] = (tw + (1 << sh) - 1) >> sh;
+            const int lh = a.H >> sh, lw = a.W >> sh, k4 = K / 4;
+            const float* src = a.src[s] + (size_t)b * lh * lw * a.srcLd[s];
+            for (int i = t; i < rh[s] * rw[s] * k4; i += NTHR) {
+                const int px = i / k4, kq = i - px * k4;
+                const int py = px / rw[s], pxx = px - py * rw[s];
+                *reinterpret_cast<pf_f32x4*>(smem + xoff[s] + px * K + 4 * kq) =
+                    *reinterpret_cast<const pf_f32x4*>(src + ((size_t)((ty0 >> sh) + py) * lw + (tx0 >> sh) + pxx) * a.srcLd[s] + 4 * kq);
+            }
+        }
+        __syncthreads();                                           // patches (and, first tile, weights) in place
+        // 1x1 convs of the low-resolution pixels under the tile: thread = (pixel, four output channels), k ascending
+        for (int s = 0; s < a.nsrc; ++s) {
+            const int K = a.srcC[s], n = rh[s] * rw[s] * Q;
+            for (int i = t; i < n; i += NTHR) {
+                const int px = i / Q, q = i - px * Q;
+                pf_f32x4 acc = *reinterpret_cast<const pf_f32x4*>(a.bias[s] + 4 * q);
+                const float* xv = smem + xoff[s] + px * K;
+                const float* wv = smem + woff[s] + 4 * q;
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) {
+                    const float xk = xv[k];
+                    const pf_f32x4 w4 = *reinterpret_cast<const pf_f32x4*>(wv + k * a.Cs);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(xk, w4[e], acc[e]);
+                }
+                *reinterpret_cast<pf_f32x4*>(smem + loff[s] + px * a.Cs + 4 * q) = acc;     // channels >= C: zero weights and bias
+            }
+        }
+        __syncthreads();
+        const float* y = a.y + (size_t)b * a.H * a.W * a.yLd;
+        float* out = a.out + (size_t)b * a.H * a.W * a.outLd;
+        for (int i = t; i < th * tw * Q; i += NTHR) {
+            const int p = i / Q, q = i - p * Q;
+            const int py = p / tw, px = p - py * tw;
+            const size_t pix = (size_t)(ty0 + py) * a.W + tx0 + px;
+            const pf_f32x4 v = *reinterpret_cast<const pf_f32x4*>(y + pix * a.yLd + 4 * q);
+            float sum[4] = {v[0], v[1], v[2], v[3]};
+            for (int s = 0; s < a.nsrc; ++s) {
+                const int sh = a.shift[s];
+                const pf_f32x4 l = *reinterpret_cast<const pf_f32x4*>(smem + loff[s] + ((py >> sh) * rw[s] + (px >> sh)) * a.Cs + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += l[e];
+            }
+            pf_act_n<4>(sum, a.act);
+            *reinterpret_cast<pf_f32x4*>(out + pix * a.outLd + 4 * q) = pf_f32x4{sum[0], sum[1], sum[2], sum[3]};
+        }
+        __syncthreads();                                           // the next tile's patches overwrite what this one still reads
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // Range guard of the split-precision (f32s) convolutions, ALWAYS ON.  Those kernels write every f32 activation as hi + lo
 // with hi = f16(v): |v| >= 65504 overflows to inf, and a tensor whose LARGEST magnitude is below ~1e-3 loses its low halves to
 // the f16 subnormal range.  Weights are pre-scaled per layer at pack time; activations depend on the data, so every kernel that

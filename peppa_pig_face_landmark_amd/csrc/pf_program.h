@@ -14,7 +14,7 @@
 #include <stdint.h>
 
 #define PF_PROGRAM_MAGIC 0x47504650  // "PFPG"
-#define PF_PROGRAM_VERSION 9
+#define PF_PROGRAM_VERSION 10
 
 enum PfElem : int32_t { PF_ELEM_ACT = 0, PF_ELEM_F32 = 1, PF_ELEM_I32 = 2, PF_ELEM_U8 = 3 };
 
@@ -68,6 +68,9 @@ enum PfOpCode : int32_t {
                         //    (k_front.h lm_front_kernel); split programs only
     PF_OP_HRB = 22,     // f: in_t out_t w1 b1 w2 b2 w3 b3 wd(-1) bd(-1) s1 s2 s3 sd (float bits) CIN: an HRNet Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut, mid 64,
                         //    out 256; wd / bd = the first block's shortcut conv) in one launch (k_hrb.h hr_bottleneck_kernel); split programs only
+    PF_OP_FUSEUP = 23,  // f: y_t out_t act nsrc then per source (<= 3): src_t wt bias shift: an HRNet fuse sum towards a higher-resolution branch,
+                        //    out = act(y + sum_s nearest_up(conv1x1_s(src_s), 2^shift_s)), weights f32 [srcC][C padded to 4] (k_layers.h fuse_up_kernel);
+                        //    f32 tensors only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

@@ -17,14 +17,14 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 9
+VERSION = 10
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
 ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
-OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT, OP_HRB = range(1, 23)
+OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT, OP_HRB, OP_FUSEUP = range(1, 24)
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -689,6 +689,43 @@ class ProgramBuilder:
         out = self.tensor(ta.H, ta.W, ta.C, name=out_name)
         self.tensors[out].real_c = ta.real_c
         self._op(OP_ADDUP, [a, b, out, shift, ACT[act]], [self._tb(a), self._tb(b)], [self._tb(out)])
+        return out
+
+    def fuse_up_supported(self, y: int, srcs) -> bool:
+        ty = self.tensors[y]
+        if self.esize != 4 or not 1 <= len(srcs) <= 3 or ty.C % 4:
+            return False
+        need = 0
+        for t, shift in srcs:
+            ts = self.tensors[t]
+            if not 1 <= shift <= 3 or (ts.H << shift, ts.W << shift) != (ty.H, ty.W) or ts.C % 4 or ts.C != ts.real_c:
+                return False
+            r = max(1, 16 >> shift)
+            need += ts.C * ty.C + r * r * (ts.C + ty.C)
+        return need <= 24576
+
+    def fuse_up(self, y: int, terms, act: str, out_name: str = "") -> int:
+        """out = act(y + sum_s nearest_upsample(conv1x1_s(src_s) + b_s, 2**shift_s)) in ONE launch (csrc/k_layers.h fuse_up_kernel): the
+        fuse sum of an HRNet module towards one of its higher-resolution branches (timm hrnet.py fuse_layers[i][j > i]).
+        terms = [(src tensor, weight [C, srcC, 1, 1] BN-folded, bias [C], shift)], added in the order given."""
+        ty = self.tensors[y]
+        assert self.fuse_up_supported(y, [(t, sh) for t, _, _, sh in terms])
+        out = self.tensor(ty.H, ty.W, ty.C, name=out_name)
+        self.tensors[out].real_c = ty.real_c
+        f = [y, out, ACT[act], len(terms)]
+        reads = [self._tb(y)]
+        for t, w, b, shift in terms:
+            ts = self.tensors[t]
+            c, k = w.shape[0], w.shape[1]
+            assert c == ty.real_c and k == ts.real_c == ts.C
+            wt = np.zeros((k, ty.C), np.float64)
+            wt[:, :c] = w.reshape(c, k).T
+            bb = np.zeros(ty.C, np.float64)
+            bb[:c] = b
+            f += [t, self.const_f32(wt), self.const_f32(bb), shift]
+            reads.append(self._tb(t))
+        f += [-1, 0, 0, 0] * (3 - len(terms)) + [ty.real_c]
+        self._op(OP_FUSEUP, f, reads, [self._tb(out)])
         return out
 
     def gap(self, x: int) -> int:

@@ -110,6 +110,11 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                                ("relu" if final else "none") if lastc else "relu", stride=2, res=y if lastc else -1,
                                name=name if final else "")
                     y = t
+                if up and fuse_chains and pb.fuse_up_supported(y, [(xs[j], j - i) for j in up]):
+                    # every upsampled term of this output in one launch (csrc/k_layers.h fuse_up_kernel); they are the last terms of the sum
+                    terms = [(xs[j], *ir.fold_bn(w[f"{p}.fuse_layers.{i}.{j}.0.weight"], None, _bn(w, f"{p}.fuse_layers.{i}.{j}.1")), j - i) for j in up]
+                    y = pb.fuse_up(y, terms, "relu", out_name=name)
+                    up = []
                 for j in up:       # 1x1 conv at low resolution, nearest upsample, add
                     t = cb(xs[j], f"{p}.fuse_layers.{i}.{j}.0", f"{p}.fuse_layers.{i}.{j}.1", "none")
                     done += 1

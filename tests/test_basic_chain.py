@@ -169,3 +169,45 @@ def test_bottleneck_equals_separate_convs_emu(emu_engine, h, w, batch):
 @pytest.mark.parametrize("h,w,batch", [(64, 64, 5), (20, 40, 9), (36, 24, 3)])
 def test_bottleneck_equals_separate_convs_gpu(gpu_engine, h, w, batch):
     _bottleneck_case(gpu_engine, h, w, batch, seed=800 + h + w)
+
+
+def _fuse_up_case(eng, h, w, c, src_c, batch, seed):
+    """PF_OP_FUSEUP (csrc/k_layers.h fuse_up_kernel: every upsampled term of an HRNet fuse sum in one launch; timm hrnet.py
+    HighResolutionModule fuse_layers[i][j > i], TeacherNet model.py:306-311) against the launches it replaces in the same program:
+    1x1 conv at low resolution -> nearest upsample -> add, term by term, relu on the last."""
+    rng = np.random.default_rng(seed)
+    pb = ir.ProgramBuilder("f32s", 2 * h, 2 * w, keep_all=True)
+    f0 = pb.stem(rng.normal(0, 0.6, (16, 3, 3, 3)), rng.normal(0, 0.1, 16), "relu")
+    y = pb.conv(f0, rng.normal(0, 0.35, (c, 16, 1, 1)), rng.normal(0, 0.2, c), "none", out_name="y")
+    srcs, t = [], f0
+    for s, k in enumerate(src_c):                        # the lower branches: strided convs of the stem map
+        t = pb.conv(t, rng.normal(0, np.sqrt(2.0 / (9 * pb.tensors[t].real_c)), (k, pb.tensors[t].real_c, 3, 3)), rng.normal(0, 0.1, k), "relu",
+                    stride=2, pad=1)
+        srcs.append(t)
+    terms = [(srcs[s], rng.normal(0, np.sqrt(1.0 / k), (c, k, 1, 1)), rng.normal(0, 0.1, c), s + 1) for s, k in enumerate(src_c)]
+    assert pb.fuse_up_supported(y, [(t, sh) for t, _, _, sh in terms])
+    fused = pb.fuse_up(y, terms, "relu", out_name="fused")
+    r = y
+    for i, (t, wt, b, sh) in enumerate(terms):
+        u = pb.conv(t, wt, b, "none")
+        r = pb.add_up(r, u, sh, "relu" if i == len(terms) - 1 else "none", out_name="ref" if i == len(terms) - 1 else "")
+    blob = pb.finish([pb.buffer(196, ir.ELEM_F32, "loc"), pb.buffer(98, ir.ELEM_F32, "score")])
+    eng.load_program(0, blob, batch)
+    eng.landmark_forward(rng.integers(0, 256, (batch, 2 * h, 2 * w, 3), dtype=np.uint8))
+    cp = (c + 3) // 4 * 4
+    got = eng.read_tensor(0, pb.tensor_names["fused"], batch, (h, w, cp))
+    ref = eng.read_tensor(0, pb.tensor_names["ref"], batch, (h, w, cp))
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0.1 and (ref == 0).any() and not got[..., c:].any()
+    rel = np.abs(got - ref).max() / np.abs(ref).max()
+    assert rel < 2e-5, (h, w, c, rel)          # the reference's 1x1 convs are split-precision products, the fused ones plain f32 FMAs
+
+
+@pytest.mark.parametrize("h,w,c,src_c,batch", [(32, 32, 18, (36, 72, 144), 2), (24, 40, 36, (72,), 1), (8, 8, 72, (144,), 3)])
+def test_fuse_up_equals_separate_launches_emu(emu_engine, h, w, c, src_c, batch):
+    _fuse_up_case(emu_engine, h, w, c, src_c, batch, seed=900 + h + c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,c,src_c,batch", [(64, 64, 18, (36, 72, 144), 5), (32, 32, 36, (72, 144), 7), (16, 16, 72, (144,), 9), (24, 40, 18, (36,), 3)])
+def test_fuse_up_equals_separate_launches_gpu(gpu_engine, h, w, c, src_c, batch):
+    _fuse_up_case(gpu_engine, h, w, c, src_c, batch, seed=1000 + h + c)
