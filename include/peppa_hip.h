@@ -169,7 +169,8 @@ int pf_decode_jpeg(pf_handle* h, const uint8_t* jpeg, size_t bytes, int* height,
  * compressed scan crosses PCIe; files WITHOUT restart markers always take the device's sub-sequence decoder
  * (pf_set_option(PF_OPT_JPEG_ENTROPY, 1 | 2) overrides either choice).  If that decoder does not settle, this asynchronous call cannot decode
  * again by itself: the next synchronising call on the handle fails with "did not synchronise" and the batch has to be resubmitted
- * after pf_set_option(PF_OPT_JPEG_ENTROPY, 1) (ordinary photographs settle in the first rounds; PF_OPT_JPEG_SYNC_ROUNDS queues fewer
+ * after pf_set_option(PF_OPT_JPEG_ENTROPY, 1) -- the Python shim's Engine.run_jpeg_files() does that and repeats the pipeline
+ * call that consumed the frames (ordinary photographs settle in the first rounds; PF_OPT_JPEG_SYNC_ROUNDS queues fewer
  * rounds than the default 10 -- that can only make the decoder give up sooner, i.e. fall back or report, never return different
  * pixels).  Asynchronous like pf_run_frames: the frames are valid in the order of the
  * handle's stream (pf_run_frames on the same handle just works; pf_sync before another stream reads them).  Two buffer sets

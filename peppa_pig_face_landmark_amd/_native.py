@@ -451,6 +451,49 @@ class Engine:
                     "pf_decode_jpeg_batch")
         return d.value, n, hh.value, ww.value
 
+    def run_jpeg_files(self, files, score_thres: float, iou_thres: float, min_face: float, top_k: int, threads: int = 16,
+                       planted_rows: Optional[np.ndarray] = None):
+        """``pf_decode_jpeg_batch`` + ``pf_run_frames`` on the decoded frames, synchronous, numpy results as ``run_frames``.
+
+        The C ABI's batch decode is asynchronous and reports a Huffman stream the device's parallel entropy decoder could not
+        synchronise (a valid file with a long stretch that never re-aligns) at the NEXT synchronising call, when the frames have
+        already been consumed.  This wrapper owns the recovery the ABI leaves to its caller: the batch is decoded again with the
+        host's Huffman loop (``PF_OPT_JPEG_ENTROPY`` = 1 for that one call) and the frames are run again -- no file that the
+        host path decodes fails here."""
+        files = [bytes(d) for d in files]
+        F = len(files)
+        counts = np.zeros((F,), np.int32)
+        boxes = np.zeros((F, top_k, 4), np.float32)
+        kps = np.zeros((F, top_k, 98, 2), np.float32)
+        scores = np.zeros((F, top_k, 98), np.float32)
+
+        pr = None if planted_rows is None else np.ascontiguousarray(planted_rows, np.float32)     # benchmark / test instrument, as run_frames
+
+        def once():
+            d, n, hh, ww = self.decode_jpeg_batch(files, threads)
+            if pr is None:
+                rc = self.lib.pf_run_frames(self.h, _ptr(d), PF_MEM_DEVICE, n, hh, ww, score_thres, iou_thres, min_face, top_k,
+                                            _ptr(counts), _ptr(boxes), _ptr(kps), _ptr(scores), PF_MEM_HOST)
+            else:
+                rc = self.lib.pf_run_frames_planted(self.h, _ptr(d), PF_MEM_DEVICE, n, hh, ww, _ptr(pr), pr.shape[1], score_thres,
+                                                    iou_thres, min_face, top_k, _ptr(counts), _ptr(boxes), _ptr(kps), _ptr(scores),
+                                                    PF_MEM_HOST)
+            self._check(rc, "pf_run_frames")
+            self.sync()
+
+        try:
+            once()
+        except PeppaHipError as e:
+            if "did not synchronise" not in str(e):
+                raise
+            before = self.__dict__.get("_options", {}).get(PF_OPT_JPEG_ENTROPY, 0)
+            self.set_option(PF_OPT_JPEG_ENTROPY, 1)
+            try:
+                once()
+            finally:
+                self.set_option(PF_OPT_JPEG_ENTROPY, before)
+        return counts, boxes, kps, scores
+
     def imread(self, path_or_bytes, want_host: bool = True) -> "DeviceFrame":
         """cv2.imread(path) for baseline JPEG files, decoded into device memory (see decode_jpeg)."""
         data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
@@ -519,6 +562,7 @@ class Engine:
     def set_option(self, option: int, value: int):
         """PF_OPT_HIP_GRAPH (1): replay device-resident run_frames calls from a captured hipGraph."""
         self._check(self.lib.pf_set_option(self.h, int(option), int(value)), "pf_set_option")
+        self.__dict__.setdefault("_options", {})[int(option)] = int(value)
 
     # ---- profiling ----------------------------------------------------------------------------
     def profile_enable(self, on: bool = True):

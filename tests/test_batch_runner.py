@@ -144,3 +144,34 @@ def test_frame_batch_runner_facade(hip_library, student_weights, detector_weight
         want = fa.run(frames[f])
         assert len(got[f]) == len(want)
     fa.engine.close()
+
+
+def test_run_jpeg_files_recovers_with_the_host_decoder_emu(emu_library, student_weights):
+    """Engine.run_jpeg_files = pf_decode_jpeg_batch + pf_run_frames (demo.py:76 over a batch of files).  A Huffman stream the device's
+    sub-sequence decoder cannot synchronise in the rounds it was given (forced here: one round, quality-100 noise) is reported by the
+    C ABI at the next synchronising call; the wrapper decodes the batch again on the host path and runs the frames again -- results
+    equal to the same pipeline fed with libjpeg's pixels."""
+    import io
+    from PIL import Image
+    S, top_k = 64, 3
+    frames, rows = _small_inputs(2)
+    rng = np.random.default_rng(5)
+    noisy = np.clip(frames.astype(np.int16) + rng.integers(-60, 60, frames.shape), 0, 255).astype(np.uint8)
+    files = []
+    for f in noisy:
+        buf = io.BytesIO()
+        Image.fromarray(f[..., ::-1]).save(buf, "JPEG", quality=100, subsampling=2)
+        files.append(buf.getvalue())
+    decoded = np.stack([np.asarray(Image.open(io.BytesIO(d)).convert("RGB"))[..., ::-1] for d in files])
+    eng = _native.Engine(0, emu_library)
+    eng.load_program(0, build_student_program(student_weights, S, "f32")[0], 2 * top_k)
+    ref = eng.run_frames(decoded, 0.5, 0.3, 100.0, top_k, planted_rows=rows)
+    eng.set_option(_native.PF_OPT_JPEG_SYNC_ROUNDS, 1)
+    eng.decode_jpeg_batch(files, threads=2)
+    with pytest.raises(_native.PeppaHipError, match="did not synchronise"):      # what the bare ABI does
+        eng.sync()
+    got = eng.run_jpeg_files(files, 0.5, 0.3, 100.0, top_k, threads=2, planted_rows=rows)
+    eng.close()
+    assert ref[0].tolist() == [top_k, top_k]
+    for r, g in zip(ref, got):
+        assert np.array_equal(r, g)
