@@ -130,6 +130,7 @@ def parse_args():
                     "rocprofv3 traces of the multi-lane steady state); roofline is null then")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
                     "(a sustained rate an external GPU-busy sampler can see)")
+    ap.add_argument("--jpeg-threads", type=int, default=4, help="host threads per lane that strip the byte stuffing in the JPEG-file ingest probe")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-faces", type=int, default=24)
     ap.add_argument("--dump-profile", default="", help="write the full per-kernel HIP-event table (JSON) here")
@@ -588,7 +589,7 @@ def main():
         try:
             if not have_pil:
                 raise ImportError("PIL not installed: no way to write the JPEG test files")
-            thr = 4
+            thr = max(1, args.jpeg_threads)
             jpeg = {"note": "every frame of the step arrives as a baseline 4:2:0 JPEG file (quality 90) in host memory: pf_decode_jpeg_batch "
                             "feeds pf_run_frames, one host thread per lane drives decode + pipeline; output bit-identical with libjpeg.  The "
                             "files carry no restart markers: the host threads only strip the byte stuffing, the Huffman stream is decoded on the "
