@@ -99,7 +99,7 @@ def tag_flops_per_face(tag: str):
 
 
 KERNEL_OF_TAG_F32S = (   # profile tag prefix -> the HIP kernel that runs it in an f32s program (csrc/engine.cpp dispatch)
-    ("conv3x3_c128_n128_64x64", "conv3x3_halo_split_kernel<128,4,2>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
+    ("conv3x3_c128_n128_64x64", "conv3x3_hero_kernel<4>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
     ("sepup_", "sepup_skip_kernel + sepup_pipe_kernel (sepup_patch_kernel fallback)"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
     ("conv", "conv_gemm_split_kernel"))
 
@@ -535,7 +535,7 @@ def main():
             with open(pmc_path) as f:
                 pmc = json.load(f)
             faces_pmc = int(pmc.get("_meta", {}).get("faces_per_launch", 256))
-            rec = next((v for k, v in pmc.items() if "conv3x3_halo_split_kernel<128" in k), None)
+            rec = next((v for k, v in pmc.items() if "conv3x3_hero_kernel" in k or "conv3x3_halo_split_kernel<128" in k), None)
             if rec and "FETCH_SIZE" in rec and "WRITE_SIZE" in rec:
                 # raw counters are KB; FETCH_SIZE under-reports wide coalesced reads by exactly 2x on gfx950 (MI355X_MICROARCH.md, HBM)
                 roofline["traffic"] = int((2.0 * rec["FETCH_SIZE"] + rec["WRITE_SIZE"]) * 1024.0 * faces_per_launch / faces_pmc)

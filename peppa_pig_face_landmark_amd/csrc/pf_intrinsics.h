@@ -74,11 +74,20 @@ __device__ __forceinline__ void pf_glds16_raw(const void* gsrc, void* lds_lane_p
 // The instruction's offset is added to BOTH addresses, the global one and the LDS one (LLVM's llvm.amdgcn.global.load.lds: "imm
 // offset, applied to both global and LDS address"): the LDS base handed to M0 is moved back by it.
 template <int OFF> __device__ __forceinline__ void pf_glds16_raw_off(const void* gsrc, void* lds_lane_ptr) {
-    static_assert(OFF >= 0 && OFF < 4096, "13-bit signed instruction offset");
+    static_assert(OFF >= -4096 && OFF < 4096, "13-bit signed instruction offset");
     const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_lane_ptr) - (unsigned)OFF;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(base), "n"(OFF) : "memory");
+}
+
+// ... and with the address as wave-uniform base + 32-bit per-lane byte offset (one VGPR instead of two per pointer)
+template <int OFF> __device__ __forceinline__ void pf_glds16_raw_soff(const void* sbase, unsigned voff, void* lds_lane_ptr) {
+    static_assert(OFF >= -4096 && OFF < 4096, "13-bit signed instruction offset");
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_lane_ptr) - (unsigned)OFF;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(base), "n"(OFF) : "memory");
 }
 
 // Workgroup barrier that leaves the wave's N youngest VMEM operations (LDS-DMA requests, global loads) in flight:

@@ -110,6 +110,7 @@ inline void pf_wave_sync() { pf_emu::wave_barrier(); }
 
 inline void pf_glds16(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
 inline void pf_glds16_raw(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, gsrc, 16); }
+template <int OFF> inline void pf_glds16_raw_soff(const void* sbase, unsigned voff, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, static_cast<const unsigned char*>(sbase) + voff + OFF, 16); }
 template <int OFF> inline void pf_glds16_raw_off(const void* gsrc, void* lds_lane_ptr) { std::memcpy(lds_lane_ptr, static_cast<const unsigned char*>(gsrc) + OFF, 16); }
 
 template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous

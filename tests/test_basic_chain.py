@@ -77,13 +77,13 @@ def _narrow_conv_case(eng, c, hw, batch, seed):
     assert rel < 5e-6, (c, hw, rel)          # f32 accumulation over up to 576 products
 
 
-@pytest.mark.parametrize("c,hw,batch", [(18, 16, 3), (18, 32, 1), (36, 16, 2), (64, 64, 1)])
+@pytest.mark.parametrize("c,hw,batch", [(18, 16, 3), (18, 32, 1), (36, 16, 2), (64, 64, 1), (128, 64, 1)])      # (128, 64): csrc/k_hero.h
 def test_narrow_halo_convs_emu(emu_engine, c, hw, batch):
     _narrow_conv_case(emu_engine, c, hw, batch, seed=300 + c + hw)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2), (64, 64, 3)])
+@pytest.mark.parametrize("c,hw,batch", [(18, 64, 5), (36, 32, 9), (18, 32, 3), (36, 16, 4), (72, 16, 2), (64, 64, 3), (128, 64, 5)])
 def test_narrow_halo_convs_gpu(gpu_engine, c, hw, batch):
     _narrow_conv_case(gpu_engine, c, hw, batch, seed=400 + c + hw)
 

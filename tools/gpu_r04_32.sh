@@ -17,15 +17,15 @@ timeout 300 python bench.py --workload landmark --steps 20 --warmup 3 --no-cpu-b
 import json; d=json.loads(open('gpurun_out/${T}_bench_landmark.json').read().strip().splitlines()[-1]); print('LANDMARK-ONLY', d['value'], d['ms_per_step'])"
 cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof1 -- python $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 2 --no-probes --no-cpu-baseline --no-kernel-table --lanes 1 --frames 32 > /tmp/prof1.out 2>&1
 cd $GRAFT_REPO_ROOT && python tools/rocprof_summary.py /tmp/prof1 gpurun_out/${T}_rocprofv3_kernel_stats_1lane.md > /dev/null && head -8 gpurun_out/${T}_rocprofv3_kernel_stats_1lane.md
-timeout 600 python tools/pmc_kernel.py conv3x3_halo_split_kernel --out=${T}_pmc_hero_sq > /dev/null 2>&1
-timeout 300 python tools/pmc_kernel.py conv3x3_halo_split_kernel --counters=FETCH_SIZE,WRITE_SIZE --out=${T}_pmc_hero_mem > /dev/null 2>&1
+timeout 600 python tools/pmc_kernel.py conv3x3_hero_kernel --out=${T}_pmc_hero_sq > /dev/null 2>&1
+timeout 300 python tools/pmc_kernel.py conv3x3_hero_kernel --counters=FETCH_SIZE,WRITE_SIZE --out=${T}_pmc_hero_mem > /dev/null 2>&1
 DET="--workload pipeline --steps 2 --warmup 1 --no-cpu-baseline --no-probes --no-kernel-table --lanes 1 --frames 32"
 timeout 600 python tools/pmc_kernel.py det_ --out=${T}_pmc_det_sq $DET > /dev/null 2>&1
 timeout 300 python tools/pmc_kernel.py det_ --counters=FETCH_SIZE,WRITE_SIZE --out=${T}_pmc_det_mem $DET > /dev/null 2>&1
 python - <<PY
 import json
 a=json.load(open("gpurun_out/${T}_pmc_hero_sq.json")); b=json.load(open("gpurun_out/${T}_pmc_hero_mem.json"))
-k=[x for x in a if "halo_split_kernel<128" in x][0]
+k=[x for x in a if "conv3x3_hero_kernel" in x][0]
 rec=dict(a[k]); rec.update(b.get(k, {}))
 json.dump({"_meta": {"round": 4, "faces_per_launch": 256, "tool": "tools/pmc_kernel.py (one rocprofv3 --pmc pass per counter group; FETCH_SIZE / WRITE_SIZE in KB)"}, k: rec}, open("gpurun_out/${T}_pmc_hero.json", "w"), indent=1)
 print("hero", {c: rec.get(c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA")})
