@@ -267,7 +267,8 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
-            if (a.Npad == 128 && a.Cpad == 128 && a.outW == 64 && !(host_dbg(h) & 2048)) PF_LAUNCH((conv3x3_hero_kernel<4>), grid, dim3(512), h->stream, a);   // k_hero.h
+            if (a.Npad == 128 && a.Cpad == 128 && a.outW == 64 && (host_dbg(h) & 16384)) PF_LAUNCH((conv3x3_hero_kernel<4, false>), grid, dim3(512), h->stream, a);   // A/B aid (ablation build)
+            else if (a.Npad == 128 && a.Cpad == 128 && a.outW == 64 && !(host_dbg(h) & 2048)) PF_LAUNCH((conv3x3_hero_kernel<4>), grid, dim3(512), h->stream, a);   // k_hero.h
             else if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
             else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);

@@ -15,7 +15,7 @@
 #pragma once
 #include "k_conv_gemm.h"
 
-template <int CB>
+template <int CB, bool LATE_DMA = true>
 __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
     constexpr int BN = 128, BM = 128, W = 64, TR = 2, WARPS_M = 4, WARPS_N = 2, NTHR = 512;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N, MT = WM / 16, NT = WN / 16;
@@ -125,7 +125,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
         constexpr int kt = decltype(kt_tag)::value;
         constexpr int tap = kt % 9, cb = kt / 9, ky = tap / 3, kx = tap % 3;
         constexpr bool next_x = tap == 0 && cb + 1 < CB;
-        if constexpr (kt + 2 < NKT) load_w(std::integral_constant<int, kt + 2>{});
+        constexpr bool restage = tap == 8 && cb + 1 < CB;                           // this step ends with the next chunk's planes being written
+        constexpr bool late = restage && LATE_DMA;
+        // (the compiler waits for the pixel registers with vmcnt(0) where it splits them: a DMA issued in front of that would be drained
+        // on the spot, so the re-staging steps request their weights behind the split)
+        if constexpr (kt + 2 < NKT && !late) load_w(std::integral_constant<int, kt + 2>{});
         if constexpr (next_x) load_x(std::integral_constant<int, cb + 1>{});         // AFTER the DMA: younger, may outlive two barriers
         const unsigned char* wh = wbase + (kt % NSTG) * W_BYTES;
         const unsigned char* wl = wh + BN * 64;
@@ -173,10 +177,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
         // (2 XU) while they are younger than those weights, i.e. in the steps of taps 0 and 1
         constexpr int dma = kt + 2 < NKT ? WCH : 0;
         constexpr int keep = dma + (((tap == 0 || tap == 1) && cb + 1 < CB) ? 2 * XU : 0);
-        if constexpr (tap == 8 && cb + 1 < CB) {
-            pf_wait_vm_barrier<keep>();                  // every wave is done with this chunk's planes
+        if constexpr (restage) {
+            pf_wait_vm_barrier<late ? 0 : keep>();       // every wave is done with this chunk's planes
             store_x();
             pf_pin(amax);
+            if constexpr (kt + 2 < NKT && late) load_w(std::integral_constant<int, kt + 2>{});
         }
         pf_wait_vm_barrier<keep>();
         pf_sched_fence();
