@@ -47,20 +47,28 @@ def needs_build() -> bool:
 
 
 ABLATE_OUT = os.path.join(HERE, "libpeppa_hip_ablate.so")
+STRICT_OUT = os.path.join(HERE, "libpeppa_hip_strict.so")
+# tool / test flavours of the same sources (never loaded by the product: _native.DEFAULT_LIBRARY is libpeppa_hip.so)
+FLAVOURS = {"": (OUT, []), "ablate": (ABLATE_OUT, ["-DPF_ABLATE=1"]), "strict": (STRICT_OUT, ["-DPF_STRICT_WAITS=1"])}
 
 
-def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False) -> str:
-    """``ablate=True`` builds the TOOL flavour (``libpeppa_hip_ablate.so``, -DPF_ABLATE=1): the same sources with the timing
-    ablations of the GEMM kernels compiled in and PEPPA_DBG honoured (tools/ab_env.py; wrong results by construction).  The
-    production library has neither."""
-    out, stamp = (ABLATE_OUT, ABLATE_OUT + ".srchash") if ablate else (OUT, STAMP)
+def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False, flavour: str = "") -> str:
+    """``ablate=True`` (= ``flavour="ablate"``) builds the TOOL flavour (``libpeppa_hip_ablate.so``, -DPF_ABLATE=1): the same
+    sources with the timing ablations of the GEMM kernels compiled in and PEPPA_DBG honoured (tools/ab_env.py; wrong results
+    by construction).  ``flavour="strict"`` builds the TEST flavour ``libpeppa_hip_strict.so`` (-DPF_STRICT_WAITS=1): every
+    partial ``s_waitcnt vmcnt(N)`` in front of a raw barrier (pf_wait_vm_barrier<N>, the hand-counted LDS-DMA rings) drains to
+    vmcnt(0) instead, so a miscounted N shows up as production != strict in tests/test_gpu_race_net.py.  The production
+    library has neither switch."""
+    flavour = "ablate" if ablate else flavour
+    out, defs = FLAVOURS[flavour]
+    stamp = STAMP if not flavour else out + ".srchash"
     if not force:
-        if ablate and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
+        if flavour and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == source_hash():
             return out
-        if not ablate and not needs_build():
+        if not flavour and not needs_build():
             return out
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", CSRC] + (["-DPF_ABLATE=1"] if ablate else []) + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+           "-I", CSRC] + defs + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
     if verbose:
         print("[peppa-hip] " + " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
@@ -70,4 +78,4 @@ def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False) -
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv, ablate="--ablate" in sys.argv))
+    print(build_hip(force="--force" in sys.argv, ablate="--ablate" in sys.argv, flavour="strict" if "--strict" in sys.argv else ""))

@@ -16,9 +16,11 @@ from typing import Dict, List, Optional
 import numpy as np
 
 from ... import _native
+from ...logger.logger import logger
 from ...graph.detector import build_detector_program
 from ...graph.student import build_student_program
-from .facer import _load_weights, get_cfg
+from ..smoother.lk import EmaFilter
+from .facer import _box_iou, _load_weights, get_cfg
 from .hip_model_base import _RANGE_ERR
 
 
@@ -42,6 +44,8 @@ class FrameBatchRunner:
         self.iou_thrs = float(sk["Detect"]["iou_thrs"])
         self.min_face = float(sk["Detect"]["min_face"])
         self.top_k = int(top_k if top_k is not None else sk["Detect"]["topk"])
+        self.track_iou_thres = float(sk["Trace"]["iou_thres"])
+        self._box_filter = EmaFilter(float(sk["Trace"]["smooth_box"]))
         self.lanes, self.frames_per_lane = int(lanes), int(frames_per_lane)
         self.engine = _native.BatchEngine(self.device, self.lanes, library)
         self.engine.set_option(_native.PF_OPT_HIP_GRAPH, 1 if graph else 0)
@@ -74,6 +78,7 @@ class FrameBatchRunner:
                 m = _RANGE_ERR.search(str(e))
                 if not m:
                     raise
+                logger.warning("range guard: %s -- reloading network %s as exact f32 on all %d lanes", e, m.group(1), self.lanes)
                 self._load(int(m.group(1)), "f32")
         raise _native.PeppaHipError("range guard fallback did not converge")
 
@@ -87,14 +92,31 @@ class FrameBatchRunner:
             raise ValueError("%d frames exceed lanes * frames_per_lane = %d" % (frames.shape[0], self.max_frames))
         return self._guarded(self.engine.run_frames, frames, self.score_thrs, self.iou_thrs, self.min_face, self.top_k, planted_rows)
 
+    def _returned_boxes(self, det_boxes: np.ndarray, kps: np.ndarray) -> np.ndarray:
+        """The 'box' a fresh ``FaceAna.run`` hands back (facer.py:81-84): not the detector's box but the hull of the face's
+        landmarks, EMA-smoothed against the first detector box it overlaps (``judge_boxs(boxes_return, hulls)``)."""
+        hulls = np.array([[np.min(l[:, 0]), np.min(l[:, 1]), np.max(l[:, 0]), np.max(l[:, 1])] for l in kps])
+        out = []
+        for i in range(hulls.shape[0]):
+            for j in range(det_boxes.shape[0]):
+                if _box_iou(hulls[i], det_boxes[j]) > self.track_iou_thres:
+                    out.append(self._box_filter(hulls[i][:4], det_boxes[j][:4]))
+                    break
+            else:
+                out.append(hulls[i][0:4])
+        return np.array(out)
+
     def run(self, frames) -> List[List[Dict[str, np.ndarray]]]:
-        """Per frame what ``FaceAna.run(frame)`` returns for a fresh instance: ``[{'box', 'kps', 'scores'}, ...]``."""
+        """Per frame what ``FaceAna.run(frame)`` returns for a fresh instance: ``[{'box', 'kps', 'scores'}, ...]`` -- 'box' is
+        the smoothed landmark hull like the reference's, the detector's own box rides along as 'det_box'."""
         frames = np.stack(frames) if isinstance(frames, (list, tuple)) else np.asarray(frames)
         out: List[List[Dict[str, np.ndarray]]] = []
         for s in range(0, frames.shape[0], self.max_frames):
             counts, boxes, kps, scores = self.run_arrays(frames[s:s + self.max_frames])
             for f in range(counts.shape[0]):
-                out.append([{"box": boxes[f, i], "kps": kps[f, i], "scores": scores[f, i]} for i in range(int(counts[f]))])
+                n = int(counts[f])
+                ret = self._returned_boxes(boxes[f, :n], kps[f, :n]) if n else np.zeros((0, 4), np.float32)
+                out.append([{"box": ret[i], "kps": kps[f, i], "scores": scores[f, i], "det_box": boxes[f, i]} for i in range(n)])
         return out
 
     def close(self):

@@ -55,7 +55,11 @@ def _host_imread(data: bytes):
     except ImportError:
         return None
     try:
+        from PIL import ImageOps
         with Image.open(io.BytesIO(data)) as im:
+            im = ImageOps.exif_transpose(im)         # cv2.imread applies the EXIF orientation (IMREAD_COLOR without IGNORE_ORIENTATION)
+            if im.mode in ("I;16", "I;16B", "I;16L", "I"):      # 16-bit greyscale: cv2.imread(IMREAD_COLOR) keeps the HIGH byte
+                im = im.point(lambda v: v / 256.0).convert("L")
             rgb = np.asarray(im.convert("RGB"))
     except Exception:  # noqa: BLE001  (truncated / unknown format)
         return None
@@ -155,6 +159,7 @@ class FaceAna:
             # Everything else cv2.imread opens (demo.py:76) -- progressive / arithmetic-coded / CMYK JPEG, PNG, BMP, ... -- is
             # decoded on the HOST, as the reference itself does for every file, and handed to run() as the numpy array
             # cv2.imread would have returned; only baseline JPEG has a device decoder (csrc/jpeg.inl).
+            # NOTE the type: a host-decoded file comes back as the ndarray cv2.imread returns, not as a DeviceFrame (run() takes both)
             frame = _host_imread(bytes(data))
             if frame is None:
                 logger.warning("imread: %s", e)

@@ -119,14 +119,33 @@ int pf_batch_run_frames(pf_batch* b, const uint8_t* frames, int mem, int n_frame
         s_counts = (int*)q;
         lane_out = PF_MEM_HOST_PINNED;
     }
+    // every lane's share is checked BEFORE anything is enqueued: a lane that refuses its slice must not leave the lanes in front of
+    // it writing into buffers the caller frees when the call fails
+    for (int i = 0; i < L; ++i) {
+        const int f0 = i * per, nf = std::min(per, n_frames - f0);
+        if (nf <= 0) break;
+        const Program& det = b->lane[i]->prog[PF_NET_DETECTOR];
+        const Program& lm = b->lane[i]->prog[PF_NET_LANDMARK];
+        if (!lm.loaded) PF_BFAIL(b, "lane %d: landmark program not loaded", i);
+        if (!det.loaded && !det_rows) PF_BFAIL(b, "lane %d: no detector program and no planted rows", i);
+        if (nf * top_k > lm.max_batch) PF_BFAIL(b, "lane %d: %d faces exceed the landmark program's max_batch %d", i, nf * top_k, lm.max_batch);
+        if (det.loaded && nf > det.max_batch) PF_BFAIL(b, "lane %d: %d frames exceed the detector program's max_batch %d", i, nf, det.max_batch);
+    }
     for (int i = 0; i < L; ++i) {
         const int f0 = i * per, nf = std::min(per, n_frames - f0);
         if (nf <= 0) break;
         if (pf_run_frames_planted(b->lane[i], frames + (size_t)f0 * frame_bytes, mem, nf, height, width,
                                   det_rows ? det_rows + (size_t)f0 * rows * 16 : nullptr, rows, score_thres, iou_thres, min_face, top_k,
                                   counts ? s_counts + f0 : nullptr, boxes ? s_boxes + (size_t)f0 * n_box : nullptr,
-                                  kps ? s_kps + (size_t)f0 * n_kps : nullptr, scores ? s_scores + (size_t)f0 * n_sc : nullptr, lane_out))
-            PF_BFAIL(b, "lane %d: %s", i, pf_last_error(b->lane[i]));
+                                  kps ? s_kps + (size_t)f0 * n_kps : nullptr, scores ? s_scores + (size_t)f0 * n_sc : nullptr, lane_out)) {
+            // the lanes already launched keep writing into the caller's buffers (or the staging): drain them before reporting, and
+            // keep the FIRST error text
+            char first[640];
+            snprintf(first, sizeof(first), "lane %d: %s", i, pf_last_error(b->lane[i]));
+            for (int j = 0; j < i; ++j) (void)pf_sync(b->lane[j]);
+            b->err = first;
+            return 1;
+        }
     }
     if (out_mem != PF_MEM_HOST) return 0;
     if (pf_batch_sync(b)) return 1;

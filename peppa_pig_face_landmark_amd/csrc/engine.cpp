@@ -31,17 +31,19 @@
 
 namespace {
 
-// Compute units of the device the process runs on: 256 on MI355X (8 XCDs x 32 CUs), queried at pf_create.  Persistent kernels size
-// their grids with it and the tile pickers count rounds of workgroups over the chip with it; correctness never depends on it (tiles
-// are strided over gridDim).  The blockIdx & 7 == XCD affinity of the sepup kernels is an MI355X speed assumption only.
-int kNumCUs = 256;
+// Compute units of a handle's device: 256 on MI355X (8 XCDs x 32 CUs), queried at pf_create and kept WITH THE HANDLE (pf_handle::num_cus;
+// a process-wide variable would follow whichever handle was created last).  Persistent kernels size their grids with it and the tile
+// pickers count rounds of workgroups over the chip with it; correctness never depends on it (tiles are strided over gridDim).  The
+// blockIdx & 7 == XCD affinity of the sepup kernels is an MI355X speed assumption only.
+constexpr int kDefaultCUs = 256;
 // workgroups per CU x CUs of the tile-walking kernels (k_det.h det_stem_kernel, k_front.h): the CPU emulator flavour caps the grid
 // at 5 workgroups so that its small test images still make every workgroup walk several tiles
 #ifdef PF_SIMT_EMULATION
-inline int persistent_grid(int tiles, int) { return std::min(tiles, 5); }
+inline int persistent_grid_n(int tiles, int, int) { return std::min(tiles, 5); }
 #else
-inline int persistent_grid(int tiles, int per_cu) { return std::min(tiles, per_cu * kNumCUs); }
+inline int persistent_grid_n(int tiles, int per_cu, int num_cus) { return std::min(tiles, per_cu * num_cus); }
 #endif
+#define persistent_grid(tiles, per_cu) persistent_grid_n((tiles), (per_cu), h->num_cus)      /* `h` is in scope at every launch site */
 
 struct Program {
     bool loaded = false;
@@ -75,6 +77,7 @@ struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
 
 struct pf_handle {
     int device = 0;
+    int num_cus = kDefaultCUs;      // compute units of `device`
     hipStream_t stream = nullptr;
     Program prog[PF_NET_SLOTS];
     std::string err;
@@ -171,7 +174,7 @@ struct ProfScope {
 // phases (~3 us of fixed latency = ~768 rows' worth of work), so fewer rounds of workgroups over the chip come first, then
 // the smaller tile; the halo rows every extra tile re-computes count with the chip's width.
 static int g_det_tile_th = 0, g_det_tile_tw = 0;     // ablation build only: PEPPA_DET_TILE=th,tw forces the tile wherever it fits (tile sweeps)
-static void det_pick_tile(int outH, int outW, int S, int max_rows, int B, int wg_per_cu, int* TH, int* TW) {
+static void det_pick_tile(int num_cus, int outH, int outW, int S, int max_rows, int B, int wg_per_cu, int* TH, int* TW) {
     double best = 1e30;
     *TH = 1; *TW = 1;
     if (PF_ABLATE != 0 && g_det_tile_th > 0 && ((g_det_tile_th - 1) * S + 3) * ((g_det_tile_tw - 1) * S + 3) <= max_rows) {
@@ -186,8 +189,8 @@ static void det_pick_tile(int outH, int outW, int S, int max_rows, int B, int wg
             const int rows = ((th - 1) * S + 3) * rw;
             if (rows > max_rows) break;
             const long long wgs = (long long)B * ((outH + th - 1) / th) * ((outW + tw - 1) / tw);
-            const long long rounds = (wgs + (long long)kNumCUs * wg_per_cu - 1) / ((long long)kNumCUs * wg_per_cu);
-            const double cost = (double)rounds * (768.0 + rows) + 0.5 * (double)wgs * rows / kNumCUs;
+            const long long rounds = (wgs + (long long)num_cus * wg_per_cu - 1) / ((long long)num_cus * wg_per_cu);
+            const double cost = (double)rounds * (768.0 + rows) + 0.5 * (double)wgs * rows / num_cus;
             if (cost < best) { best = cost; *TH = th; *TW = tw; }
         }
     }
@@ -267,8 +270,11 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
             grid = dim3(pf_div_up(M, 128), 1);
             const bool big = ((a.outH * a.outW) % 256) == 0 && !(host_dbg(h) & 1024);     // narrow variants: 256-pixel tiles
             if (big && a.Npad <= 64) grid = dim3(pf_div_up(M, 256), 1);
-            if (a.Npad == 128 && a.Cpad == 128 && a.outW == 64 && (host_dbg(h) & 16384)) PF_LAUNCH((conv3x3_hero_kernel<4, false>), grid, dim3(512), h->stream, a);   // A/B aid (ablation build)
-            else if (a.Npad == 128 && a.Cpad == 128 && a.outW == 64 && !(host_dbg(h) & 2048)) PF_LAUNCH((conv3x3_hero_kernel<4>), grid, dim3(512), h->stream, a);   // k_hero.h
+            // k_hero.h loads all 128 channels of every pixel as 16-byte vectors, unmasked: a 3x3 conv whose inC < Cpad == 128 would feed
+            // neighbouring bytes to the MFMAs and the range guard -- such a layer takes the masked halo kernel below
+            const bool hero = a.Npad == 128 && a.Cpad == 128 && a.inC == 128 && (a.inLd & 3) == 0 && a.outW == 64;
+            if (hero && (host_dbg(h) & 16384)) PF_LAUNCH((conv3x3_hero_kernel<4, false>), grid, dim3(512), h->stream, a);   // A/B aid (ablation build)
+            else if (hero && !(host_dbg(h) & 2048)) PF_LAUNCH((conv3x3_hero_kernel<4>), grid, dim3(512), h->stream, a);   // k_hero.h
             else if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
             else if (a.Npad == 64) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2>), grid, dim3(512), h->stream, a);
@@ -421,7 +427,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         }
                         const int tpf = to.H * to.W / 128, nskip = a.Cpad / 32 - tl.C / 32;
                         const int per_xcd = ((B + 7) / 8) * tpf;                  // tiles of the busiest XCD
-                        const int wgs = 8 * std::min(kNumCUs / 8, per_xcd);
+                        const int wgs = 8 * std::min(h->num_cus / 8, per_xcd);
                         const dim3 sg(B * tpf);
 #define PF_SEPUP_CASE(WW)                                                                                          \
     if (to.W == WW) {                                                                                              \
@@ -552,7 +558,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     ProfScope ps(h, tagbuf);
 #define PF_DETUNIT_CASE(CC, KK, SS, MAXR, NTHR, PERCU)                                                             \
     if (C == CC && K1 == KK && S == SS) {                                                                          \
-        det_pick_tile(to.H, to.W, SS, MAXR, B, PERCU, &a.TH, &a.TW);                                               \
+        det_pick_tile(h->num_cus, to.H, to.W, SS, MAXR, B, PERCU, &a.TH, &a.TW);                                               \
         a.tilesX = pf_div_up(to.W, a.TW); a.tpf = a.tilesX * pf_div_up(to.H, a.TH);                                 \
         PF_LAUNCH((det_unit_kernel<CC, KK, SS, MAXR, NTHR, PERCU * NTHR / 256>), dim3(a.tpf * B), dim3(NTHR), h->stream, a); \
     } else
@@ -706,7 +712,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     ProfScope ps(h, tagbuf);
 #define PF_DETC3_CASE(CC, TT, MAXR, NTHR)                                                                          \
     if (CIN == CC && tail == TT) {                                                                                 \
-        det_pick_tile(a.H, a.W, 1, MAXR, B, 1, &a.TH, &a.TW);                                                      \
+        det_pick_tile(h->num_cus, a.H, a.W, 1, MAXR, B, 1, &a.TH, &a.TW);                                                      \
         a.tilesX = pf_div_up(a.W, a.TW); a.tpf = a.tilesX * pf_div_up(a.H, a.TH);                                   \
         PF_LAUNCH((det_c3_kernel<CC, TT, MAXR, NTHR>), dim3(a.tpf * B), dim3(NTHR), h->stream, a); \
     } else
@@ -1080,12 +1086,12 @@ int pf_create(int device_id, pf_handle** out) {
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_create_error = "no HIP device visible (the engine has no CPU fallback)"; return 1; }
     if (device_id < 0 || device_id >= n) { g_create_error = "device id out of range"; return 1; }
     if (hipSetDevice(device_id) != hipSuccess) { g_create_error = "hipSetDevice failed"; return 1; }
-    {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus >= 8) kNumCUs = cus;
-    }
     pf_handle* h = new pf_handle();
     h->device = device_id;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus >= 8) h->num_cus = cus;
+    }
     if constexpr (PF_ABLATE != 0) {      // ablation build only (libpeppa_hip_ablate.so): ablated kernels compute garbage, so the guard is off
         if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) h->range_every = 0; }
         if (const char* v = getenv("PEPPA_DET_TILE")) { if (sscanf(v, "%d,%d", &g_det_tile_th, &g_det_tile_tw) != 2) g_det_tile_th = g_det_tile_tw = 0; }
@@ -1097,8 +1103,8 @@ int pf_create(int device_id, pf_handle** out) {
         if (const char* v = getenv("PEPPA_CU_PARTITION")) (void)sscanf(v, "%d,%d", &parts, &mode);
         if (parts > 1) {
             uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const int lane = s_lane++ % parts, per = kNumCUs / parts;
-            for (int c = 0; c < kNumCUs; ++c)
+            const int lane = s_lane++ % parts, per = h->num_cus / parts;
+            for (int c = 0; c < h->num_cus; ++c)
                 if ((mode == 1 && c % parts == lane) || (mode == 2 && c / per == lane) || (mode == 3 && (c / 8) % parts == lane)) mask[c >> 5] |= 1u << (c & 31);
             masked = hipExtStreamCreateWithCUMask(&h->stream, 8, mask) == hipSuccess;
             fprintf(stderr, "[peppa-hip] handle %d: CU partition %d/%d mode %d: %s\n", s_lane - 1, lane, parts, mode, masked ? "ok" : "FAILED");

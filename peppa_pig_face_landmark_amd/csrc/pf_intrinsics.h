@@ -90,6 +90,9 @@ template <int OFF> __device__ __forceinline__ void pf_glds16_raw_soff(const void
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(base), "n"(OFF) : "memory");
 }
 
+#ifndef PF_STRICT_WAITS
+#define PF_STRICT_WAITS 0
+#endif
 // Workgroup barrier that leaves the wave's N youngest VMEM operations (LDS-DMA requests, global loads) in flight:
 // "s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier".  __syncthreads() drains vmcnt to 0, which ends every software-pipeline
 // stage with a full global-memory latency; LDS-DMA stays in flight across s_barrier (MI355X_MICROARCH.md).
@@ -98,7 +101,9 @@ template <int N> __device__ __forceinline__ void pf_wait_vm_barrier() {
     // no fence builtins here: a workgroup-scope release fence is lowered to s_waitcnt vmcnt(0) whenever LDS-DMA is
     // pending, which is exactly the drain this barrier exists to avoid; the memory clobber keeps the compiler from moving
     // LDS / global accesses across it, lgkmcnt(0) retires this wave's own LDS writes before the rendezvous
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(N) : "memory");
+    // PF_STRICT_WAITS (test flavour libpeppa_hip_strict.so, build.py): every partial wait drains completely, so the rings lose their
+    // look-ahead but cannot read a stage early -- tests/test_gpu_race_net.py requires production == strict, bit for bit
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(PF_STRICT_WAITS ? 0 : N) : "memory");
 }
 
 // Nothing is scheduled across this point (machine scheduler only): the steps of a completely unrolled K loop are one basic block,

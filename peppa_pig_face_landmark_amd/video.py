@@ -93,12 +93,14 @@ def parse_mjpeg_avi(data: bytes) -> Tuple[dict, List[Tuple[int, int]]]:
         raise ValueError("not a RIFF AVI file")
     info = {"width": 0, "height": 0, "fps": 0.0, "frames": 0, "fourcc": ""}
     frames: List[Tuple[int, int]] = []
+    vid_id = [b"00"]          # chunk-id prefix of the first 'vids' stream: its position among the header's strl lists ("01dc" when audio comes first)
+    n_strl = 0
 
     def walk_movi(start, end):
         for cid, off, size in _chunks(buf, start, end):
             if cid == b"LIST" and bytes(buf[off:off + 4]) == b"rec ":
                 walk_movi(off + 4, off + size)
-            elif cid[2:4] in (b"dc", b"db") and cid[0:2] == b"00" and size > 0:
+            elif cid[2:4] in (b"dc", b"db") and cid[0:2] == vid_id[0] and size > 0:
                 frames.append((off, size))
 
     for cid, off, size in _chunks(buf, 12, len(data)):
@@ -112,11 +114,16 @@ def parse_mjpeg_avi(data: bytes) -> Tuple[dict, List[Tuple[int, int]]]:
                     total, = struct.unpack("<I", buf[o2 + 16:o2 + 20])
                     w, h = struct.unpack("<II", buf[o2 + 32:o2 + 40])
                     info.update(width=int(w), height=int(h), frames=int(total), fps=(1e6 / usec if usec else 0.0))
-                elif c2 == b"LIST" and bytes(buf[o2:o2 + 4]) == b"strl" and not info["fourcc"]:
+                elif c2 == b"LIST" and bytes(buf[o2:o2 + 4]) == b"strl":
+                    stream_no, n_strl = n_strl, n_strl + 1
+                    if info["fourcc"]:
+                        continue                      # a video stream has been found already
                     is_video = False
                     for c3, o3, s3 in _chunks(buf, o2 + 4, o2 + s2):
                         if c3 == b"strh" and s3 >= 8:
                             is_video = bytes(buf[o3:o3 + 4]) == b"vids"
+                            if is_video:
+                                vid_id[0] = b"%02d" % stream_no
                         elif c3 == b"strf" and is_video and s3 >= 20:
                             info["fourcc"] = bytes(buf[o3 + 16:o3 + 20]).decode("latin1")
         elif kind == b"movi":
@@ -143,6 +150,7 @@ class MJPEGCapture:
         self._frames: List[Tuple[int, int]] = []
         self.info = {}
         self._pos = 0
+        self.error = ""
         try:
             data = bytes(path_or_bytes) if isinstance(path_or_bytes, (bytes, bytearray, memoryview)) else open(path_or_bytes, "rb").read()
             self.info, self._frames = parse_mjpeg_avi(data)
@@ -163,13 +171,20 @@ class MJPEGCapture:
         return complete_mjpeg_frame(self._data[off:off + size])
 
     def read(self):
+        """``(ok, frame)`` like ``cv2.VideoCapture.read``: a truncated or corrupt frame is ``(False, None)`` with the reason in
+        ``self.error`` -- never an exception -- and the stream position moves past it."""
         if self._pos >= len(self._frames):
             return False, None
-        jpeg = self.frame_bytes(self._pos)
+        i = self._pos
         self._pos += 1
-        if self.engine is None:
-            return True, jpeg               # no engine: the self-contained JPEG bytes (FaceAna.imread takes them)
-        return True, self.engine.imread(jpeg, self.want_host)
+        try:
+            jpeg = self.frame_bytes(i)
+            if self.engine is None:
+                return True, jpeg           # no engine: the self-contained JPEG bytes (FaceAna.imread takes them)
+            return True, self.engine.imread(jpeg, self.want_host)
+        except (ValueError, _native.PeppaHipError) as e:
+            self.error = "frame %d: %s" % (i, e)
+            return False, None
 
     def read_batch(self, n: int, threads: int = 4):
         """Up to n frames, decoded into device memory by ONE pf_decode_jpeg_batch call: (device pointer [k][H][W][3] BGR, k, H, W),
@@ -179,12 +194,17 @@ class MJPEGCapture:
         k = min(n, len(self._frames) - self._pos)
         if k <= 0:
             return None
-        files = [self.frame_bytes(self._pos + i) for i in range(k)]
+        first = self._pos
         self._pos += k
-        return self.engine.decode_jpeg_batch(files, threads)
+        try:
+            files = [self.frame_bytes(first + i) for i in range(k)]
+            return self.engine.decode_jpeg_batch(files, threads)
+        except (ValueError, _native.PeppaHipError) as e:       # one bad frame spoils the batch: report it like the end of the stream
+            self.error = "frames %d..%d: %s" % (first, first + k - 1, e)
+            return None
 
     def release(self):
-        self._data, self._frames = b"", []
+        self._data, self._frames, self._pos = b"", [], 0
 
 
 def write_mjpeg_avi(jpegs: List[bytes], width: int, height: int, fps: float = 25.0) -> bytes:

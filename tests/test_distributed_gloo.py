@@ -79,6 +79,30 @@ def test_bench_self_spawns_n_ranks_dry_run():
     assert out["frames_per_rank"] == [7, 7] and out["max_over_ranks_check"] == 2.0
 
 
+def test_bench_world8_dry_run_launched_like_the_driver():
+    """The node shape the driver measures: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...`, eight ranks, 96 frames each (frame f of the job -> rank f mod 8), one JSON line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--dry-run-cpu", "--frames", "96",
+           "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=420, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_run"] is True and out["value"] is None and out["scaling"] == "weak"
+    assert out["frames_per_rank"] == [96] * 8 and out["max_over_ranks_check"] == 8.0
+    shards = [bs.shard_frames(96 * 8, rk, 8) for rk in range(8)]
+    assert sorted(f for sh in shards for f in sh) == list(range(768)) and all(len(sh) == 96 for sh in shards)
+    assert all(f % 8 == rk for rk, sh in enumerate(shards) for f in sh)
+
+
 def test_bench_refuses_more_gpus_than_visible():
     """--gpus N on a node with fewer GPUs fails loudly (non-zero exit, no JSON line) instead of printing a 1-GPU line."""
     import torch

@@ -112,6 +112,56 @@ def test_imread_falls_back_to_the_host_for_what_the_device_decoder_refuses(emu_e
     assert FaceAna.imread(fa, str(tmp_path / "nope.jpg")) is None
 
 
+def test_corrupt_frames_and_second_stream_videos_behave_like_cv2(emu_engine):
+    """cv2.VideoCapture.read() answers (False, None) for a frame it cannot decode -- it does not raise -- and reads the video
+    stream wherever it sits among the file's streams (round-4 advisor: '00dc' was hard-coded)."""
+    h, w = 32, 48
+    jpegs = [_jpeg(_photo(h, w, s), quality=85) for s in range(3)]
+    broken = [jpegs[0], jpegs[1][:len(jpegs[1]) // 3], b"\x00\x01garbage" * 4]       # truncated scan, no SOI at all
+    cap = video.MJPEGCapture(video.write_mjpeg_avi(broken, w, h), engine=emu_engine)
+    assert cap.isOpened()
+    ok0, f0 = cap.read()
+    assert ok0 and f0.shape == (h, w, 3)
+    for i in (1, 2):
+        ok, frame = cap.read()
+        assert (ok, frame) == (False, None) and ("frame %d" % i) in cap.error
+    assert cap.get(cap.CAP_PROP_POS_FRAMES) == 3 and cap.read() == (False, None)
+    cap2 = video.MJPEGCapture(video.write_mjpeg_avi(broken, w, h), engine=emu_engine)
+    assert cap2.read_batch(8) is None and "frames 0..2" in cap2.error
+    cap2.release()
+    assert cap2.get(cap2.CAP_PROP_POS_FRAMES) == 0 and not cap2.isOpened()
+    # the video as stream 01 behind an audio stream: frames are '01dc' chunks
+    avi = video.write_mjpeg_avi(jpegs, w, h)
+    strl_at = avi.index(b"strl") - 8
+    strl_len = 8 + int.from_bytes(avi[strl_at + 4:strl_at + 8], "little")
+    audio = bytearray(avi[strl_at:strl_at + strl_len])
+    audio[audio.index(b"vids"):audio.index(b"vids") + 4] = b"auds"
+    two = bytearray(avi[:strl_at] + bytes(audio) + avi[strl_at:])
+    hdrl_at = two.index(b"hdrl") - 8
+    for at in (4, hdrl_at + 4):                                                       # RIFF and hdrl LIST sizes grow by the new strl
+        two[at:at + 4] = (int.from_bytes(two[at:at + 4], "little") + strl_len).to_bytes(4, "little")
+    two = bytes(two).replace(b"00dc", b"01dc")
+    cap3 = video.MJPEGCapture(two, engine=emu_engine)
+    assert cap3.isOpened() and cap3.get(cap3.CAP_PROP_FRAME_COUNT) == 3
+    ok, frame = cap3.read()
+    assert ok and np.array_equal(frame.numpy(), np.asarray(Image.open(io.BytesIO(jpegs[0])).convert("RGB"))[:, :, ::-1])
+
+
+def test_host_imread_applies_exif_orientation_like_cv2(emu_engine):
+    """cv2.imread rotates by the EXIF orientation tag; the Pillow fallback has to do the same or rotated progressive files give other boxes."""
+    fa = types.SimpleNamespace(engine=emu_engine)
+    rgb = _photo(24, 40, 3)
+    buf = io.BytesIO()
+    exif = Image.Exif()
+    exif[0x0112] = 6                      # rotate 90 degrees clockwise to display
+    Image.fromarray(rgb).save(buf, format="JPEG", quality=92, progressive=True, exif=exif)
+    got = FaceAna.imread(fa, buf.getvalue())
+    assert isinstance(got, np.ndarray) and got.shape == (40, 24, 3)
+    from PIL import ImageOps
+    want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(buf.getvalue()))).convert("RGB"))[:, :, ::-1]
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.gpu
 def test_mjpeg_avi_through_faceana_on_the_gpu(hip_library, student_weights, detector_weights):
     """demo.py:13-17 with the engine's ingest: every frame of a Motion-JPEG AVI decoded on the GPU (read() and read_batch()) is
