@@ -100,6 +100,12 @@ def tag_flops_per_face(tag: str):
     if m:
         c, n, h, w = map(int, m.groups())
         return 2.0 * h * w * c * (n + 9)
+    m = re.fullmatch(r"mbx([AB]?)(\d)x\dd\d_c(\d+)_m(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # whole inverted-residual block (csrc/k_mbx.h)
+    if m:
+        mode, (k, c, mid, n, h, w) = m.group(1), map(int, m.groups()[1:])
+        # algorithmic work of the launch: expand + depthwise (pass A and, recomputed, pass B count once each: what the launch does
+        # for the block's result is expand + depthwise + projection; the squeeze pass is priced as expand + depthwise)
+        return 2.0 * h * w * mid * (c + k * k + (0 if mode == "A" else n))
     m = re.fullmatch(r"expdw(\d)x\d[ds]\d_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # expand C -> N + depthwise KxK on N
     if m:
         k, c, n, h, w = map(int, m.groups())
@@ -109,7 +115,7 @@ def tag_flops_per_face(tag: str):
 
 KERNEL_OF_TAG_F32S = (   # profile tag prefix -> the HIP kernel that runs it in an f32s program (csrc/engine.cpp dispatch)
     ("conv3x3_c128_n128_64x64", "conv3x3_hero_kernel<4>"), ("block_c", "basic_block_kernel"), ("chain", "basic_chain_kernel"),
-    ("sepup_", "sepup_skip_kernel + sepup_pipe_kernel (sepup_patch_kernel fallback)"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
+    ("sepup_", "sepup_skip_kernel + sepup_pipe_kernel (sepup_patch_kernel fallback)"), ("mbx", "mbx_kernel"), ("expdw", "conv_gemm_split_kernel<..EPI_K> / expdw_image_kernel"), ("conv3x3_c64_n64_64x64", "conv3x3_halo_split_kernel<64,4,2,256>"),
     ("conv", "conv_gemm_split_kernel"))
 
 
@@ -272,7 +278,9 @@ def hbm_ops_table(prof, steps, frames_per_launch, faces_per_launch, frame_hw, fa
 
 def dense_kernel_table(prof, steps, faces_per_launch, dtype, pmc_traffic=None):
     out = {}
-    for tag, flop in DENSE_FLOP_PER_FACE.items():
+    table = dict(DENSE_FLOP_PER_FACE)
+    table.update({t: tag_flops_per_face(t) for t in prof if t.startswith("mbx")})     # the block kernels name their own shapes
+    for tag, flop in table.items():
         if tag not in prof or prof[tag][1] == 0:
             continue
         ms = prof[tag][0] / steps

@@ -23,6 +23,7 @@
 #include "k_hrb.h"
 #include "k_hero.h"
 #include "k_sepup.h"
+#include "k_mbx.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
 #include "k_track.h"
@@ -842,6 +843,51 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     else if (K == 5 && dil == 1) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 1>), grid, dim3(512), h->stream, a);
                     else if (K == 5 && dil == 2) PF_LAUNCH((conv_gemm_split_kernel<256, 64, 8, 1, 1, 0, 5, 2>), grid, dim3(512), h->stream, a);
                     else PF_FAIL(h, "expdw: no kernel for k%d dil %d", K, dil);
+                }
+                break;
+            }
+            case PF_OP_MBX: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused inverted-residual op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& ti = p.tens[f[0]];
+                    MbxArgs a{};
+                    a.in = (const float*)p.tensor_ptr(f[0]);
+                    a.out = f[1] >= 0 ? (float*)p.tensor_ptr(f[1]) : nullptr;
+                    a.res = f[2] >= 0 ? (const float*)p.tensor_ptr(f[2]) : nullptr;
+                    a.gap_out = f[3] >= 0 ? (float*)p.buf_ptr(f[3]) : nullptr;
+                    a.gate = f[4] >= 0 ? (const float*)p.buf_ptr(f[4]) : nullptr;
+                    a.w1 = (const unsigned char*)p.cptr(f[5]); a.ctile = (const float*)p.cptr(f[6]);
+                    a.w2 = (const unsigned char*)p.cptr(f[7]); a.b2 = (const float*)p.cptr(f[8]);
+                    const int K = f[9], pad = f[10], dil = f[11], KS = f[13], Cout = f[15], mode = f[19];
+                    a.act = f[12]; a.T = f[14]; a.CEXP = f[16];
+                    memcpy(&a.scale1, &f[17], 4); memcpy(&a.scale2, &f[18], 4);
+                    a.B = B; a.inC = ti.C; a.inLd = ti.ld;
+                    a.outLd = f[1] >= 0 ? p.tens[f[1]].ld : 0; a.resLd = f[2] >= 0 ? p.tens[f[2]].ld : 0;
+                    a.range_slot = slot_of(oi);
+                    if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 2 ||
+                        (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T ||
+                        (mode != 1 && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||
+                        (mode == 1 && !a.gap_out) || (mode == 2 && !a.gate))
+                        PF_FAIL(h, "mbx: unsupported shape (%dx%dx%d, k%d pad %d dil %d, mode %d)", ti.H, ti.W, ti.C, K, pad, dil, mode);
+                    char tagbuf[96];
+                    tagbuf[0] = 0;
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbx%s%dx%dd%d_c%d_m%d_n%d_16x16", mode == 0 ? "" : (mode == 1 ? "A" : "B"), K, K, dil, ti.C, a.CEXP, mode == 1 ? 0 : Cout);
+                    ProfScope ps(h, tagbuf);
+                    const dim3 grid(persistent_grid(B, 1));      // one workgroup per CU, faces strided over the grid
+                    bool launched = false;
+#define PF_MBX_CASE(KS_, NTO_, K_, DIL_, MODE_)                                                                     \
+    if (!launched && KS == KS_ && K == K_ && dil == DIL_ && mode == MODE_ && (MODE_ == 1 || Cout == 16 * NTO_)) {   \
+        PF_LAUNCH((mbx_kernel<KS_, NTO_, K_, DIL_, MODE_>), grid, dim3(512), h->stream, a);                         \
+        launched = true;                                                                                            \
+    }
+                    PF_MBX_CASE(3, 5, 3, 1, 0)                                    // blocks 3.1 - 3.3: 80 -> 200 / 184 -> 80
+                    PF_MBX_CASE(3, 7, 3, 1, 1) PF_MBX_CASE(3, 7, 3, 1, 2)         // block 4.0: 80 -> 480 -> 112
+                    PF_MBX_CASE(4, 7, 3, 1, 1) PF_MBX_CASE(4, 7, 3, 1, 2)         // block 4.1: 112 -> 672 -> 112
+                    PF_MBX_CASE(4, 10, 5, 1, 1) PF_MBX_CASE(4, 10, 5, 1, 2)       // block 5.0: 112 -> 672 -> 160, 5 x 5
+                    PF_MBX_CASE(5, 10, 5, 2, 1) PF_MBX_CASE(5, 10, 5, 2, 2)       // blocks 5.1 / 5.2: 160 -> 960 -> 160, 5 x 5 dilated
+#undef PF_MBX_CASE
+                    if (!launched) PF_FAIL(h, "mbx: no kernel for KS %d Cout %d k%d dil %d mode %d", KS, Cout, K, dil, mode);
                 }
                 break;
             }

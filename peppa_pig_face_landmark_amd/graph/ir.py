@@ -25,6 +25,7 @@ ELEM_ACT, ELEM_F32, ELEM_I32, ELEM_U8 = 0, 1, 2, 3
 ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5}
 
 OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT, OP_HRB, OP_FUSEUP = range(1, 24)
+OP_MBX = 24
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -561,6 +562,61 @@ class ProgramBuilder:
                             ACT[act], cpad, npad, mid, struct.unpack("<i", struct.pack("<f", acc_scale))[0], stride],
                  [self._tb(x)], [self._tb(out), gap])
         return out, gap
+
+    # (Cin padded / 32, Cout / 16, k, dilation, has SE) with an mbx_kernel instantiation (csrc/k_mbx.h, engine.cpp PF_OP_MBX)
+    MBX_KERNELS = {(3, 5, 3, 1, False), (3, 7, 3, 1, True), (4, 7, 3, 1, True), (4, 10, 5, 1, True), (5, 10, 5, 2, True)}
+
+    def mbx_supported(self, x: int, k: int, stride: int, pad: int, dil: int, cout: int, se: bool) -> bool:
+        """A whole inverted-residual block at 16 x 16 in the input-stationary kernel (csrc/k_mbx.h): f32s programs, stride 1."""
+        ti = self.tensors[x]
+        return (self.split and (ti.H, ti.W) == (16, 16) and stride == 1 and pad == dil * (k - 1) // 2 and ti.C == ti.real_c
+                and ti.C % 4 == 0 and cout % 16 == 0 and (_round_up(ti.C, 32) // 32, cout // 16, k, dil, bool(se)) in self.MBX_KERNELS)
+
+    def _mbx_pack(self, w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl):
+        """(w1 off, ctile off, w2 off, b2 off, KS, T, scale1, scale2): expand rows in tiles of 32 expanded channels (zero rows up
+        to a whole tile), per-tile constants [T][k*k + 2][32] = depthwise taps | expand bias | depthwise bias, projection rows
+        [Cout][T][hi 32 | lo 32]."""
+        mid, cin = w_exp.shape[:2]
+        cout, k = w_pwl.shape[0], w_dw.shape[2]
+        T, cp = _round_up(mid, 32) // 32, _round_up(cin, 32)
+        we = np.zeros((T * 32, cp)); we[:mid, :cin] = w_exp.reshape(mid, cin)
+        wp = np.zeros((cout, T * 32)); wp[:, :mid] = w_pwl.reshape(cout, mid)
+        ct = np.zeros((T, k * k + 2, 32))
+        taps = np.zeros((k * k, T * 32)); taps[:, :mid] = w_dw.reshape(mid, k * k).T
+        be = np.zeros(T * 32); be[:mid] = b_exp
+        bd = np.zeros(T * 32); bd[:mid] = b_dw
+        ct[:, :k * k, :] = taps.reshape(k * k, T, 32).transpose(1, 0, 2)
+        ct[:, k * k, :] = be.reshape(T, 32)
+        ct[:, k * k + 1, :] = bd.reshape(T, 32)
+        we_s, s1 = self._split_rows(we)
+        wp_s, s2 = self._split_rows(wp)
+        return self.const(we_s), self.const_f32(ct), self.const(wp_s), self.const_f32(b_pwl), cp // 32, T, s1, s2
+
+    def mbx(self, x: int, w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl, act: str, *, pad: int, dil: int = 1, res: int = -1,
+            se_fcs=None, out_name: str = "") -> int:
+        """Inverted-residual block (expand 1x1 -> depthwise kxk -> [SE] -> project 1x1 [+ res]) on a 16 x 16 map, weights BN-folded.
+        Without SE: one launch.  With SE (``se_fcs`` = (w_reduce [R,Mid], b_reduce, w_expand [Mid,R], b_expand)): the squeeze pass
+        (expand + depthwise -> per-face channel means), the two FCs, then the pass that recomputes expand + depthwise, applies the
+        gate and projects -- the expanded tensor never exists in HBM."""
+        ti = self.tensors[x]
+        mid, cin = w_exp.shape[:2]
+        cout, k = w_pwl.shape[0], w_dw.shape[2]
+        assert cin == ti.real_c == ti.C and w_dw.shape == (mid, 1, k, k) and w_pwl.shape[1] == mid
+        assert self.mbx_supported(x, k, 1, pad, dil, cout, se_fcs is not None)
+        w1, ct, w2, b2, ks, T, s1, s2 = self._mbx_pack(w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        out = self.tensor(ti.H, ti.W, cout, name=out_name)
+        common = [w1, ct, w2, b2, k, pad, dil, ACT[act], ks, T, cout, mid, fbits(s1), fbits(s2)]
+        if se_fcs is None:
+            self._op(OP_MBX, [x, out, res, -1, -1] + common + [0], [self._tb(x), self._tb(res)], [self._tb(out)])
+            return out
+        w_rd, b_rd, w_ex, b_ex = se_fcs
+        gap = self.buffer(mid, ELEM_F32, "gap")
+        self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1], [self._tb(x)], [gap])
+        hid = self.fc(gap, w_rd, b_rd, "relu")
+        gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
+        self._op(OP_MBX, [x, out, res, -1, gate] + common + [2], [self._tb(x), self._tb(res), gate], [self._tb(out)])
+        return out
 
     CHAIN_SHAPES = ((72, 16), (144, 8))       # (channels, map side) with a basic_chain_kernel instantiation
     CHAIN_MAX_CONVS = 8

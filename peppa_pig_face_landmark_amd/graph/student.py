@@ -120,10 +120,13 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 
 
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
-                          keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True, fuse_front: bool = False):
+                          keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True, fuse_front: bool = False,
+                          fuse_mbx: Optional[bool] = None):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
+    if fuse_mbx is None:       # the input-stationary block kernels of stages 3-5 (16 x 16 maps at 256 x 256; csrc/k_mbx.h): on with the other fusions
+        fuse_mbx = fuse_mbconv
     w = weights
     pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
 
@@ -170,6 +173,18 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 x = pb.dw(x, wt, b, act, stride=s, pad=pad, dil=cur_dil, out_name=f"{p}.dw")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
+            elif fuse_mbx and kind == "ir" and pb.mbx_supported(x, k, s, pad, cur_dil, cout, se):
+                # stages 3-5 at 16 x 16: the whole block with the face's input stationary in registers (csrc/k_mbx.h); an SE block is
+                # squeeze pass -> two FCs -> recompute + gate + project, the expanded tensor never in HBM
+                we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
+                wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
+                wl, bl = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
+                fcs = None
+                if se:
+                    rd, ex = w[f"{p}.se.conv_reduce.weight"], w[f"{p}.se.conv_expand.weight"]
+                    fcs = (rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"],
+                           ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"])
+                x = pb.mbx(x, we, be, wd, bd, wl, bl, act, pad=pad, dil=cur_dil, res=inp if skip else -1, se_fcs=fcs, out_name=f"{p}.out")
             elif (fuse_mbconv and not se and pb.mbconv_supported(cin, k, s, cur_dil, cout)
                   and not pb.expdw_supported(pb.tensors[x].H, pb.tensors[x].W, k, s, pad, cur_dil)):
                 we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))

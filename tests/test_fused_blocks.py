@@ -75,3 +75,52 @@ def test_fused_blocks_match_unfused_emu(emu_engine, student_weights, size, batch
 @pytest.mark.parametrize("size,batch", [(128, 3), (256, 5)])
 def test_fused_blocks_match_unfused_gpu(gpu_engine, student_weights, size, batch):
     _check(gpu_engine, student_weights, size, batch)
+
+
+def _mbx_vs_layerwise(eng, weights, batch, keep_all):
+    """Stages 3-5 at 16 x 16 through the input-stationary block kernel (csrc/k_mbx.h, PF_OP_MBX: non-SE blocks in one launch, SE
+    blocks as squeeze pass + FCs + recompute-and-project pass) against the same program with those blocks as expand + depthwise
+    launch -> gated projection (fuse_mbx=False): the non-SE blocks bit for bit (same products in the same order), the SE blocks to
+    f32 rounding (their channel means are summed in another order)."""
+    crops = sw.smooth_blob_images(batch, 256, seed=5100 + batch)
+    res = {}
+    for mbx in (False, True):
+        blob, info = build_student_program(weights, 256, "f32s", keep_all=keep_all, fuse_mbx=mbx)
+        codes = _op_codes(blob)
+        assert (ir.OP_MBX in codes) == mbx and codes.count(ir.OP_MBX) == (13 if mbx else 0)
+        eng.load_program(0, blob, batch)
+        loc, score = eng.landmark_forward(crops)
+        blocks = {}
+        if keep_all:
+            for name in info["tensors"]:
+                if name.startswith("encoder.blocks.") and name.endswith(".out") and name.split(".")[2] in "345":
+                    c = {"3": 80, "4": 112, "5": 160}[name.split(".")[2]]
+                    blocks[name] = helpers.read_engine_tensor(eng, 0, info, name, batch, (16, 16, c), 4)
+        res[mbx] = (loc, score, blocks)
+    for name, ref in res[False][2].items():
+        got = res[True][2][name]
+        if name.split(".")[2] == "3":
+            assert np.array_equal(got, ref), (name, float(np.abs(got - ref).max()))
+        else:
+            rel = np.abs(got - ref).max() / np.abs(ref).max()
+            assert rel < 2e-5, (name, rel)
+    if keep_all:
+        assert len(res[True][2]) == 9
+    oloc, oscore, taps = helpers.oracle_student(weights, crops[:min(batch, 8)])
+    n = oloc.shape[0]
+    safe = helpers.heat_margins(taps) > 1e-3
+    d = np.abs(res[True][0][:n] - oloc).reshape(n, 98, 2).max(2)
+    assert d[safe].max() < 2e-4
+    d = np.abs(res[True][0] - res[False][0]).reshape(batch, 98, 2).max(2)
+    assert np.quantile(d, 0.99) < 1e-4                   # (a near-tie arg-max may flip on a last-bit difference: not the kernels' business here)
+    assert np.isfinite(res[True][1]).all()
+
+
+def test_mbx_blocks_match_layerwise_emu(emu_engine, student_weights):
+    _mbx_vs_layerwise(emu_engine, student_weights, 7, True)      # 7 faces on the emulator's 5 workgroups: the face loop runs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,keep_all", [(5, True), (300, False)])
+def test_mbx_blocks_match_layerwise_gpu(gpu_engine, student_weights, batch, keep_all):
+    _mbx_vs_layerwise(gpu_engine, student_weights, batch, keep_all)   # 300 faces on 256 CUs: some workgroups walk two faces
