@@ -865,6 +865,12 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.B = B; a.inC = ti.C; a.inLd = ti.ld;
                     a.outLd = f[1] >= 0 ? p.tens[f[1]].ld : 0; a.resLd = f[2] >= 0 ? p.tens[f[2]].ld : 0;
                     a.range_slot = slot_of(oi);
+                    a.dbg = h->dbg;
+                    if (host_dbg(h) & 64) {      // per-wave cycle accounting (ablation build; printed at pf_destroy)
+                        if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
+                        const int shape = KS == 3 ? 0 : (KS == 4 ? (K == 3 ? 1 : 2) : 3);
+                        a.prof = h->d_dbg + 160 + 8 * (shape * 3 + mode);
+                    }
                     if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 2 ||
                         (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T ||
                         (mode != 1 && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||
@@ -1201,6 +1207,16 @@ void pf_destroy(pf_handle* h) {
                 if (hb[4 * k + 3])
                     fprintf(stderr, "[det_hr_bottleneck CIN=%d] per workgroup (cycles): conv1 %.0f | conv2 %.0f | conv3+store %.0f  (%.0f workgroups)\n", k ? 256 : 64,
                             hb[4 * k] / (double)hb[4 * k + 3], hb[4 * k + 1] / (double)hb[4 * k + 3], hb[4 * k + 2] / (double)hb[4 * k + 3], (double)hb[4 * k + 3]);
+        unsigned long long mb[96];
+        if (hipMemcpy(mb, h->d_dbg + 160, sizeof(mb), hipMemcpyDeviceToHost) == hipSuccess)
+            for (int k = 0; k < 12; ++k) {
+                const unsigned long long* q = mb + 8 * k;
+                if (!q[7]) continue;
+                static const char* shp[4] = {"KS3 k3", "KS4 k3", "KS4 k5", "KS5 k5d2"};
+                const double n = (double)q[7];
+                fprintf(stderr, "[det_mbx %s mode %d] per wave and launch-face (cycles): prologue+expand0 %.0f | matrix jobs %.0f | wait a %.0f | taps %.0f | finish %.0f | wait b %.0f | epilogue %.0f  (%.0f waves)\n",
+                        shp[k / 3], k % 3, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, n);
+            }
         unsigned long long w9[9];
         if (hipMemcpy(w9, h->d_dbg + 128, sizeof(w9), hipMemcpyDeviceToHost) == hipSuccess && w9[8]) {
             const double n = (double)w9[8];

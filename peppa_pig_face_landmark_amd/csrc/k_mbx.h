@@ -10,22 +10,26 @@
 //
 // Here the face's INPUT is the stationary operand: 8 waves, wave w owns image rows 2w and 2w + 1 (two 16-pixel MFMA tiles) and keeps
 // their pixel fragments of ALL input channels in registers as split f16 hi / lo (KS k-steps x 2 tiles x 8 VGPRs), loaded once per face.
-// The expanded channels are walked 32 at a time ("tiles"); per tile
-//   phase 1   expand: E = act(W1[tile] . x + b1) on the matrix cores (3 x v_mfma_f32_16x16x32_f16 per product, f32 accumulate), the
-//             32 x (KS x 32) pre-split weight rows from a 20 KB LDS stage (LDS-DMA), E -> LDS as f32 [256 px][36];
-//   barrier
-//   phase 2   depthwise k x k (dilation DIL, zero padding) on E out of LDS, thread = (channel pair, image row, half row), f32 fma in
-//             the order of the unfused kernel; + bias, activation; then
-//               MODE 1 (squeeze pass of an SE block): per-thread sums -> LDS -> per-face channel means (the SE squeeze), nothing else;
-//               MODE 0 / 2: (x SE gate) -> split hi / lo -> pixel-operand planes D[tile & 1] in LDS;
-//             and, side by side with it, project(tile - 1): out += W2[:, tile - 1] . D[(tile - 1) & 1] on the matrix cores, the
-//             accumulators (2 tiles x NTO x 4 VGPRs) living in registers for the whole face.  Waves 0-3 run project first and the
-//             depthwise second, waves 4-7 the other way round: waves w and w + 4 share a SIMD, so its matrix pipe and its VALU are
-//             busy at the same time without any instruction-level interleaving;
-//   barrier
+// The expanded channels are walked 32 at a time ("tiles"), two barrier-separated phases per tile, each pairing a matrix-core job with
+// a VALU job that does not depend on it:
+//   phase a(t)  project(t - 1): out += W2[:, t - 1] . D on the matrix cores, the accumulators (2 tiles x NTO x 4 VGPRs) living in
+//               registers for the whole face
+//             | depthwise taps of tile t on E out of LDS: thread = (channel pair, image row, half row), k x k x 16 f32 fma in the
+//               order of the unfused kernel (v_fmac_f32 from inline asm: hipcc packs them into v_pk_fma_f32 otherwise, which
+//               measured ~4x slower per flop here), results stay in 16 registers;
+//   phase b(t)  expand(t + 1): E = act(W1[t + 1] . x + b1) (3 x v_mfma_f32_16x16x32_f16 per product, f32 accumulate; the 32 x (KS x 32)
+//               pre-split weight rows from a 20 KB LDS stage) -> LDS as f32 [256 px][36]
+//             | finish tile t: + activation, then MODE 1 (squeeze pass of an SE block): per-thread sums -> LDS -> per-face channel
+//               means, nothing else; MODE 0 / 2: (x SE gate) -> split hi / lo -> the pixel-operand planes D in LDS.
+// Waves 0-3 run the matrix job first and the VALU job second, waves 4-7 the other way round: waves w and w + 4 share a SIMD, so its
+// matrix pipe and its VALU are busy at the same time without instruction-level interleaving.  E and D are single buffers: E is
+// read in phase a and rewritten in phase b, D is written in phase b and read in the next phase a.
 // Everything that comes from memory inside the loop arrives by LDS-DMA issued at the START of a phase for the NEXT phase that reads
-// it (W1 / taps / biases / gate of tile + 1 during phase 2, W2 of tile - 1 during phase 1), so every barrier is a plain
-// "vmcnt(0) + s_barrier": no hand-counted partial waits in this kernel, and a phase (>= 2 k cycles) hides the DMA's ~400.
+// it (W1 / taps / biases / gate of tile t + 1 during phase a(t), W2 of tile t during phase b(t)), so every barrier is a plain
+// "vmcnt(0) + s_barrier": no hand-counted partial waits in this kernel.
+// First cut (round 5, profiles/r05_run3_mbx_phase_cycles_first_cut.txt): expand | barrier | depthwise + project | barrier with the
+// residual added in the epilogue ran 0.278 ms per 256 faces for a 160 -> 960 -> 160 block (the two launches it replaced: 0.254):
+// v_pk_fma_f32 taps, a 52 us epilogue of twenty dependent residual round trips, twenty dependent input round trips in the prologue.
 // An SE block is TWO launches around its two small FC launches: MODE 1 (expand + depthwise -> means only), then MODE 2, which
 // RECOMPUTES expand + depthwise (the input is in registers, the weights in L2: no HBM bytes) and projects the gated result.  Per
 // 160 -> 960 -> 160 block that is 2 x 24 + 24 us of matrix work instead of 0.5 GB of HBM traffic; algorithmic bytes only reach HBM:
@@ -53,6 +57,9 @@ struct MbxArgs {
     int B, inC, inLd, outLd, resLd, T, CEXP, act;
     float scale1, scale2;      // 1 / (power-of-two weight scales)
     unsigned* range_slot;
+    unsigned long long* prof;  // ablation build, dbg & 64: per-wave cycle totals {prologue + expand(0), matrix jobs, wait a, taps, finish, wait b, epilogue, waves}
+    int dbg;                   // timing ablations (ablation build only; results are WRONG when set): 1 no DMA after the first tile, 2 no depthwise
+                               // taps, 4 no MFMAs, 16 no output stores
 };
 
 template <int KS, int NTO, int K, int DIL, int MODE>
@@ -68,19 +75,19 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
     constexpr int CT_SLOTS = ((CT_FLOATS / 4 + 63) / 64) * 64;   // 16-byte slots, whole waves
     constexpr int CT_BYTES = CT_SLOTS * 16 + 1024;          // + the gate's wave (32 floats used)
     constexpr int GATE_OFF = CT_SLOTS * 16;
+    constexpr int NACC = MODE == 1 ? 1 : NTO;
     static_assert(PAD >= 1 && PAD <= 4 && (K == 3 || K == 5), "depthwise window");
-    static_assert(E_BYTES + 2 * D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[E_BYTES + 2 * D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES];
+    static_assert(E_BYTES + D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[E_BYTES + D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES];
     float* const es = reinterpret_cast<float*>(smem);
     unsigned char* const dbase = smem + E_BYTES;
     float* const psum = reinterpret_cast<float*>(dbase);    // MODE 1: [2][32 partials][32 channels] over the (unused) D planes
-    unsigned char* const w1s = dbase + 2 * D_BYTES;
+    unsigned char* const w1s = dbase + D_BYTES;
     unsigned char* const w2s = w1s + W1_BYTES;
     unsigned char* const cts = w2s + W2_BYTES;
     PF_EMU_POISON(smem);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int pcol = lane & 15, kg = lane >> 4;
     const int T = a.T;
     unsigned amax = 0;                                      // range guard (pf_common.h): everything this launch splits
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
@@ -123,63 +130,111 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
         if (tt < CT_SLOTS) {
             const int sl = tt < CT_FLOATS / 4 ? tt : 0;     // padding slots of the last wave re-read slot 0
             pf_glds16_raw_soff<0>(a.ctile + (size_t)tile * CT_FLOATS, (unsigned)(sl * 16), dst + (size_t)tt * 16);
-        }
-        if constexpr (MODE == 2) {
-            if ((tt >> 6) == 7) pf_glds16_raw_soff<0>(a.gate + (size_t)face * a.CEXP + tile * 32, (unsigned)((tt & 7) * 16), dst + GATE_OFF + (tt & 63) * 16);
+        } else if (MODE == 2 && tt < CT_SLOTS + 64) {       // the next wave: the gate values, slots GATE_OFF / 16 ... (8 distinct ones)
+            pf_glds16_raw_soff<0>(a.gate + (size_t)face * a.CEXP + tile * 32, (unsigned)((tt & 7) * 16), dst + (size_t)tt * 16);
         }
     };
 
+    const bool prof = (pf_dbg(a) & 64) != 0;
+    unsigned long long c_pro = 0, c_mma = 0, c_wa = 0, c_dwc = 0, c_dwf = 0, c_wb = 0, c_epi = 0;
     for (int face = blockIdx.x; face < a.B; face += gridDim.x) {
+        const unsigned long long q0 = prof ? pf_clock() : 0;
         dma_w1(0);
         dma_ct(0, face);
-        // ---- the face's input -> split pixel fragments in registers (lane = pixel pcol of the row, k-group kg) -------------------
+        pf_f32x4 oacc[2][NACC];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) oacc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+        // ---- the face's input -> split pixel fragments in registers (lane = pixel pcol of the row, k-group kg): one batch of KS x 2
+        // unconditional 16-byte loads per image row (channels beyond inC read the pixel's first channels and are zeroed) -------------------
         pf_half8 xh[2][KS], xl[2][KS];
         {
-            const float* xin = a.in + ((size_t)face * 256 + wave * 32 + pcol) * a.inLd + kg * 8;
+            const int pcol = lane & 15, kg = lane >> 4;
+            const float* xin = a.in + ((size_t)face * 256 + wave * 32 + pcol) * a.inLd;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i) {
+                pf_f32x4 xv[KS][2];
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
                     const int c0 = s * 32 + kg * 8;
-                    const float* p = xin + (size_t)i * 16 * a.inLd + s * 32;
-                    pf_f32x4 v0 = pf_f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                    if (c0 < a.inC) v0 = *reinterpret_cast<const pf_f32x4*>(p);
-                    if (c0 + 4 < a.inC) v1 = *reinterpret_cast<const pf_f32x4*>(p + 4);
+                    const float* p = xin + (size_t)i * 16 * a.inLd;
+                    xv[s][0] = *reinterpret_cast<const pf_f32x4*>(p + (c0 < a.inC ? c0 : 0));
+                    xv[s][1] = *reinterpret_cast<const pf_f32x4*>(p + (c0 + 4 < a.inC ? c0 + 4 : 0));
+                }
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int c0 = s * 32 + kg * 8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+                        float v = xv[s][e >> 2][e & 3];
+                        if (!(c0 + (e & 4) < a.inC)) v = 0.f;
                         const pf_half hv = (pf_half)v;
                         xh[i][s][e] = hv;
                         xl[i][s][e] = (pf_half)(v - (float)hv);
                         amax = pf_amax(amax, v);
                     }
                 }
+            }
         }
-        pf_f32x4 oacc[2][MODE == 1 ? 1 : NTO];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < (MODE == 1 ? 1 : NTO); ++j) oacc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        pf_wait_vm_barrier<0>();
 
-        // ---- project(tile): out += W2[:, tile] . D[tile & 1] ------------------------------------------------------------------------
-        auto project = [&](int tile) {
+        // ---- expand(tile): E = act(W1[tile] . x + b1) ----------------------------------------------------------------------------------
+        auto expand = [&](int tile) {
+            const int tt = pf_opaque(t);
+            const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
+            const float* ct = reinterpret_cast<const float*>(cts + (tile & 1) * CT_BYTES);
+            pf_f32x4 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int off = s * 4096 + pf_lds_chunk_off(j * 16 + pcol, kg);
+                    const pf_half8 wh = *reinterpret_cast<const pf_half8*>(w1s + off);
+                    const pf_half8 wl = *reinterpret_cast<const pf_half8*>(w1s + 2048 + off);
+                    if (pf_dbg(a) & 4) continue;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wl, xh[i][s], acc[i][j]);      // small terms first
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wh, xl[i][s], acc[i][j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wh, xh[i][s], acc[i][j]);
+                    asm volatile("" ::: "memory");          // (register footprint: two weight fragments at a time)
+                }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(ct + K * K * 32 + j * 16 + kg * 4);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    pf_f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], a.scale1, bv[r]);
+                    pf_act_rh<4>(v, a.act);
+                    *reinterpret_cast<pf_f32x4*>(es + (wv * 32 + i * 16 + pcol) * ES + j * 16 + kg * 4) = v;
+                }
+            }
+        };
+        // ---- project(tile): out += W2[:, tile] . D ----------------------------------------------------------------------------------------
+        auto project = [&]() {
             if constexpr (MODE != 1) {
                 const int tt = pf_opaque(t);
-                const int pcol = tt & 15, kg = (tt >> 4) & 3, wave = tt >> 6;
-                const unsigned char* dp = dbase + (tile & 1) * D_BYTES;
+                const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
                 pf_half8 dh[2], dl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int off = pf_lds_chunk_off(wave * 32 + i * 16 + pcol, kg);
-                    dh[i] = *reinterpret_cast<const pf_half8*>(dp + off);
-                    dl[i] = *reinterpret_cast<const pf_half8*>(dp + 16384 + off);
+                    const int off = pf_lds_chunk_off(wv * 32 + i * 16 + pcol, kg);
+                    dh[i] = *reinterpret_cast<const pf_half8*>(dbase + off);
+                    dl[i] = *reinterpret_cast<const pf_half8*>(dbase + 16384 + off);
                 }
 #pragma unroll
                 for (int j = 0; j < NTO; ++j) {
                     const int off = pf_lds_chunk_off(j * 16 + pcol, kg);
                     const pf_half8 wh = *reinterpret_cast<const pf_half8*>(w2s + off);
                     const pf_half8 wl = *reinterpret_cast<const pf_half8*>(w2s + COUT * 64 + off);
+                    if (pf_dbg(a) & 4) continue;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wl, dh[i], oacc[i][j]);     // small terms first
 #pragma unroll
@@ -190,15 +245,15 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 }
             }
         };
-        // ---- depthwise(tile): E -> bias, activation -> sums (MODE 1) or gated split planes D[tile & 1] ----------------------------------
-        auto depthwise = [&](int tile) {
+        // ---- depthwise taps of a tile: E -> 8 pixels x 2 channels per thread, bias included, in registers -----------------------------------
+        float of[16];                                       // of[2 x + c]: pixel 8 xhalf + x of row yrow, channel c2 + c
+        auto dw_taps = [&](int tile) {
             const int tt = pf_opaque(t);
             const int c2 = (tt & 15) * 2, xhalf = (tt >> 4) & 1, yrow = tt >> 5;
             const float* ct = reinterpret_cast<const float*>(cts + (tile & 1) * CT_BYTES);
             const pf_f32x2 bd = *reinterpret_cast<const pf_f32x2*>(ct + (K * K + 1) * 32 + c2);
-            pf_f32x2 o[8];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) o[x] = bd;
+            for (int x = 0; x < 8; ++x) { of[2 * x] = bd[0]; of[2 * x + 1] = bd[1]; }
             const bool right_half = xhalf != 0;
             // the PAD columns beside this half: the other half's (columns 8 .. 8 + PAD - 1 for the left half, 8 - PAD .. 7 for the right
             // half); the columns on its outer side lie outside the image and read as zero
@@ -222,17 +277,20 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 for (int kx = 0; kx < K; ++kx) {
                     pf_f32x2 w = *reinterpret_cast<const pf_f32x2*>(ct + (ky * K + kx) * 32 + c2);
                     if (!rok) w = pf_f32x2{0.f, 0.f};       // a filter row above / below the image (zero padding): its taps contribute nothing
+                    if (pf_dbg(a) & 2) continue;
 #pragma unroll
                     for (int x = 0; x < 8; ++x) {
-                        o[x][0] = fmaf(w[0], in[x + kx * DIL][0], o[x][0]);
-                        o[x][1] = fmaf(w[1], in[x + kx * DIL][1], o[x][1]);
+                        of[2 * x] = pf_fma_np(w[0], in[x + kx * DIL][0], of[2 * x]);
+                        of[2 * x + 1] = pf_fma_np(w[1], in[x + kx * DIL][1], of[2 * x + 1]);
                     }
                 }
                 asm volatile("" ::: "memory");              // one filter row's LDS reads in flight at a time (register footprint)
             }
-            float of[16];
-#pragma unroll
-            for (int x = 0; x < 8; ++x) { of[2 * x] = o[x][0]; of[2 * x + 1] = o[x][1]; }
+        };
+        // ---- finish a tile: activation -> sums (MODE 1) or gated split planes D ------------------------------------------------------------
+        auto dw_finish = [&](int tile) {
+            const int tt = pf_opaque(t);
+            const int c2 = (tt & 15) * 2, xhalf = (tt >> 4) & 1, yrow = tt >> 5;
             pf_act_rh<16>(of, a.act);
             if constexpr (MODE == 1) {
                 pf_f32x2 rs = pf_f32x2{0.f, 0.f};
@@ -247,7 +305,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 }
                 // pixel-operand row of pixel P0 + x (P0 = 16 yrow + 8 xhalf, a multiple of 8): the chunk rotation of pf_lds_chunk_off
                 // depends on x only through x >> 2, so two base addresses + compile-time offsets cover the eight stores
-                unsigned char* dp = dbase + (tile & 1) * D_BYTES + (yrow * 16 + 8 * xhalf) * 64 + (c2 & 7) * 2;
+                unsigned char* dp = dbase + (yrow * 16 + 8 * xhalf) * 64 + (c2 & 7) * 2;
                 unsigned char* const dp0 = dp + (((c2 >> 3)) & 3) * 16;
                 unsigned char* const dp1 = dp + (((c2 >> 3) + 2) & 3) * 16;
 #pragma unroll
@@ -263,76 +321,78 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 }
             }
         };
+        auto squeeze = [&](int tile) {                      // MODE 1: the 32 partial sums per channel of a finished tile, in a fixed order
+            if (t < 32) {
+                const float* ps = psum + (tile & 1) * 1024 + t;
+                float tot = 0.f;
+#pragma unroll
+                for (int q = 0; q < 32; ++q) tot += ps[q * 32];
+                const int c = tile * 32 + t;
+                if (c < a.CEXP) a.gap_out[(size_t)face * a.CEXP + c] = tot / 256.f;
+            }
+        };
 
-        for (int tile = 0; tile <= T; ++tile) {
-            // ======== phase 1: expand(tile) -> E; W2(tile - 1) on its way =========================================================================
-            if constexpr (MODE != 1) { if (tile >= 1) dma_w2(tile - 1); }
-            if (tile < T) {
-                const int tt = pf_opaque(t);
-                const int pcol = tt & 15, kg = (tt >> 4) & 3, wave = tt >> 6;
-                const float* ct = reinterpret_cast<const float*>(cts + (tile & 1) * CT_BYTES);
-                pf_f32x4 acc[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int off = s * 4096 + pf_lds_chunk_off(j * 16 + pcol, kg);
-                        const pf_half8 wh = *reinterpret_cast<const pf_half8*>(w1s + off);
-                        const pf_half8 wl = *reinterpret_cast<const pf_half8*>(w1s + 2048 + off);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wl, xh[i][s], acc[i][j]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wh, xl[i][s], acc[i][j]);
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wh, xh[i][s], acc[i][j]);
-                        asm volatile("" ::: "memory");      // (register footprint: two weight fragments at a time)
-                    }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(ct + K * K * 32 + j * 16 + kg * 4);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        pf_f32x4 v;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[i][j][r], a.scale1, bv[r]);
-                        pf_act_rh<4>(v, a.act);
-                        *reinterpret_cast<pf_f32x4*>(es + (wave * 32 + i * 16 + pcol) * ES + j * 16 + kg * 4) = v;
-                    }
-                }
-            }
-            if constexpr (MODE == 1) {
-                if (tile >= 1 && t < 32) {                  // the squeeze of tile - 1: 32 partial sums per channel in a fixed order
-                    const float* ps = psum + ((tile - 1) & 1) * 1024 + t;
-                    float tot = 0.f;
-#pragma unroll
-                    for (int q = 0; q < 32; ++q) tot += ps[q * 32];
-                    const int c = (tile - 1) * 32 + t;
-                    if (c < a.CEXP) a.gap_out[(size_t)face * a.CEXP + c] = tot / 256.f;
-                }
-                if (tile == T) break;
-            }
-            pf_wait_vm_barrier<0>();
-            // ======== phase 2: depthwise(tile) beside project(tile - 1); W1 / constants of tile + 1 on their way ====================================
-            if (tile + 1 < T) { dma_w1(tile + 1); dma_ct(tile + 1, face); }
+        pf_wait_vm_barrier<0>();                            // W1(0), constants(0) have landed (and the input / residual loads with them)
+        expand(0);
+        pf_wait_vm_barrier<0>();
+        if (prof) c_pro += pf_clock() - q0;
+        for (int tile = 0; tile < T; ++tile) {
+            // ======== phase a: project(tile - 1) | taps of tile; W1 / constants of tile + 1 on their way ==================================
+            const unsigned long long q1 = prof ? pf_clock() : 0;
+            if (tile + 1 < T && !((pf_dbg(a) & 1) && tile > 0)) { dma_w1(tile + 1); dma_ct(tile + 1, face); }
+            unsigned long long q2 = q1, q3 = q1;
             if (wave < 4) {
-                if (tile >= 1) project(tile - 1);
-                if (tile < T) depthwise(tile);
+                if (tile >= 1) project();
+                if (prof) q2 = pf_clock();
+                dw_taps(tile);
+                if (prof) { q3 = pf_clock(); c_mma += q2 - q1; c_dwc += q3 - q2; }
             } else {
-                if (tile < T) depthwise(tile);
-                if (tile >= 1) project(tile - 1);
+                dw_taps(tile);
+                if (prof) q2 = pf_clock();
+                if (tile >= 1) project();
+                if (prof) { q3 = pf_clock(); c_dwc += q2 - q1; c_mma += q3 - q2; }
+            }
+            if constexpr (MODE == 1) { if (tile >= 1) squeeze(tile - 1); }
+            pf_wait_vm_barrier<0>();
+            // ======== phase b: expand(tile + 1) | finish tile -> D; W2 of tile on its way ==================================================
+            const unsigned long long q4 = prof ? pf_clock() : 0;
+            if constexpr (MODE != 1) { if (!((pf_dbg(a) & 1) && tile > 0)) dma_w2(tile); }
+            unsigned long long q5 = q4, q6 = q4;
+            if (wave < 4) {
+                if (tile + 1 < T) expand(tile + 1);
+                if (prof) q5 = pf_clock();
+                dw_finish(tile);
+                if (prof) { q6 = pf_clock(); c_mma += q5 - q4; c_dwf += q6 - q5; }
+            } else {
+                dw_finish(tile);
+                if (prof) q5 = pf_clock();
+                if (tile + 1 < T) expand(tile + 1);
+                if (prof) { q6 = pf_clock(); c_dwf += q5 - q4; c_mma += q6 - q5; }
             }
             pf_wait_vm_barrier<0>();
+            if (prof) { c_wa += q4 - q3; c_wb += pf_clock() - q6; }
         }
-        // ---- block output: + bias (+ residual), no activation (timm InvertedResidual: the projection is linear) ----------------------------
-        if constexpr (MODE != 1) {
+        const unsigned long long q7 = prof ? pf_clock() : 0;
+        if constexpr (MODE == 1) {
+            squeeze(T - 1);
+        } else {
+            // ---- block output = acc * scale2 + bias (+ residual), no activation (timm InvertedResidual: the projection is linear).  The
+            // residual vectors are requested BEFORE the last tile's projection -- all of them at once (the input fragments are dead by
+            // now, so the registers are there): one round trip hidden behind 60 MFMAs.  The first cut added them load by load between
+            // the stores (the compiler cannot move a load above a store that may alias it): twenty dependent round trips, 52 us per launch.
             const int tt = pf_opaque(t);
-            const int pcol = tt & 15, kg = (tt >> 4) & 3, wave = tt >> 6;
-            float* orow = a.out + ((size_t)face * 256 + wave * 32 + pcol) * a.outLd + kg * 4;
-            const float* rrow = a.res ? a.res + ((size_t)face * 256 + wave * 32 + pcol) * a.resLd + kg * 4 : nullptr;
+            const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
+            pf_f32x4 rv[2][NTO];
+            if (a.res) {
+                const float* __restrict__ rrow = a.res + ((size_t)face * 256 + wv * 32 + pcol) * a.resLd + kg * 4;
+#pragma unroll
+                for (int j = 0; j < NTO; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) rv[i][j] = *reinterpret_cast<const pf_f32x4*>(rrow + (size_t)i * 16 * a.resLd + j * 16);
+            }
+            project();                                      // tile T - 1
+            float* __restrict__ orow = a.out + ((size_t)face * 256 + wv * 32 + pcol) * a.outLd + kg * 4;
+            if (!(pf_dbg(a) & 16))
 #pragma unroll
             for (int j = 0; j < NTO; ++j) {
                 const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(a.b2 + j * 16 + kg * 4);
@@ -341,12 +401,18 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                     pf_f32x4 v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(oacc[i][j][r], a.scale2, bv[r]);
-                    if (rrow) v += *reinterpret_cast<const pf_f32x4*>(rrow + (size_t)i * 16 * a.resLd + j * 16);
+                    if (a.res) v += rv[i][j];
                     *reinterpret_cast<pf_f32x4*>(orow + (size_t)i * 16 * a.outLd + j * 16) = v;
                 }
             }
         }
-        // the next face's first DMA targets (W1, constants of tile 0) were last read before the loop's final barrier
+        if (prof) c_epi += pf_clock() - q7;
+        // the next face's first requests (W1 and constants of tile 0) target stages last read before the loop's final barrier; W2 and D,
+        // which the trailing project reads, are next written two barriers into the next face
+    }
+    if (prof && lane == 0) {
+        atomicAdd(a.prof + 0, c_pro); atomicAdd(a.prof + 1, c_mma); atomicAdd(a.prof + 2, c_wa); atomicAdd(a.prof + 3, c_dwc);
+        atomicAdd(a.prof + 4, c_dwf); atomicAdd(a.prof + 5, c_wb); atomicAdd(a.prof + 6, c_epi); atomicAdd(a.prof + 7, 1ull);
     }
     pf_amax_commit(a.range_slot, amax, amax_seen);
 }

@@ -77,7 +77,7 @@ def test_fused_blocks_match_unfused_gpu(gpu_engine, student_weights, size, batch
     _check(gpu_engine, student_weights, size, batch)
 
 
-def _mbx_vs_layerwise(eng, weights, batch, keep_all):
+def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False):
     """Stages 3-5 at 16 x 16 through the input-stationary block kernel (csrc/k_mbx.h, PF_OP_MBX: non-SE blocks in one launch, SE
     blocks as squeeze pass + FCs + recompute-and-project pass) against the same program with those blocks as expand + depthwise
     launch -> gated projection (fuse_mbx=False): the non-SE blocks bit for bit (same products in the same order), the SE blocks to
@@ -99,7 +99,7 @@ def _mbx_vs_layerwise(eng, weights, batch, keep_all):
         res[mbx] = (loc, score, blocks)
     for name, ref in res[False][2].items():
         got = res[True][2][name]
-        if name.split(".")[2] == "3":
+        if name.split(".")[2] == "3" and on_gpu:      # (the emulator build has no fma contraction in the layer-wise epilogue: one rounding apart)
             assert np.array_equal(got, ref), (name, float(np.abs(got - ref).max()))
         else:
             rel = np.abs(got - ref).max() / np.abs(ref).max()
@@ -123,4 +123,4 @@ def test_mbx_blocks_match_layerwise_emu(emu_engine, student_weights):
 @pytest.mark.gpu
 @pytest.mark.parametrize("batch,keep_all", [(5, True), (300, False)])
 def test_mbx_blocks_match_layerwise_gpu(gpu_engine, student_weights, batch, keep_all):
-    _mbx_vs_layerwise(gpu_engine, student_weights, batch, keep_all)   # 300 faces on 256 CUs: some workgroups walk two faces
+    _mbx_vs_layerwise(gpu_engine, student_weights, batch, keep_all, on_gpu=True)   # 300 faces on 256 CUs: some workgroups walk two faces
