@@ -568,7 +568,7 @@ def main():
         kern = "conv_gemm_kernel<%s>" % args.dtype
         if args.dtype == "f32s":
             kern = next(k for pre, k in KERNEL_OF_TAG_F32S if dom.startswith(pre))
-        m = __import__("re").search(r"_c(\d+)(?:_n(\d+))?_(\d+)x(\d+)$", dom)
+        m = __import__("re").search(r"_c(\d+)(?:_m\d+)?(?:_n(\d+))?_(\d+)x(\d+)$", dom)
         cin, nout, hh, ww = int(m.group(1)), int(m.group(2) or m.group(1)), int(m.group(3)), int(m.group(4))
         esz = 2 if args.dtype == "f16" else 4
         roofline = {"bound": "mfma", "kernel": "%s %s" % (kern, dom),

@@ -15,7 +15,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpeppa_hip.so")
-SOURCES = ["engine.cpp"]
+SOURCES = ["engine.cpp", "mbx_launch.cpp"]
+# per-source extra flags: k_mbx.h's depthwise taps must stay scalar v_fma_f32 (see csrc/mbx_launch.cpp)
+SOURCE_FLAGS = {"mbx_launch.cpp": ["-fno-slp-vectorize"]}
 STAMP = os.path.join(HERE, "libpeppa_hip.srchash")
 
 
@@ -67,11 +69,24 @@ def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False, f
             return out
         if not flavour and not needs_build():
             return out
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I", CSRC] + defs + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC] + defs
+    objs, procs = [], []
+    for src in SOURCES:                       # one object per translation unit, compiled side by side, then one link
+        obj = out + "." + os.path.splitext(src)[0] + ".o"
+        cmd = base + SOURCE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[peppa-hip] " + " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
-        print("[peppa-hip] " + " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print("[peppa-hip] " + " ".join(link), flush=True)
+    subprocess.run(link, check=True)
+    for obj in objs:
+        os.remove(obj)
     with open(stamp, "w") as f:
         f.write(source_hash() + "\n")
     return out

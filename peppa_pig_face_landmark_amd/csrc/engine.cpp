@@ -23,7 +23,7 @@
 #include "k_hrb.h"
 #include "k_hero.h"
 #include "k_sepup.h"
-#include "k_mbx.h"
+#include "k_mbx_args.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
 #include "k_track.h"
@@ -881,18 +881,9 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbx%s%dx%dd%d_c%d_m%d_n%d_16x16", mode == 0 ? "" : (mode == 1 ? "A" : "B"), K, K, dil, ti.C, a.CEXP, mode == 1 ? 0 : Cout);
                     ProfScope ps(h, tagbuf);
                     const dim3 grid(persistent_grid(B, 1));      // one workgroup per CU, faces strided over the grid
-                    bool launched = false;
-#define PF_MBX_CASE(KS_, NTO_, K_, DIL_, MODE_)                                                                     \
-    if (!launched && KS == KS_ && K == K_ && dil == DIL_ && mode == MODE_ && (MODE_ == 1 || Cout == 16 * NTO_)) {   \
-        PF_LAUNCH((mbx_kernel<KS_, NTO_, K_, DIL_, MODE_>), grid, dim3(512), h->stream, a);                         \
-        launched = true;                                                                                            \
-    }
-                    PF_MBX_CASE(3, 5, 3, 1, 0)                                    // blocks 3.1 - 3.3: 80 -> 200 / 184 -> 80
-                    PF_MBX_CASE(3, 7, 3, 1, 1) PF_MBX_CASE(3, 7, 3, 1, 2)         // block 4.0: 80 -> 480 -> 112
-                    PF_MBX_CASE(4, 7, 3, 1, 1) PF_MBX_CASE(4, 7, 3, 1, 2)         // block 4.1: 112 -> 672 -> 112
-                    PF_MBX_CASE(4, 10, 5, 1, 1) PF_MBX_CASE(4, 10, 5, 1, 2)       // block 5.0: 112 -> 672 -> 160, 5 x 5
-                    PF_MBX_CASE(5, 10, 5, 2, 1) PF_MBX_CASE(5, 10, 5, 2, 2)       // blocks 5.1 / 5.2: 160 -> 960 -> 160, 5 x 5 dilated
-#undef PF_MBX_CASE
+                    const int lrc = pf_mbx_launch(a, KS, Cout, K, dil, mode, (int)grid.x, h->stream);      // mbx_launch.cpp (own translation unit)
+                    if (lrc > 0) PF_FAIL(h, "launch of mbx_kernel failed: %s", hipGetErrorString((hipError_t)lrc));
+                    const bool launched = lrc == 0;
                     if (!launched) PF_FAIL(h, "mbx: no kernel for KS %d Cout %d k%d dil %d mode %d", KS, Cout, K, dil, mode);
                 }
                 break;

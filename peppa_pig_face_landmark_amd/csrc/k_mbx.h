@@ -12,18 +12,19 @@
 // their pixel fragments of ALL input channels in registers as split f16 hi / lo (KS k-steps x 2 tiles x 8 VGPRs), loaded once per face.
 // The expanded channels are walked 32 at a time ("tiles"), two barrier-separated phases per tile, each pairing a matrix-core job with
 // a VALU job that does not depend on it:
-//   phase a(t)  project(t - 1): out += W2[:, t - 1] . D on the matrix cores, the accumulators (2 tiles x NTO x 4 VGPRs) living in
-//               registers for the whole face
-//             | depthwise taps of tile t on E out of LDS: thread = (channel pair, image row, half row), k x k x 16 f32 fma in the
-//               order of the unfused kernel (v_fmac_f32 from inline asm: hipcc packs them into v_pk_fma_f32 otherwise, which
-//               measured ~4x slower per flop here), results stay in 16 registers;
+//   phase a(t)  project(t - 1): out += W2[:, t - 1] . D[(t - 1) & 1] on the matrix cores, the accumulators (2 tiles x NTO x 4 VGPRs)
+//               living in registers for the whole face
+//             | depthwise of tile t on E out of LDS: thread = (channel pair, image row, half row), k x k x 16 f32 fma in the order of
+//               the unfused kernel -- as SCALAR v_fma / v_fmac: this kernel lives in its own translation unit (mbx_launch.cpp, built
+//               with -fno-slp-vectorize) because hipcc's SLP vectoriser packs the channel pair into v_pk_fma_f32, which measured
+//               ~4x slower per flop here -- then + activation and MODE 1 (squeeze pass of an SE block): per-thread sums -> LDS ->
+//               per-face channel means, nothing else; MODE 0 / 2: (x SE gate) -> split hi / lo -> the pixel-operand planes D[t & 1];
 //   phase b(t)  expand(t + 1): E = act(W1[t + 1] . x + b1) (3 x v_mfma_f32_16x16x32_f16 per product, f32 accumulate; the 32 x (KS x 32)
-//               pre-split weight rows from a 20 KB LDS stage) -> LDS as f32 [256 px][36]
-//             | finish tile t: + activation, then MODE 1 (squeeze pass of an SE block): per-thread sums -> LDS -> per-face channel
-//               means, nothing else; MODE 0 / 2: (x SE gate) -> split hi / lo -> the pixel-operand planes D in LDS.
-// Waves 0-3 run the matrix job first and the VALU job second, waves 4-7 the other way round: waves w and w + 4 share a SIMD, so its
-// matrix pipe and its VALU are busy at the same time without instruction-level interleaving.  E and D are single buffers: E is
-// read in phase a and rewritten in phase b, D is written in phase b and read in the next phase a.
+//               pre-split weight rows from a 20 KB LDS stage) -> LDS as f32 [256 px][36].
+// In phase a waves 0-3 run the matrix job first and the VALU job second, waves 4-7 the other way round: waves w and w + 4 share a
+// SIMD, so its matrix pipe and its VALU are busy at the same time without instruction-level interleaving.  (A cut that carried the
+// tap results over the barrier to finish them beside expand balanced the phases better on paper, and spilled the output accumulators
+// to scratch inside the projection's MFMA chain: 16 more live registers next to 160 resident ones.)
 // Everything that comes from memory inside the loop arrives by LDS-DMA issued at the START of a phase for the NEXT phase that reads
 // it (W1 / taps / biases / gate of tile t + 1 during phase a(t), W2 of tile t during phase b(t)), so every barrier is a plain
 // "vmcnt(0) + s_barrier": no hand-counted partial waits in this kernel.
@@ -43,24 +44,7 @@
 #include "pf_common.h"
 #include "k_conv_gemm.h"
 #include "k_det.h"        // PF_EMU_POISON
-
-struct MbxArgs {
-    const float* in;           // [B][256][inLd]
-    float* out;                // [B][256][outLd]           MODE 0 / 2
-    const float* res;          // residual [B][256][resLd] or nullptr
-    float* gap_out;            // [B][CEXP] channel means   MODE 1
-    const float* gate;         // [B][CEXP] SE gate         MODE 2
-    const unsigned char* w1;   // [32 T][KS][hi 32 | lo 32] f16, rows beyond CEXP zero
-    const float* ctile;        // [T][K K + 2][32]: depthwise taps, expand bias, depthwise bias
-    const unsigned char* w2;   // [COUT][T][hi 32 | lo 32] f16
-    const float* b2;           // [COUT]
-    int B, inC, inLd, outLd, resLd, T, CEXP, act;
-    float scale1, scale2;      // 1 / (power-of-two weight scales)
-    unsigned* range_slot;
-    unsigned long long* prof;  // ablation build, dbg & 64: per-wave cycle totals {prologue + expand(0), matrix jobs, wait a, taps, finish, wait b, epilogue, waves}
-    int dbg;                   // timing ablations (ablation build only; results are WRONG when set): 1 no DMA after the first tile, 2 no depthwise
-                               // taps, 4 no MFMAs, 16 no output stores
-};
+#include "k_mbx_args.h"
 
 template <int KS, int NTO, int K, int DIL, int MODE>
 __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
@@ -77,12 +61,12 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
     constexpr int GATE_OFF = CT_SLOTS * 16;
     constexpr int NACC = MODE == 1 ? 1 : NTO;
     static_assert(PAD >= 1 && PAD <= 4 && (K == 3 || K == 5), "depthwise window");
-    static_assert(E_BYTES + D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[E_BYTES + D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES];
+    static_assert(E_BYTES + 2 * D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[E_BYTES + 2 * D_BYTES + W1_BYTES + W2_BYTES + 2 * CT_BYTES];
     float* const es = reinterpret_cast<float*>(smem);
     unsigned char* const dbase = smem + E_BYTES;
     float* const psum = reinterpret_cast<float*>(dbase);    // MODE 1: [2][32 partials][32 channels] over the (unused) D planes
-    unsigned char* const w1s = dbase + D_BYTES;
+    unsigned char* const w1s = dbase + 2 * D_BYTES;
     unsigned char* const w2s = w1s + W1_BYTES;
     unsigned char* const cts = w2s + W2_BYTES;
     PF_EMU_POISON(smem);
@@ -97,6 +81,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
     // assume changes it), once per call: left alone, the loop-invariant per-lane addresses of ALL phases (~40 of them, the DMA sources
     // as 64-bit pointers) are hoisted out of the tile loop, and next to 160 resident fragment / accumulator registers they spill
     // (first build: 616 bytes of scratch per lane).  Recomputing them costs a few dozen VALU instructions per phase.
+    auto glds = [&](const void* sb, unsigned voff, void* dst) { pf_glds16_raw_soff<0>(sb, voff, dst); };
     auto dma_w1 = [&](int tile) {                           // slot -> [k-step][plane][row][position], chunk rotation on the SOURCE
         const int tt = pf_opaque(t);
         const unsigned char* sb = a.w1 + (size_t)tile * (32 * KS * 128);
@@ -106,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
             if (sl < KS * 256) {
                 const int s = sl >> 8, plane = (sl >> 7) & 1, row = (sl >> 2) & 31;
                 const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                pf_glds16_raw_soff<0>(sb, (unsigned)((row * KS + s) * 128 + plane * 64 + chunk * 16), w1s + (size_t)sl * 16);
+                glds(sb, (unsigned)((row * KS + s) * 128 + plane * 64 + chunk * 16), w1s + (size_t)sl * 16);
             }
         }
     };
@@ -120,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 const int plane = sl >= COUT * 4 ? 1 : 0;
                 const int row = (sl - plane * COUT * 4) >> 2;
                 const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                pf_glds16_raw_soff<0>(sb, (unsigned)(row * T * 128 + plane * 64 + chunk * 16), w2s + (size_t)sl * 16);
+                glds(sb, (unsigned)(row * T * 128 + plane * 64 + chunk * 16), w2s + (size_t)sl * 16);
             }
         }
     };
@@ -129,9 +114,9 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
         unsigned char* dst = cts + (tile & 1) * CT_BYTES;
         if (tt < CT_SLOTS) {
             const int sl = tt < CT_FLOATS / 4 ? tt : 0;     // padding slots of the last wave re-read slot 0
-            pf_glds16_raw_soff<0>(a.ctile + (size_t)tile * CT_FLOATS, (unsigned)(sl * 16), dst + (size_t)tt * 16);
+            glds(a.ctile + (size_t)tile * CT_FLOATS, (unsigned)(sl * 16), dst + (size_t)tt * 16);
         } else if (MODE == 2 && tt < CT_SLOTS + 64) {       // the next wave: the gate values, slots GATE_OFF / 16 ... (8 distinct ones)
-            pf_glds16_raw_soff<0>(a.gate + (size_t)face * a.CEXP + tile * 32, (unsigned)((tt & 7) * 16), dst + (size_t)tt * 16);
+            glds(a.gate + (size_t)face * a.CEXP + tile * 32, (unsigned)((tt & 7) * 16), dst + (size_t)tt * 16);
         }
     };
 
@@ -218,16 +203,17 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
             }
         };
         // ---- project(tile): out += W2[:, tile] . D ----------------------------------------------------------------------------------------
-        auto project = [&]() {
+        auto project = [&](int tile) {
             if constexpr (MODE != 1) {
                 const int tt = pf_opaque(t);
                 const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
+                const unsigned char* dsrc = dbase + (tile & 1) * D_BYTES;
                 pf_half8 dh[2], dl[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int off = pf_lds_chunk_off(wv * 32 + i * 16 + pcol, kg);
-                    dh[i] = *reinterpret_cast<const pf_half8*>(dbase + off);
-                    dl[i] = *reinterpret_cast<const pf_half8*>(dbase + 16384 + off);
+                    dh[i] = *reinterpret_cast<const pf_half8*>(dsrc + off);
+                    dl[i] = *reinterpret_cast<const pf_half8*>(dsrc + 16384 + off);
                 }
 #pragma unroll
                 for (int j = 0; j < NTO; ++j) {
@@ -246,8 +232,8 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
             }
         };
         // ---- depthwise taps of a tile: E -> 8 pixels x 2 channels per thread, bias included, in registers -----------------------------------
-        float of[16];                                       // of[2 x + c]: pixel 8 xhalf + x of row yrow, channel c2 + c
-        auto dw_taps = [&](int tile) {
+        auto depthwise = [&](int tile) {
+            float of[16];                                   // of[2 x + c]: pixel 8 xhalf + x of row yrow, channel c2 + c
             const int tt = pf_opaque(t);
             const int c2 = (tt & 15) * 2, xhalf = (tt >> 4) & 1, yrow = tt >> 5;
             const float* ct = reinterpret_cast<const float*>(cts + (tile & 1) * CT_BYTES);
@@ -280,17 +266,13 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                     if (pf_dbg(a) & 2) continue;
 #pragma unroll
                     for (int x = 0; x < 8; ++x) {
-                        of[2 * x] = pf_fma_np(w[0], in[x + kx * DIL][0], of[2 * x]);
-                        of[2 * x + 1] = pf_fma_np(w[1], in[x + kx * DIL][1], of[2 * x + 1]);
+                        of[2 * x] = fmaf(w[0], in[x + kx * DIL][0], of[2 * x]);
+                        of[2 * x + 1] = fmaf(w[1], in[x + kx * DIL][1], of[2 * x + 1]);
                     }
                 }
                 asm volatile("" ::: "memory");              // one filter row's LDS reads in flight at a time (register footprint)
             }
-        };
-        // ---- finish a tile: activation -> sums (MODE 1) or gated split planes D ------------------------------------------------------------
-        auto dw_finish = [&](int tile) {
-            const int tt = pf_opaque(t);
-            const int c2 = (tt & 15) * 2, xhalf = (tt >> 4) & 1, yrow = tt >> 5;
+            // ---- activation -> sums (MODE 1) or gated split planes D[tile & 1] ----
             pf_act_rh<16>(of, a.act);
             if constexpr (MODE == 1) {
                 pf_f32x2 rs = pf_f32x2{0.f, 0.f};
@@ -305,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
                 }
                 // pixel-operand row of pixel P0 + x (P0 = 16 yrow + 8 xhalf, a multiple of 8): the chunk rotation of pf_lds_chunk_off
                 // depends on x only through x >> 2, so two base addresses + compile-time offsets cover the eight stores
-                unsigned char* dp = dbase + (yrow * 16 + 8 * xhalf) * 64 + (c2 & 7) * 2;
+                unsigned char* dp = dbase + (tile & 1) * D_BYTES + (yrow * 16 + 8 * xhalf) * 64 + (c2 & 7) * 2;
                 unsigned char* const dp0 = dp + (((c2 >> 3)) & 3) * 16;
                 unsigned char* const dp1 = dp + (((c2 >> 3) + 2) & 3) * 16;
 #pragma unroll
@@ -337,45 +319,33 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
         pf_wait_vm_barrier<0>();
         if (prof) c_pro += pf_clock() - q0;
         for (int tile = 0; tile < T; ++tile) {
-            // ======== phase a: project(tile - 1) | taps of tile; W1 / constants of tile + 1 on their way ==================================
+            // ======== phase a: project(tile - 1) | depthwise of tile -> D[tile & 1]; W1 / constants of tile + 1 on their way ==================
             const unsigned long long q1 = prof ? pf_clock() : 0;
             if (tile + 1 < T && !((pf_dbg(a) & 1) && tile > 0)) { dma_w1(tile + 1); dma_ct(tile + 1, face); }
             unsigned long long q2 = q1, q3 = q1;
             if (wave < 4) {
-                if (tile >= 1) project();
+                if (tile >= 1) project(tile - 1);
                 if (prof) q2 = pf_clock();
-                dw_taps(tile);
+                depthwise(tile);
                 if (prof) { q3 = pf_clock(); c_mma += q2 - q1; c_dwc += q3 - q2; }
             } else {
-                dw_taps(tile);
+                depthwise(tile);
                 if (prof) q2 = pf_clock();
-                if (tile >= 1) project();
+                if (tile >= 1) project(tile - 1);
                 if (prof) { q3 = pf_clock(); c_dwc += q2 - q1; c_mma += q3 - q2; }
             }
-            if constexpr (MODE == 1) { if (tile >= 1) squeeze(tile - 1); }
             pf_wait_vm_barrier<0>();
-            // ======== phase b: expand(tile + 1) | finish tile -> D; W2 of tile on its way ==================================================
+            // ======== phase b: expand(tile + 1) -> E; W2 of tile on its way =================================================================
             const unsigned long long q4 = prof ? pf_clock() : 0;
             if constexpr (MODE != 1) { if (!((pf_dbg(a) & 1) && tile > 0)) dma_w2(tile); }
-            unsigned long long q5 = q4, q6 = q4;
-            if (wave < 4) {
-                if (tile + 1 < T) expand(tile + 1);
-                if (prof) q5 = pf_clock();
-                dw_finish(tile);
-                if (prof) { q6 = pf_clock(); c_mma += q5 - q4; c_dwf += q6 - q5; }
-            } else {
-                dw_finish(tile);
-                if (prof) q5 = pf_clock();
-                if (tile + 1 < T) expand(tile + 1);
-                if (prof) { q6 = pf_clock(); c_dwf += q5 - q4; c_mma += q6 - q5; }
-            }
+            if (tile + 1 < T) expand(tile + 1);
+            if constexpr (MODE == 1) squeeze(tile);
+            const unsigned long long q6 = prof ? pf_clock() : 0;
             pf_wait_vm_barrier<0>();
-            if (prof) { c_wa += q4 - q3; c_wb += pf_clock() - q6; }
+            if (prof) { c_wa += q4 - q3; c_dwf += q6 - q4; c_wb += pf_clock() - q6; }
         }
         const unsigned long long q7 = prof ? pf_clock() : 0;
-        if constexpr (MODE == 1) {
-            squeeze(T - 1);
-        } else {
+        if constexpr (MODE != 1) {
             // ---- block output = acc * scale2 + bias (+ residual), no activation (timm InvertedResidual: the projection is linear).  The
             // residual vectors are requested BEFORE the last tile's projection -- all of them at once (the input fragments are dead by
             // now, so the registers are there): one round trip hidden behind 60 MFMAs.  The first cut added them load by load between
@@ -390,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void mbx_kernel(MbxArgs a) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) rv[i][j] = *reinterpret_cast<const pf_f32x4*>(rrow + (size_t)i * 16 * a.resLd + j * 16);
             }
-            project();                                      // tile T - 1
+            project(T - 1);
             float* __restrict__ orow = a.out + ((size_t)face * 256 + wv * 32 + pcol) * a.outLd + kg * 4;
             if (!(pf_dbg(a) & 16))
 #pragma unroll

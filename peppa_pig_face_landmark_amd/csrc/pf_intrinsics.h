@@ -116,10 +116,6 @@ __device__ __forceinline__ void pf_pin(unsigned& v) { asm volatile("" : "+v"(v))
 // a copy of v the compiler must assume is a different value (loop-invariant index arithmetic derived from it stays inside the loop)
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
-// c + a * b as ONE v_fmac_f32 the compiler cannot pair with its neighbour: hipcc's SLP vectoriser turns adjacent independent f32 fmas into
-// v_pk_fma_f32, which runs well below two v_fma_f32 on gfx950 (MI355X_MICROARCH.md: "an anti-lever"; k_mbx.h measured ~4x per flop)
-__device__ __forceinline__ float pf_fma_np(float a, float b, float c) { asm("v_fmac_f32 %0, %1, %2" : "+v"(c) : "v"(a), "v"(b)); return c; }
-
 // shader clock (s_memtime), for the per-wave time accounting of the ablation build
 __device__ __forceinline__ unsigned long long pf_clock() { return __builtin_amdgcn_s_memtime(); }
 

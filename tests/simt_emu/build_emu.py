@@ -27,7 +27,7 @@ def build_emu(force: bool = False, flavour: str = "") -> str:
     os.makedirs(OUT_DIR, exist_ok=True)
     out = OUT if not flavour else os.path.join(OUT_DIR, "libpeppa_emu_%s.so" % flavour)
     extra = {"": [], "asan": ["-fsanitize=address", "-fno-omit-frame-pointer", "-shared-libasan", "-O1"]}[flavour]
-    srcs = [os.path.join(CSRC, "engine.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+    srcs = [os.path.join(CSRC, "engine.cpp"), os.path.join(CSRC, "mbx_launch.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [
         os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "include", "pf_intrinsics.h"),
         os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "peppa_hip.h")]

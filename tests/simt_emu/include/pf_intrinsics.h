@@ -116,7 +116,6 @@ template <int OFF> inline void pf_glds16_raw_off(const void* gsrc, void* lds_lan
 template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous
 
 inline int pf_opaque(int v) { return v; }
-inline float pf_fma_np(float a, float b, float c) { return std::fmaf(a, b, c); }
 inline void pf_sched_fence() {}
 inline void pf_pin(unsigned&) {}
 inline unsigned long long pf_clock() { return 0; }

@@ -3,7 +3,8 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 T=${1:-r05_run4}
-( timeout 900 python -m pytest tests/test_fused_blocks.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -15 ) | tee gpurun_out/${T}_pytest_mbx.log
+python tools/mbx_determinism.py peppa_pig_face_landmark_amd/libpeppa_hip.so 2>&1 | grep -v "^RCCL\|amdgpu.ids" | tee gpurun_out/${T}_mbx_determinism.txt
+( timeout 900 python -m pytest tests/test_fused_blocks.py tests/test_gpu_race_net.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -15 ) | tee gpurun_out/${T}_pytest_mbx.log
 timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --dump-profile gpurun_out/${T}_kernel_table.json > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 tail -c 300 gpurun_out/${T}_bench.err
 python - <<PY
