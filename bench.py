@@ -141,6 +141,10 @@ def parse_args():
                     "rocprofv3 --stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
     ap.add_argument("--fuse-front", type=int, default=-1, help="A/B aid: 1 / 0 = Student program with / without the fused encoder front end "
                     "(csrc/k_front.h); default: the program builder's own default")
+    ap.add_argument("--mbx", default="default", choices=["default", "off", "recompute", "store"],
+                    help="A/B aid for the Student's 16 x 16 inverted-residual blocks (csrc/k_mbx.h): off = the layer-wise expand + depthwise / "
+                         "projection launches, recompute / store = force one SE strategy for every SE block; default: the builder's choice")
+    ap.add_argument("--mbx-waves", type=int, default=16, choices=[8, 16], help="A/B aid: waves per workgroup of the block kernels that have both flavours")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel HIP-event pass after the timed steps (lane sweeps, "
                     "rocprofv3 traces of the multi-lane steady state); roofline is null then")
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
@@ -436,6 +440,13 @@ def main():
     # ---- weights: packed on rank 0, broadcast once by the ENGINE over RCCL / xGMI (pf_broadcast_weights) -----------
     t0 = time.time()
     skw = {} if args.fuse_front < 0 or args.model != "student" else {"fuse_front": bool(args.fuse_front)}
+    if args.model == "student":
+        if args.mbx == "off":
+            skw["fuse_mbx"] = False
+        elif args.mbx != "default":
+            skw["mbx_se"] = args.mbx
+        if args.mbx_waves != 16:
+            skw["mbx_waves"] = args.mbx_waves
     blobs = bs.build_programs(workload, args.dtype, args.model, **skw) if rank == 0 else None
     slots = [PF_NET_LANDMARK] + ([PF_NET_DETECTOR] if workload == "pipeline" else [])
 

@@ -859,32 +859,33 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     a.gate = f[4] >= 0 ? (const float*)p.buf_ptr(f[4]) : nullptr;
                     a.w1 = (const unsigned char*)p.cptr(f[5]); a.ctile = (const float*)p.cptr(f[6]);
                     a.w2 = (const unsigned char*)p.cptr(f[7]); a.b2 = (const float*)p.cptr(f[8]);
-                    const int K = f[9], pad = f[10], dil = f[11], KS = f[13], Cout = f[15], mode = f[19];
+                    const int K = f[9], pad = f[10], dil = f[11], KS = f[13], Cout = f[15], mode = f[19], nw = f[20];
                     a.act = f[12]; a.T = f[14]; a.CEXP = f[16];
                     memcpy(&a.scale1, &f[17], 4); memcpy(&a.scale2, &f[18], 4);
                     a.B = B; a.inC = ti.C; a.inLd = ti.ld;
                     a.outLd = f[1] >= 0 ? p.tens[f[1]].ld : 0; a.resLd = f[2] >= 0 ? p.tens[f[2]].ld : 0;
                     a.range_slot = slot_of(oi);
                     a.dbg = h->dbg;
+                    const bool proj = mode == 0 || mode == 2, sq = mode == 1 || mode == 3;
                     if (host_dbg(h) & 64) {      // per-wave cycle accounting (ablation build; printed at pf_destroy)
                         if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
                         const int shape = KS == 3 ? 0 : (KS == 4 ? (K == 3 ? 1 : 2) : 3);
-                        a.prof = h->d_dbg + 160 + 8 * (shape * 3 + mode);
+                        a.prof = h->d_dbg + 160 + 8 * (shape * 4 + mode);
                     }
-                    if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 2 ||
-                        (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T ||
-                        (mode != 1 && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||
-                        (mode == 1 && !a.gap_out) || (mode == 2 && !a.gate))
-                        PF_FAIL(h, "mbx: unsupported shape (%dx%dx%d, k%d pad %d dil %d, mode %d)", ti.H, ti.W, ti.C, K, pad, dil, mode);
+                    if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 3 ||
+                        (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T || (nw != 8 && nw != 16) ||
+                        (proj && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||
+                        (sq && !a.gap_out) || (mode == 2 && !a.gate) || (mode == 3 && (!a.out || (a.outLd & 1) || p.tens[f[1]].C < a.CEXP)))
+                        PF_FAIL(h, "mbx: unsupported shape (%dx%dx%d, k%d pad %d dil %d, mode %d, %d waves)", ti.H, ti.W, ti.C, K, pad, dil, mode, nw);
                     char tagbuf[96];
                     tagbuf[0] = 0;
-                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbx%s%dx%dd%d_c%d_m%d_n%d_16x16", mode == 0 ? "" : (mode == 1 ? "A" : "B"), K, K, dil, ti.C, a.CEXP, mode == 1 ? 0 : Cout);
+                    if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbx%s%dx%dd%d_c%d_m%d_n%d_16x16", mode == 0 ? "" : (mode == 1 ? "A" : (mode == 2 ? "B" : "S")), K, K, dil, ti.C, a.CEXP, proj ? Cout : 0);
                     ProfScope ps(h, tagbuf);
                     const dim3 grid(persistent_grid(B, 1));      // one workgroup per CU, faces strided over the grid
-                    const int lrc = pf_mbx_launch(a, KS, Cout, K, dil, mode, (int)grid.x, h->stream);      // mbx_launch.cpp (own translation unit)
+                    const int lrc = pf_mbx_launch(a, nw, KS, Cout, K, dil, mode, (int)grid.x, h->stream);      // mbx_launch.cpp (own translation unit)
                     if (lrc > 0) PF_FAIL(h, "launch of mbx_kernel failed: %s", hipGetErrorString((hipError_t)lrc));
                     const bool launched = lrc == 0;
-                    if (!launched) PF_FAIL(h, "mbx: no kernel for KS %d Cout %d k%d dil %d mode %d", KS, Cout, K, dil, mode);
+                    if (!launched) PF_FAIL(h, "mbx: no kernel for %d waves, KS %d Cout %d k%d dil %d mode %d", nw, KS, Cout, K, dil, mode);
                 }
                 break;
             }
@@ -1198,15 +1199,15 @@ void pf_destroy(pf_handle* h) {
                 if (hb[4 * k + 3])
                     fprintf(stderr, "[det_hr_bottleneck CIN=%d] per workgroup (cycles): conv1 %.0f | conv2 %.0f | conv3+store %.0f  (%.0f workgroups)\n", k ? 256 : 64,
                             hb[4 * k] / (double)hb[4 * k + 3], hb[4 * k + 1] / (double)hb[4 * k + 3], hb[4 * k + 2] / (double)hb[4 * k + 3], (double)hb[4 * k + 3]);
-        unsigned long long mb[96];
+        unsigned long long mb[128];
         if (hipMemcpy(mb, h->d_dbg + 160, sizeof(mb), hipMemcpyDeviceToHost) == hipSuccess)
-            for (int k = 0; k < 12; ++k) {
+            for (int k = 0; k < 16; ++k) {
                 const unsigned long long* q = mb + 8 * k;
                 if (!q[7]) continue;
                 static const char* shp[4] = {"KS3 k3", "KS4 k3", "KS4 k5", "KS5 k5d2"};
                 const double n = (double)q[7];
-                fprintf(stderr, "[det_mbx %s mode %d] per wave and launch-face (cycles): prologue+expand0 %.0f | matrix jobs %.0f | wait a %.0f | taps %.0f | finish %.0f | wait b %.0f | epilogue %.0f  (%.0f waves)\n",
-                        shp[k / 3], k % 3, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, n);
+                fprintf(stderr, "[det_mbx %s mode %d] per wave and launch-face (cycles): prologue+expand0 %.0f | project %.0f | wait a %.0f | depthwise %.0f | expand %.0f | wait b %.0f | epilogue %.0f  (%.0f waves)\n",
+                        shp[k / 4], k % 4, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, n);
             }
         unsigned long long w9[9];
         if (hipMemcpy(w9, h->d_dbg + 128, sizeof(w9), hipMemcpyDeviceToHost) == hipSuccess && w9[8]) {

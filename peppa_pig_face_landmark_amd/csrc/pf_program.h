@@ -72,9 +72,10 @@ enum PfOpCode : int32_t {
                         //    out = act(y + sum_s nearest_up(conv1x1_s(src_s), 2^shift_s)), weights f32 [srcC][C padded to 4] (k_layers.h fuse_up_kernel);
                         //    f32 tensors only
     PF_OP_MBX = 24,     // f: in_t out_t(-1) res_t(-1) gap_buf(-1) gate_buf(-1) w1 ctile w2(-1) b2(-1) K pad dil act KS T Cout Cexp scale1 scale2 (float
-                        //    bits) mode: a whole inverted-residual block at 16 x 16 with the face's input stationary in registers and the expanded
-                        //    tensor in LDS only (k_mbx.h mbx_kernel); mode 0 = block without squeeze-excite, 1 = expand + depthwise -> per-face channel
-                        //    means into gap_buf (the SE squeeze), 2 = expand + depthwise recomputed, x gate_buf, projected (+ res); split programs only
+                        //    bits) mode waves(8 | 16): a whole inverted-residual block at 16 x 16 with the face's input stationary in registers and
+                        //    the expanded tile in LDS (k_mbx.h mbx_kernel); mode 0 = block without squeeze-excite, 1 = expand + depthwise -> per-face
+                        //    channel means into gap_buf (the SE squeeze), 2 = expand + depthwise recomputed, x gate_buf, projected (+ res), 3 = mode 1
+                        //    + the activated depthwise map stored in out_t (for the layer-wise gated projection); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

@@ -592,30 +592,48 @@ class ProgramBuilder:
         wp_s, s2 = self._split_rows(wp)
         return self.const(we_s), self.const_f32(ct), self.const(wp_s), self.const_f32(b_pwl), cp // 32, T, s1, s2
 
+    MBX_RECOMPUTE_16 = {(3, 7, 3, 1), (4, 7, 3, 1)}     # (KS, Cout / 16, k, dil) whose gate-and-project pass fits 16 waves x 128 registers
+
     def mbx(self, x: int, w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl, act: str, *, pad: int, dil: int = 1, res: int = -1,
-            se_fcs=None, out_name: str = "") -> int:
+            se_fcs=None, se_mode: Optional[str] = None, waves: int = 16, out_name: str = "", dw_name: str = "") -> int:
         """Inverted-residual block (expand 1x1 -> depthwise kxk -> [SE] -> project 1x1 [+ res]) on a 16 x 16 map, weights BN-folded.
-        Without SE: one launch.  With SE (``se_fcs`` = (w_reduce [R,Mid], b_reduce, w_expand [Mid,R], b_expand)): the squeeze pass
-        (expand + depthwise -> per-face channel means), the two FCs, then the pass that recomputes expand + depthwise, applies the
-        gate and projects -- the expanded tensor never exists in HBM."""
+        Without SE: one launch.  With SE (``se_fcs`` = (w_reduce [R,Mid], b_reduce, w_expand [Mid,R], b_expand)) a squeeze pass
+        (expand + depthwise -> per-face channel means), the two FCs, then by ``se_mode``
+          "recompute": a second pass that recomputes expand + depthwise, applies the gate and projects -- the expanded tensor
+                       never exists in HBM (default for 3 x 3 depthwise convs: recomputing nine taps is cheap);
+          "store":     the squeeze pass also stores the activated depthwise map and the layer-wise gated projection reads it
+                       back (default for 5 x 5: a second depthwise pass costs more than the round trip).
+        ``waves``: 16 or 8 waves per workgroup for the launches that have both flavours (A/B aid)."""
         ti = self.tensors[x]
         mid, cin = w_exp.shape[:2]
         cout, k = w_pwl.shape[0], w_dw.shape[2]
         assert cin == ti.real_c == ti.C and w_dw.shape == (mid, 1, k, k) and w_pwl.shape[1] == mid
-        assert self.mbx_supported(x, k, 1, pad, dil, cout, se_fcs is not None)
+        assert self.mbx_supported(x, k, 1, pad, dil, cout, se_fcs is not None) and waves in (8, 16)
         w1, ct, w2, b2, ks, T, s1, s2 = self._mbx_pack(w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl)
         fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
-        out = self.tensor(ti.H, ti.W, cout, name=out_name)
         common = [w1, ct, w2, b2, k, pad, dil, ACT[act], ks, T, cout, mid, fbits(s1), fbits(s2)]
         if se_fcs is None:
-            self._op(OP_MBX, [x, out, res, -1, -1] + common + [0], [self._tb(x), self._tb(res)], [self._tb(out)])
+            out = self.tensor(ti.H, ti.W, cout, name=out_name)
+            self._op(OP_MBX, [x, out, res, -1, -1] + common + [0, waves], [self._tb(x), self._tb(res)], [self._tb(out)])
             return out
+        if se_mode is None:
+            se_mode = "store" if k == 5 else "recompute"
+        assert se_mode in ("recompute", "store")
         w_rd, b_rd, w_ex, b_ex = se_fcs
         gap = self.buffer(mid, ELEM_F32, "gap")
-        self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1], [self._tb(x)], [gap])
+        if se_mode == "store":
+            assert mid % 32 == 0, "the stored map is written in whole 32-channel tiles"
+            dwt = self.tensor(ti.H, ti.W, mid, name=dw_name)
+            self._op(OP_MBX, [x, dwt, -1, gap, -1] + common + [3, 16], [self._tb(x)], [self._tb(dwt), gap])
+            hid = self.fc(gap, w_rd, b_rd, "relu")
+            gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
+            return self.conv(dwt, w_pwl, b_pwl, "none", res=res, gate_buf=gate, out_name=out_name)
+        out = self.tensor(ti.H, ti.W, cout, name=out_name)
+        self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1, 16], [self._tb(x)], [gap])
         hid = self.fc(gap, w_rd, b_rd, "relu")
         gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
-        self._op(OP_MBX, [x, out, res, -1, gate] + common + [2], [self._tb(x), self._tb(res), gate], [self._tb(out)])
+        nw2 = waves if (ks, cout // 16, k, dil) in self.MBX_RECOMPUTE_16 else 8
+        self._op(OP_MBX, [x, out, res, -1, gate] + common + [2, nw2], [self._tb(x), self._tb(res), gate], [self._tb(out)])
         return out
 
     CHAIN_SHAPES = ((72, 16), (144, 8))       # (channels, map side) with a basic_chain_kernel instantiation

@@ -31,7 +31,7 @@ def _compare_programs(eng, weights, size, batch):
     for fuse in (False, True):
         blob, info = build_student_program(weights, size, "f32s", keep_all=True, fuse_mbconv=fuse)
         codes = _op_codes(blob)
-        assert (ir.OP_MBCONV in codes) == fuse and (ir.OP_EXPDW in codes) == fuse
+        assert (ir.OP_MBCONV in codes) == fuse and (ir.OP_EXPDW in codes) == fuse and (ir.OP_MBX in codes) == (fuse and size == 256)
         eng.load_program(0, blob, batch)
         loc, score = eng.landmark_forward(crops)
         outs[fuse] = (loc, score)
@@ -77,17 +77,18 @@ def test_fused_blocks_match_unfused_gpu(gpu_engine, student_weights, size, batch
     _check(gpu_engine, student_weights, size, batch)
 
 
-def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False):
+def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=10, **mbx_kw):
     """Stages 3-5 at 16 x 16 through the input-stationary block kernel (csrc/k_mbx.h, PF_OP_MBX: non-SE blocks in one launch, SE
-    blocks as squeeze pass + FCs + recompute-and-project pass) against the same program with those blocks as expand + depthwise
-    launch -> gated projection (fuse_mbx=False): the non-SE blocks bit for bit (same products in the same order), the SE blocks to
-    f32 rounding (their channel means are summed in another order)."""
+    blocks as squeeze pass + FCs + either a recompute-gate-project pass or the layer-wise projection on the map the squeeze pass
+    stored) against the same program with those blocks as expand + depthwise launch -> gated projection (fuse_mbx=False): the
+    non-SE blocks bit for bit (same products in the same order), the SE blocks to the rounding noise of the f32s path (their channel
+    means are summed in another order and the SE gates amplify it; each block is held to the ORACLE at 2e-4 by _check above)."""
     crops = sw.smooth_blob_images(batch, 256, seed=5100 + batch)
     res = {}
     for mbx in (False, True):
-        blob, info = build_student_program(weights, 256, "f32s", keep_all=keep_all, fuse_mbx=mbx)
+        blob, info = build_student_program(weights, 256, "f32s", keep_all=keep_all, fuse_mbx=mbx, **(mbx_kw if mbx else {}))
         codes = _op_codes(blob)
-        assert (ir.OP_MBX in codes) == mbx and codes.count(ir.OP_MBX) == (13 if mbx else 0)
+        assert (ir.OP_MBX in codes) == mbx and codes.count(ir.OP_MBX) == (n_mbx if mbx else 0), codes.count(ir.OP_MBX)
         eng.load_program(0, blob, batch)
         loc, score = eng.landmark_forward(crops)
         blocks = {}
@@ -99,11 +100,11 @@ def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False):
         res[mbx] = (loc, score, blocks)
     for name, ref in res[False][2].items():
         got = res[True][2][name]
-        if name.split(".")[2] == "3" and on_gpu:      # (the emulator build has no fma contraction in the layer-wise epilogue: one rounding apart)
+        if name.split(".")[2] == "3":
             assert np.array_equal(got, ref), (name, float(np.abs(got - ref).max()))
         else:
             rel = np.abs(got - ref).max() / np.abs(ref).max()
-            assert rel < 2e-5, (name, rel)
+            assert rel < 2e-4, (name, rel)
     if keep_all:
         assert len(res[True][2]) == 9
     oloc, oscore, taps = helpers.oracle_student(weights, crops[:min(batch, 8)])
@@ -116,11 +117,18 @@ def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False):
     assert np.isfinite(res[True][1]).all()
 
 
-def test_mbx_blocks_match_layerwise_emu(emu_engine, student_weights):
-    _mbx_vs_layerwise(emu_engine, student_weights, 7, True)      # 7 faces on the emulator's 5 workgroups: the face loop runs
+_MBX_VARIANTS = [({}, 10),                                       # default: 3 x 3 SE blocks recompute (16 waves), 5 x 5 SE blocks store
+                 ({"mbx_se": "recompute"}, 13),                  # every SE block: squeeze pass + 8- / 16-wave recompute pass
+                 ({"mbx_se": "store", "mbx_waves": 8}, 8)]      # every SE block stores; the non-SE blocks on 8 waves
+
+
+@pytest.mark.parametrize("kw,n_mbx", _MBX_VARIANTS)
+def test_mbx_blocks_match_layerwise_emu(emu_engine, student_weights, kw, n_mbx):
+    _mbx_vs_layerwise(emu_engine, student_weights, 7, True, n_mbx=n_mbx, **kw)      # 7 faces on the emulator's 5 workgroups: the face loop runs
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kw,n_mbx", _MBX_VARIANTS)
 @pytest.mark.parametrize("batch,keep_all", [(5, True), (300, False)])
-def test_mbx_blocks_match_layerwise_gpu(gpu_engine, student_weights, batch, keep_all):
-    _mbx_vs_layerwise(gpu_engine, student_weights, batch, keep_all, on_gpu=True)   # 300 faces on 256 CUs: some workgroups walk two faces
+def test_mbx_blocks_match_layerwise_gpu(gpu_engine, student_weights, batch, keep_all, kw, n_mbx):
+    _mbx_vs_layerwise(gpu_engine, student_weights, batch, keep_all, on_gpu=True, n_mbx=n_mbx, **kw)   # 300 faces on 256 CUs: some workgroups walk two faces

@@ -1,0 +1,22 @@
+#!/bin/bash
+# round 5, session E: block kernels v4 (8 / 16 waves, squeeze-and-store mode) -- determinism, GPU parity, A/B of the SE strategies, phase cycles
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+T=${1:-r05_run10}
+python tools/mbx_determinism.py peppa_pig_face_landmark_amd/libpeppa_hip.so 2>&1 | grep -v "^RCCL\|amdgpu.ids" | tee gpurun_out/${T}_mbx_determinism.txt
+( timeout 900 python -m pytest tests/test_fused_blocks.py tests/test_gpu_race_net.py -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -15 ) | tee gpurun_out/${T}_pytest_mbx.log
+for v in default off recompute store; do
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probes --mbx $v --dump-profile gpurun_out/${T}_kernel_table_$v.json > gpurun_out/${T}_bench_$v.json 2> gpurun_out/${T}_bench_$v.err
+  tail -c 200 gpurun_out/${T}_bench_$v.err | grep -i "error\|assert"
+  python - <<PY
+import json
+d=json.loads(open("gpurun_out/${T}_bench_$v.json").read().strip().splitlines()[-1])
+k=json.load(open("gpurun_out/${T}_kernel_table_$v.json"))["kernels"]
+g={n: round(x["ms_per_step"],4) for n,x in k.items() if n.startswith("mbx") or n.startswith("expdw") and "16x16" in n or n.startswith("conv1x1_c") and "16x16" in n or n in ("fc","gap")}
+print("$v VALUE", d["value"], "serial", d["extra"]["lane_step_ms_serial"], "group", round(sum(g.values()),4))
+print("   ", g)
+PY
+done 2>&1 | tee gpurun_out/${T}_mbx_ab.txt
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probes --mbx-waves 8 --dump-profile gpurun_out/${T}_kernel_table_w8.json > gpurun_out/${T}_bench_w8.json 2>/dev/null; python -c "
+import json; k=json.load(open('gpurun_out/${T}_kernel_table_w8.json'))['kernels']; print('waves 8:', {n: round(x['ms_per_step'],4) for n,x in k.items() if n.startswith('mbx')})" | tee -a gpurun_out/${T}_mbx_ab.txt
+python tools/ab_env.py "mbx" "PEPPA_DBG=64" 2>&1 | grep "det_mbx" | head -12 | tee gpurun_out/${T}_mbx_phase_cycles.txt
