@@ -100,12 +100,12 @@ def tag_flops_per_face(tag: str):
     if m:
         c, n, h, w = map(int, m.groups())
         return 2.0 * h * w * c * (n + 9)
-    m = re.fullmatch(r"mbx([AB]?)(\d)x\dd\d_c(\d+)_m(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # whole inverted-residual block (csrc/k_mbx.h)
+    m = re.fullmatch(r"mbx([ABS]?)(\d)x\dd\d_c(\d+)_m(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # whole inverted-residual block (csrc/k_mbx.h)
     if m:
         mode, (k, c, mid, n, h, w) = m.group(1), map(int, m.groups()[1:])
         # algorithmic work of the launch: expand + depthwise (pass A and, recomputed, pass B count once each: what the launch does
         # for the block's result is expand + depthwise + projection; the squeeze pass is priced as expand + depthwise)
-        return 2.0 * h * w * mid * (c + k * k + (0 if mode == "A" else n))
+        return 2.0 * h * w * mid * (c + k * k + (0 if mode in ("A", "S") else n))
     m = re.fullmatch(r"expdw(\d)x\d[ds]\d_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # expand C -> N + depthwise KxK on N
     if m:
         k, c, n, h, w = map(int, m.groups())

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     constexpr int NCT = PROJECT ? 2 : 3;                    // constant stages
     constexpr int PS_BYTES = SQUEEZE ? 2 * NPART * 32 * 4 : 0;
     constexpr int NACC = PROJECT ? NTO : 1;
-    constexpr int LDS_BYTES = NE * E_BYTES + (PROJECT ? 2 * D_BYTES : 0) + NW1 * W1_BYTES + W2_BYTES + NCT * CT_BYTES + PS_BYTES;
+    constexpr int Z_BYTES = 1024;                           // zeros: what a depthwise thread reads for the columns outside the image
+    constexpr int LDS_BYTES = NE * E_BYTES + (PROJECT ? 2 * D_BYTES : 0) + NW1 * W1_BYTES + W2_BYTES + NCT * CT_BYTES + PS_BYTES + Z_BYTES;
     static_assert(NW == 8 || NW == 16, "8 or 16 waves");
     static_assert(PAD >= 1 && PAD <= XP && (K == 3 || K == 5), "depthwise window");
     static_assert(CT_SLOTS + 64 <= NTHR, "constants + gate: one request per thread");
@@ -89,7 +90,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     unsigned char* const w2s = w1s + NW1 * W1_BYTES;
     unsigned char* const cts = w2s + W2_BYTES;
     float* const psum = reinterpret_cast<float*>(cts + NCT * CT_BYTES);     // [2][NPART][32]
+    unsigned char* const zeros = cts + NCT * CT_BYTES + PS_BYTES;
+    static_assert((PAD - 1) * ES * 4 + 8 <= Z_BYTES, "zero block covers a side's PAD columns");
     PF_EMU_POISON(smem);
+    if (threadIdx.x < Z_BYTES / 4) reinterpret_cast<float*>(zeros)[threadIdx.x] = 0.f;      // (the first barrier of the first face orders it)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int T = a.T;
@@ -267,30 +271,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
             const pf_f32x2 bd = *reinterpret_cast<const pf_f32x2*>(ct + (K * K + 1) * 32 + c2);
 #pragma unroll
             for (int x = 0; x < XP; ++x) { of[2 * x] = bd[0]; of[2 * x + 1] = bd[1]; }
-            // the PAD columns either side of this part of the row belong to its neighbours, or lie outside the image and read as zero
-            // (PAD <= XP: a side is wholly inside or wholly outside); an outside side re-reads the part's own columns, then selects zero
+            // The PAD columns either side of this part of the row belong to its neighbours, or lie outside the image (PAD <= XP: a side is
+            // wholly inside or wholly outside); an outside side is READ FROM A BLOCK OF ZEROS -- one address select per side and filter
+            // row instead of a select per value (the depthwise is VALU-bound: scalar f32 VALU runs at 4 cycles per wave instruction here,
+            // and the selects were a fifth of the instruction stream).  With 16 waves a wave is one image row, so a filter row that falls
+            // above / below the image is skipped by a scalar branch -- with its reads and taps, 15 % of a dilated 5 x 5 -- where the
+            // 8-wave layout (two rows per wave) has to zero the row's taps instead.
             const bool lok = part > 0, rok = part < NP - 1;
-            const int lcol = lok ? XP * part - PAD : XP * part, rcol = rok ? XP * part + XP : XP * part;
+            const unsigned char* ebase = reinterpret_cast<const unsigned char*>(esrc + c2);
+            const int mid_off = XP * part * ES * 4;
+            constexpr bool ROW_UNIFORM = NW == 16;
+            const int yrow_u = ROW_UNIFORM ? pf_uniform_i32(yrow) : yrow;
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
-                const int yy = yrow + ky * DIL - PAD;
+                const int yy = yrow_u + ky * DIL - PAD;
                 const bool yok = (unsigned)yy < 16u;
-                const int yc = yy < 0 ? 0 : (yy > 15 ? 15 : yy);
-                const float* erow = esrc + (yc * 16) * ES + c2;
+                if constexpr (ROW_UNIFORM) { if (!yok) continue; }
+                const int yc = ROW_UNIFORM ? yy : (yy < 0 ? 0 : (yy > 15 ? 15 : yy));
+                const unsigned char* erow = ebase + yc * 16 * ES * 4;
+                const unsigned char* lp = lok ? erow + mid_off - PAD * ES * 4 : zeros;
+                const unsigned char* rp = rok ? erow + mid_off + XP * ES * 4 : zeros;
                 pf_f32x2 in[XP + 2 * PAD];                  // in[PAD + j] = column XP part + j, j = -PAD .. XP - 1 + PAD
 #pragma unroll
-                for (int j = 0; j < XP; ++j) in[PAD + j] = *reinterpret_cast<const pf_f32x2*>(erow + (XP * part + j) * ES);
+                for (int j = 0; j < XP; ++j) in[PAD + j] = *reinterpret_cast<const pf_f32x2*>(erow + mid_off + j * ES * 4);
 #pragma unroll
                 for (int s = 0; s < PAD; ++s) {
-                    const pf_f32x2 lv = *reinterpret_cast<const pf_f32x2*>(erow + (lcol + s) * ES);
-                    const pf_f32x2 rv = *reinterpret_cast<const pf_f32x2*>(erow + (rcol + s) * ES);
-                    in[s] = lok ? lv : pf_f32x2{0.f, 0.f};
-                    in[PAD + XP + s] = rok ? rv : pf_f32x2{0.f, 0.f};
+                    in[s] = *reinterpret_cast<const pf_f32x2*>(lp + s * ES * 4);
+                    in[PAD + XP + s] = *reinterpret_cast<const pf_f32x2*>(rp + s * ES * 4);
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
                     pf_f32x2 w = *reinterpret_cast<const pf_f32x2*>(ct + (ky * K + kx) * 32 + c2);
-                    if (!yok) w = pf_f32x2{0.f, 0.f};       // a filter row above / below the image (zero padding): its taps contribute nothing
+                    if constexpr (!ROW_UNIFORM) { if (!yok) w = pf_f32x2{0.f, 0.f}; }      // a filter row above / below the image: its taps contribute nothing
                     if (pf_dbg(a) & 2) continue;
 #pragma unroll
                     for (int x = 0; x < XP; ++x) {

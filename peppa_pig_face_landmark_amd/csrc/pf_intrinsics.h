@@ -113,6 +113,9 @@ __device__ __forceinline__ void pf_sched_fence() { __builtin_amdgcn_sched_barrie
 // the value must be in its register here (ends the compiler's freedom to postpone the arithmetic that produces it)
 __device__ __forceinline__ void pf_pin(unsigned& v) { asm volatile("" : "+v"(v)); }
 
+// v, which the CALLER knows to be the same in every lane of the wave, as a scalar (branches on it become scalar branches)
+__device__ __forceinline__ int pf_uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // a copy of v the compiler must assume is a different value (loop-invariant index arithmetic derived from it stays inside the loop)
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
