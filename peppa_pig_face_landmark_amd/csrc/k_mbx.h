@@ -29,8 +29,9 @@
 //
 // An SE block is: squeeze pass (MODE 1 or 3) -> the two small FC launches -> either MODE 2, which RECOMPUTES expand + depthwise (the input
 // is in registers, the weights in L2) and projects the gated result -- the expanded tensor never reaches HBM --, or (after MODE 3) the
-// layer-wise gated projection on the stored map.  Recomputing pays where the depthwise is cheap (3 x 3); a 5 x 5 depthwise is ~100 VALU
-// instructions per output pixel pair and tile, so those blocks store (ir.py::mbx picks; measured both ways).
+// layer-wise gated projection on the stored map.  The depthwise is VALU-bound (scalar f32 VALU issues one wave instruction per 4 cycles
+// here; a dilated 5 x 5 is ~260 of them per thread and tile), so a second pass over it costs more than the map's round trip through HBM:
+// storing measured faster for every SE block of the Student, 3 x 3 included (profiles/r05_run11_mbx_ab_v4b.txt; ir.py::mbx defaults to it).
 //
 // What the first cuts taught (profiles/r05_run3 ... r05_run9):
 //   * 8 waves only (two per SIMD): a single wave issues one VALU instruction per ~4 cycles, so with its SIMD partner in a matrix job the

@@ -599,10 +599,11 @@ class ProgramBuilder:
         """Inverted-residual block (expand 1x1 -> depthwise kxk -> [SE] -> project 1x1 [+ res]) on a 16 x 16 map, weights BN-folded.
         Without SE: one launch.  With SE (``se_fcs`` = (w_reduce [R,Mid], b_reduce, w_expand [Mid,R], b_expand)) a squeeze pass
         (expand + depthwise -> per-face channel means), the two FCs, then by ``se_mode``
-          "recompute": a second pass that recomputes expand + depthwise, applies the gate and projects -- the expanded tensor
-                       never exists in HBM (default for 3 x 3 depthwise convs: recomputing nine taps is cheap);
           "store":     the squeeze pass also stores the activated depthwise map and the layer-wise gated projection reads it
-                       back (default for 5 x 5: a second depthwise pass costs more than the round trip).
+                       back (the default: measured faster for every SE block of the Student, profiles/r05_run11_mbx_ab_v4b.txt --
+                       the depthwise is VALU-bound, so a second pass over it costs more than the map's round trip through HBM);
+          "recompute": a second pass that recomputes expand + depthwise, applies the gate and projects -- the expanded tensor
+                       never exists in HBM (0.134 against 0.097 ms per 256 faces for the cheapest case, 80 -> 480 -> 112 with 3 x 3).
         ``waves``: 16 or 8 waves per workgroup for the launches that have both flavours (A/B aid)."""
         ti = self.tensors[x]
         mid, cin = w_exp.shape[:2]
@@ -617,7 +618,7 @@ class ProgramBuilder:
             self._op(OP_MBX, [x, out, res, -1, -1] + common + [0, waves], [self._tb(x), self._tb(res)], [self._tb(out)])
             return out
         if se_mode is None:
-            se_mode = "store" if k == 5 else "recompute"
+            se_mode = "store"
         assert se_mode in ("recompute", "store")
         w_rd, b_rd, w_ex, b_ex = se_fcs
         gap = self.buffer(mid, ELEM_F32, "gap")

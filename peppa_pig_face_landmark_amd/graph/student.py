@@ -126,7 +126,7 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
     if fuse_mbx is None:       # the input-stationary block kernels of stages 3-5 (16 x 16 maps at 256 x 256; csrc/k_mbx.h): on with the other fusions
-        fuse_mbx = fuse_mbconv     # mbx_se: None = ir.mbx's choice per block ("recompute" for 3 x 3, "store" for 5 x 5), or force one (A/B aid)
+        fuse_mbx = fuse_mbconv     # mbx_se: None = ir.mbx's choice ("store"), or "recompute" / "store" for every SE block (A/B aid)
     w = weights
     pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
 

@@ -77,7 +77,7 @@ def test_fused_blocks_match_unfused_gpu(gpu_engine, student_weights, size, batch
     _check(gpu_engine, student_weights, size, batch)
 
 
-def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=10, **mbx_kw):
+def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=8, **mbx_kw):
     """Stages 3-5 at 16 x 16 through the input-stationary block kernel (csrc/k_mbx.h, PF_OP_MBX: non-SE blocks in one launch, SE
     blocks as squeeze pass + FCs + either a recompute-gate-project pass or the layer-wise projection on the map the squeeze pass
     stored) against the same program with those blocks as expand + depthwise launch -> gated projection (fuse_mbx=False): the
@@ -117,9 +117,9 @@ def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=10, **m
     assert np.isfinite(res[True][1]).all()
 
 
-_MBX_VARIANTS = [({}, 10),                                       # default: 3 x 3 SE blocks recompute (16 waves), 5 x 5 SE blocks store
-                 ({"mbx_se": "recompute"}, 13),                  # every SE block: squeeze pass + 8- / 16-wave recompute pass
-                 ({"mbx_se": "store", "mbx_waves": 8}, 8)]      # every SE block stores; the non-SE blocks on 8 waves
+_MBX_VARIANTS = [({}, 8),                                        # default: non-SE blocks in one launch, SE blocks squeeze-and-store + layer-wise projection
+                 ({"mbx_se": "recompute"}, 13),                  # every SE block: squeeze pass + 8- / 16-wave recompute-gate-project pass
+                 ({"mbx_waves": 8}, 8)]                          # the non-SE blocks on 8 waves
 
 
 @pytest.mark.parametrize("kw,n_mbx", _MBX_VARIANTS)
