@@ -122,7 +122,7 @@ _MBX_VARIANTS = [({}, 8),                                        # default: non-
                  ({"mbx_waves": 8}, 8)]                          # the non-SE blocks on 8 waves
 
 
-@pytest.mark.parametrize("kw,n_mbx", _MBX_VARIANTS)
+@pytest.mark.parametrize("kw,n_mbx", [_MBX_VARIANTS[0], ({"mbx_se": "recompute", "mbx_waves": 8}, 13)])      # (the 16-wave recompute pass: GPU tier)
 def test_mbx_blocks_match_layerwise_emu(emu_engine, student_weights, kw, n_mbx):
     _mbx_vs_layerwise(emu_engine, student_weights, 7, True, n_mbx=n_mbx, **kw)      # 7 faces on the emulator's 5 workgroups: the face loop runs
 
