@@ -106,10 +106,6 @@ def tag_flops_per_face(tag: str):
         # algorithmic work of the launch: expand + depthwise (pass A and, recomputed, pass B count once each: what the launch does
         # for the block's result is expand + depthwise + projection; the squeeze pass is priced as expand + depthwise)
         return 2.0 * h * w * mid * (c + k * k + (0 if mode in ("A", "S") else n))
-    m = re.fullmatch(r"mbxP_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)      # per-face gated projection on the stored map (mbp_kernel)
-    if m:
-        c, n, h, w = map(int, m.groups())
-        return 2.0 * h * w * c * n
     m = re.fullmatch(r"expdw(\d)x\d[ds]\d_c(\d+)_n(\d+)_(\d+)x(\d+)", tag)   # expand C -> N + depthwise KxK on N
     if m:
         k, c, n, h, w = map(int, m.groups())
@@ -148,7 +144,6 @@ def parse_args():
     ap.add_argument("--mbx", default="default", choices=["default", "off", "recompute", "store"],
                     help="A/B aid for the Student's 16 x 16 inverted-residual blocks (csrc/k_mbx.h): off = the layer-wise expand + depthwise / "
                          "projection launches, recompute / store = force one SE strategy for every SE block; default: the builder's choice")
-    ap.add_argument("--mbx-layerwise-proj", action="store_true", help="A/B aid: the SE blocks' gated projections through the layer-wise pointwise GEMM instead of the per-face kernel")
     ap.add_argument("--mbx-waves", type=int, default=16, choices=[8, 16], help="A/B aid: waves per workgroup of the block kernels that have both flavours")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-kernel HIP-event pass after the timed steps (lane sweeps, "
                     "rocprofv3 traces of the multi-lane steady state); roofline is null then")
@@ -452,8 +447,6 @@ def main():
             skw["mbx_se"] = args.mbx
         if args.mbx_waves != 16:
             skw["mbx_waves"] = args.mbx_waves
-        if args.mbx_layerwise_proj:
-            skw["mbx_proj"] = False
     blobs = bs.build_programs(workload, args.dtype, args.model, **skw) if rank == 0 else None
     slots = [PF_NET_LANDMARK] + ([PF_NET_DETECTOR] if workload == "pipeline" else [])
 

@@ -872,18 +872,6 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         const int shape = KS == 3 ? 0 : (KS == 4 ? (K == 3 ? 1 : 2) : 3);
                         a.prof = h->d_dbg + 160 + 8 * (shape * 4 + mode);
                     }
-                    if (mode == 4) {             // gated projection on the stored map: in_t = the activated depthwise output
-                        if (ti.H != 16 || ti.W != 16 || ti.C < a.CEXP || (ti.ld & 1) || a.T < 1 || a.CEXP > 32 * a.T || a.CEXP > 1024 || !a.out || !a.gate || !a.w2 || !a.b2 ||
-                            (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)) || (Cout != 112 && Cout != 160))
-                            PF_FAIL(h, "mbx(mode 4): unsupported shape (%dx%dx%d -> %d)", ti.H, ti.W, ti.C, Cout);
-                        char tagbuf4[96];
-                        tagbuf4[0] = 0;
-                        if (h->profiling) snprintf(tagbuf4, sizeof(tagbuf4), "mbxP_c%d_n%d_16x16", a.CEXP, Cout);
-                        ProfScope ps4(h, tagbuf4);
-                        const int lrc4 = pf_mbx_launch(a, 8, KS, Cout, K, dil, 4, persistent_grid(B, 1), h->stream);
-                        if (lrc4 != 0) PF_FAIL(h, "launch of mbp_kernel failed: %s", lrc4 > 0 ? hipGetErrorString((hipError_t)lrc4) : "no instantiation");
-                        break;
-                    }
                     if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 3 ||
                         (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T || (nw != 8 && nw != 16) ||
                         (proj && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||

@@ -204,13 +204,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
+            pf_half8 eq[2][2];                              // weight fragments of step (s, j): requested one step ahead, as in project()
+            {
+                const int off = pf_lds_chunk_off(pcol, kg);
+                eq[0][0] = *reinterpret_cast<const pf_half8*>(wsrc + off);
+                eq[0][1] = *reinterpret_cast<const pf_half8*>(wsrc + 2048 + off);
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int off = s * 4096 + pf_lds_chunk_off(j * 16 + pcol, kg);
-                    const pf_half8 wh = *reinterpret_cast<const pf_half8*>(wsrc + off);
-                    const pf_half8 wl = *reinterpret_cast<const pf_half8*>(wsrc + 2048 + off);
+                    constexpr int dummy = 0; (void)dummy;
+                    const int step = s * 2 + j;
+                    if (step + 1 < 2 * KS) {
+                        const int s1 = (step + 1) >> 1, j1 = (step + 1) & 1;
+                        const int off = s1 * 4096 + pf_lds_chunk_off(j1 * 16 + pcol, kg);
+                        eq[(step + 1) & 1][0] = *reinterpret_cast<const pf_half8*>(wsrc + off);
+                        eq[(step + 1) & 1][1] = *reinterpret_cast<const pf_half8*>(wsrc + 2048 + off);
+                    }
+                    const pf_half8 wh = eq[step & 1][0], wl = eq[step & 1][1];
                     if (pf_dbg(a) & 4) continue;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) acc[i][j] = pf_mfma_16x16x32_f16(wl, xh[i][s], acc[i][j]);      // small terms first
@@ -246,11 +258,22 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                     dh[i] = *reinterpret_cast<const pf_half8*>(dsrc + off);
                     dl[i] = *reinterpret_cast<const pf_half8*>(dsrc + 16384 + off);
                 }
+                // the weight fragments of channel tile j + 1 are requested in front of tile j's MFMAs and no further ahead (the compiler
+                // fence): their LDS latency hides behind six MFMAs instead of standing in front of every tile's chain
+                pf_half8 wq[2][2];
+                {
+                    const int off = pf_lds_chunk_off(pcol, kg);
+                    wq[0][0] = *reinterpret_cast<const pf_half8*>(w2s + off);
+                    wq[0][1] = *reinterpret_cast<const pf_half8*>(w2s + COUT * 64 + off);
+                }
 #pragma unroll
                 for (int j = 0; j < NTO; ++j) {
-                    const int off = pf_lds_chunk_off(j * 16 + pcol, kg);
-                    const pf_half8 wh = *reinterpret_cast<const pf_half8*>(w2s + off);
-                    const pf_half8 wl = *reinterpret_cast<const pf_half8*>(w2s + COUT * 64 + off);
+                    if (j + 1 < NTO) {
+                        const int off = pf_lds_chunk_off((j + 1) * 16 + pcol, kg);
+                        wq[(j + 1) & 1][0] = *reinterpret_cast<const pf_half8*>(w2s + off);
+                        wq[(j + 1) & 1][1] = *reinterpret_cast<const pf_half8*>(w2s + COUT * 64 + off);
+                    }
+                    const pf_half8 wh = wq[j & 1][0], wl = wq[j & 1][1];
                     if (pf_dbg(a) & 4) continue;
 #pragma unroll
                     for (int i = 0; i < MT; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wl, dh[i], oacc[i][j]);     // small terms first
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                     for (int i = 0; i < MT; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wh, dl[i], oacc[i][j]);
 #pragma unroll
                     for (int i = 0; i < MT; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wh, dh[i], oacc[i][j]);
-                    asm volatile("" ::: "memory");          // one channel tile's weight fragments in flight at a time (register footprint)
+                    asm volatile("" ::: "memory");
                 }
             }
         };
@@ -459,161 +482,3 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     pf_amax_commit(a.range_slot, amax, amax_seen);
 }
 
-
-// ---- the gated projection of an SE block on the map its squeeze-and-store pass left in HBM (PF_OP_MBX mode 4, round 5) ------------------
-// out = W2 . (gate (.) D) + b2 (+ residual), D = [B][256][dLd] f32 (the activated depthwise output), gate = [B][CEXP].  The layer-wise
-// kernel (conv_gemm_split_kernel<128, 160, ...>: 512 workgroups of 128 pixels, K loop of 30 two-barrier steps each waiting for pixel loads it
-// issued one or two steps earlier) runs 960 -> 160 in 85 us per 256 faces = 2.9 TB/s of the map it reads; the matrix work is 24 us.  Here,
-// as in mbx_kernel, ONE persistent 8-wave workgroup owns a face: the 2 x NTO x 4 accumulators of a wave's two image rows stay in
-// registers, and per 32-channel tile
-//   project(t - 1)  from the split planes and weight stage of tile t - 1 (matrix cores)
-// | gate-and-split(t): the thread's 8 pixels x 2 channels of tile t -- global loads issued TWO phases earlier into one of two register
-//                      sets -- x gate (the face's whole gate vector sits in LDS) -> f16 hi / lo -> planes[t & 1];
-// then "s_waitcnt vmcnt(0)", and only THEN the requests of the phase: the map values of tile t + 2 (into the register set gate-and-split
-// just emptied) and the LDS-DMA of W2(t + 1) (three weight stages).  Waiting before issuing means every wait is a full drain of requests
-// that have had a whole phase to land -- no hand-counted partial vmcnt, like the rest of this file.
-template <int NTO>
-__global__ __launch_bounds__(512, 2) void mbp_kernel(MbxArgs a) {
-    constexpr int COUT = NTO * 16;
-    constexpr int D_BYTES = 32768;                          // hi plane 256 x 64 B + lo plane
-    constexpr int W2_BYTES = COUT * 128;
-    constexpr int G_BYTES = 4096;                           // the face's gate vector (CEXP <= 1024)
-    static_assert(2 * D_BYTES + 3 * W2_BYTES + G_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * D_BYTES + 3 * W2_BYTES + G_BYTES];
-    unsigned char* const dbase = smem;
-    unsigned char* const w2s = smem + 2 * D_BYTES;
-    float* const gs = reinterpret_cast<float*>(w2s + 3 * W2_BYTES);
-    PF_EMU_POISON(smem);
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int T = a.T;
-    unsigned amax = 0;
-    const unsigned amax_seen = pf_amax_seen(a.range_slot);
-    auto dma_w2 = [&](int tile) {                           // slot -> [plane][row][position], chunk rotation on the SOURCE
-        const int tt = pf_opaque(t);
-        const unsigned char* sb = a.w2 + (size_t)tile * 128;
-        unsigned char* dst = w2s + (tile % 3) * W2_BYTES;
-#pragma unroll
-        for (int r = 0; r < (COUT * 8 + 511) / 512; ++r) {
-            const int sl = r * 512 + tt;
-            if (sl < COUT * 8) {
-                const int plane = sl >= COUT * 4 ? 1 : 0;
-                const int row = (sl - plane * COUT * 4) >> 2;
-                const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                pf_glds16_raw_soff<0>(sb, (unsigned)(row * T * 128 + plane * 64 + chunk * 16), dst + (size_t)sl * 16);
-            }
-        }
-    };
-    for (int face = blockIdx.x; face < a.B; face += gridDim.x) {
-        const float* __restrict__ dmap = a.in + (size_t)face * 256 * a.inLd;
-        pf_f32x2 dv[2][8];                                  // two register sets: this thread's 8 pixels x 2 channels of a tile
-        auto load_d = [&](int tile, pf_f32x2 (&d)[8]) {     // thread = (channel pair, image row, half row), as mbx_kernel's depthwise
-            const int tt = pf_opaque(t);
-            const int c2 = (tt & 15) * 2, part = (tt >> 4) & 1, yrow = tt >> 5;
-            const float* p = dmap + (size_t)(yrow * 16 + 8 * part) * a.inLd + tile * 32 + c2;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) d[x] = *reinterpret_cast<const pf_f32x2*>(p + (size_t)x * a.inLd);
-        };
-        auto gate_split = [&](int tile, const pf_f32x2 (&d)[8]) {
-            const int tt = pf_opaque(t);
-            const int c2 = (tt & 15) * 2, part = (tt >> 4) & 1, yrow = tt >> 5;
-            const pf_f32x2 g = *reinterpret_cast<const pf_f32x2*>(gs + tile * 32 + c2);
-            unsigned char* dp = dbase + (tile & 1) * D_BYTES + (yrow * 16 + 8 * part) * 64 + (c2 & 7) * 2;
-            unsigned char* const dp0 = dp + ((c2 >> 3) & 3) * 16;
-            unsigned char* const dp1 = dp + (((c2 >> 3) + 2) & 3) * 16;
-#pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const float v0 = d[x][0] * g[0], v1 = d[x][1] * g[1];
-                pf_half2 hi, lo;
-                hi[0] = (pf_half)v0; hi[1] = (pf_half)v1;
-                lo[0] = (pf_half)(v0 - (float)hi[0]); lo[1] = (pf_half)(v1 - (float)hi[1]);
-                amax = pf_amax(pf_amax(amax, v0), v1);
-                unsigned char* q = (x < 4 ? dp0 : dp1) + x * 64;
-                *reinterpret_cast<pf_half2*>(q) = hi;
-                *reinterpret_cast<pf_half2*>(q + 16384) = lo;
-            }
-        };
-        pf_f32x4 oacc[2][NTO];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < NTO; ++j) oacc[i][j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-        auto project = [&](int tile) {
-            const int tt = pf_opaque(t);
-            const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
-            const unsigned char* dsrc = dbase + (tile & 1) * D_BYTES;
-            const unsigned char* wsrc = w2s + (tile % 3) * W2_BYTES;
-            pf_half8 dh[2], dl[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int off = pf_lds_chunk_off(wv * 32 + i * 16 + pcol, kg);
-                dh[i] = *reinterpret_cast<const pf_half8*>(dsrc + off);
-                dl[i] = *reinterpret_cast<const pf_half8*>(dsrc + 16384 + off);
-            }
-#pragma unroll
-            for (int j = 0; j < NTO; ++j) {
-                const int off = pf_lds_chunk_off(j * 16 + pcol, kg);
-                const pf_half8 wh = *reinterpret_cast<const pf_half8*>(wsrc + off);
-                const pf_half8 wl = *reinterpret_cast<const pf_half8*>(wsrc + COUT * 64 + off);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wl, dh[i], oacc[i][j]);     // small terms first
-#pragma unroll
-                for (int i = 0; i < 2; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wh, dl[i], oacc[i][j]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) oacc[i][j] = pf_mfma_16x16x32_f16(wh, dh[i], oacc[i][j]);
-                asm volatile("" ::: "memory");
-            }
-        };
-        // prologue: the gate vector, the map values of tiles 0 and 1, the weights of tile 0
-        for (int i = t; i < T * 32; i += 512) gs[i] = i < a.CEXP ? a.gate[(size_t)face * a.CEXP + i] : 0.f;
-        load_d(0, dv[0]);
-        if (T > 1) load_d(1, dv[1]);
-        dma_w2(0);
-        pf_wait_vm_barrier<0>();
-        auto phase = [&](int tile, pf_f32x2 (&d)[8]) {      // `d` holds tile `tile`; it is refilled with tile + 2 at the end
-            if (wave < 4) {
-                if (tile >= 1) project(tile - 1);
-                gate_split(tile, d);
-            } else {
-                gate_split(tile, d);
-                if (tile >= 1) project(tile - 1);
-            }
-            pf_wait_vm_all();                                   // what the previous phase requested (it has had this whole phase to land)
-            if (tile + 2 < T) load_d(tile + 2, d);
-            if (tile + 1 < T) dma_w2(tile + 1);                 // stage (tile + 1) % 3: last read by project(tile - 2), one barrier ago
-            pf_barrier_lds();
-        };
-        for (int tile = 0; tile < T; tile += 2) {
-            phase(tile, dv[0]);
-            if (tile + 1 < T) phase(tile + 1, dv[1]);
-        }
-        // ---- block output = acc * scale2 + bias (+ residual); the residual vectors are requested before the last tile's projection ----
-        const int tt = pf_opaque(t);
-        const int pcol = tt & 15, kg = (tt >> 4) & 3, wv = tt >> 6;
-        pf_f32x4 rv[2][NTO];
-        if (a.res) {
-            const float* __restrict__ rrow = a.res + ((size_t)face * 256 + wv * 32 + pcol) * a.resLd + kg * 4;
-#pragma unroll
-            for (int j = 0; j < NTO; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) rv[i][j] = *reinterpret_cast<const pf_f32x4*>(rrow + (size_t)i * 16 * a.resLd + j * 16);
-        }
-        project(T - 1);
-        float* __restrict__ orow = a.out + ((size_t)face * 256 + wv * 32 + pcol) * a.outLd + kg * 4;
-#pragma unroll
-        for (int j = 0; j < NTO; ++j) {
-            const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(a.b2 + j * 16 + kg * 4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                pf_f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(oacc[i][j][r], a.scale2, bv[r]);
-                if (a.res) v += rv[i][j];
-                *reinterpret_cast<pf_f32x4*>(orow + (size_t)i * 16 * a.outLd + j * 16) = v;
-            }
-        }
-        pf_wait_vm_barrier<0>();      // the next face's prologue rewrites the gate vector and stage 0 of the weights, which the trailing project may still read
-    }
-    (void)lane;
-    pf_amax_commit(a.range_slot, amax, amax_seen);
-}

@@ -7,11 +7,6 @@
 #include "k_mbx.h"
 
 int pf_mbx_launch(const MbxArgs& a, int nw, int KS, int Cout, int K, int dil, int mode, int grid, hipStream_t stream) {
-    if (mode == 4) {            // the gated projection of an SE block on the stored map (mbp_kernel)
-        if (Cout == 112) { hipLaunchKernelGGL((mbp_kernel<7>), dim3(grid), dim3(512), 0, stream, a); return (int)hipGetLastError(); }
-        if (Cout == 160) { hipLaunchKernelGGL((mbp_kernel<10>), dim3(grid), dim3(512), 0, stream, a); return (int)hipGetLastError(); }
-        return -1;
-    }
     const bool proj = mode == 0 || mode == 2;
 #define PF_MBX_CASE(NW_, KS_, NTO_, K_, DIL_, MODE_)                                                                         \
     if (nw == NW_ && KS == KS_ && K == K_ && dil == DIL_ && mode == MODE_ && (!proj || Cout == 16 * NTO_)) {                 \

@@ -106,11 +106,6 @@ template <int N> __device__ __forceinline__ void pf_wait_vm_barrier() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(PF_STRICT_WAITS ? 0 : N) : "memory");
 }
 
-// the two halves of pf_wait_vm_barrier for kernels that wait BEFORE they issue a phase's requests: "everything this wave has requested so
-// far has landed" ... (requests of the next phase) ... "my LDS writes are done; rendezvous"
-__device__ __forceinline__ void pf_wait_vm_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void pf_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // Nothing is scheduled across this point (machine scheduler only): the steps of a completely unrolled K loop are one basic block,
 // and without fences the scheduler drags address arithmetic and epilogue set-up of later steps to the front until registers spill.
 __device__ __forceinline__ void pf_sched_fence() { __builtin_amdgcn_sched_barrier(0); }

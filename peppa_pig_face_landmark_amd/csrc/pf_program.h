@@ -75,8 +75,7 @@ enum PfOpCode : int32_t {
                         //    bits) mode waves(8 | 16): a whole inverted-residual block at 16 x 16 with the face's input stationary in registers and
                         //    the expanded tile in LDS (k_mbx.h mbx_kernel); mode 0 = block without squeeze-excite, 1 = expand + depthwise -> per-face
                         //    channel means into gap_buf (the SE squeeze), 2 = expand + depthwise recomputed, x gate_buf, projected (+ res), 3 = mode 1
-                        //    + the activated depthwise map stored in out_t, 4 = the gated projection on such a stored map (in_t = the map; k_mbx.h mbp_kernel);
-                        //    split programs only
+                        //    + the activated depthwise map stored in out_t (for the layer-wise gated projection); split programs only
     PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1])
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };

@@ -595,7 +595,7 @@ class ProgramBuilder:
     MBX_RECOMPUTE_16 = {(3, 7, 3, 1), (4, 7, 3, 1)}     # (KS, Cout / 16, k, dil) whose gate-and-project pass fits 16 waves x 128 registers
 
     def mbx(self, x: int, w_exp, b_exp, w_dw, b_dw, w_pwl, b_pwl, act: str, *, pad: int, dil: int = 1, res: int = -1,
-            se_fcs=None, se_mode: Optional[str] = None, waves: int = 16, proj_kernel: bool = True, out_name: str = "", dw_name: str = "") -> int:
+            se_fcs=None, se_mode: Optional[str] = None, waves: int = 16, out_name: str = "", dw_name: str = "") -> int:
         """Inverted-residual block (expand 1x1 -> depthwise kxk -> [SE] -> project 1x1 [+ res]) on a 16 x 16 map, weights BN-folded.
         Without SE: one launch.  With SE (``se_fcs`` = (w_reduce [R,Mid], b_reduce, w_expand [Mid,R], b_expand)) a squeeze pass
         (expand + depthwise -> per-face channel means), the two FCs, then by ``se_mode``
@@ -604,8 +604,7 @@ class ProgramBuilder:
                        the depthwise is VALU-bound, so a second pass over it costs more than the map's round trip through HBM);
           "recompute": a second pass that recomputes expand + depthwise, applies the gate and projects -- the expanded tensor
                        never exists in HBM (0.134 against 0.097 ms per 256 faces for the cheapest case, 80 -> 480 -> 112 with 3 x 3).
-        ``waves``: 16 or 8 waves per workgroup for the launches that have both flavours (A/B aid); ``proj_kernel=False``: the stored
-        map goes through the layer-wise pointwise GEMM instead of the per-face projection kernel (A/B aid)."""
+        ``waves``: 16 or 8 waves per workgroup for the launches that have both flavours (A/B aid)."""
         ti = self.tensors[x]
         mid, cin = w_exp.shape[:2]
         cout, k = w_pwl.shape[0], w_dw.shape[2]
@@ -629,11 +628,6 @@ class ProgramBuilder:
             self._op(OP_MBX, [x, dwt, -1, gap, -1] + common + [3, 16], [self._tb(x)], [self._tb(dwt), gap])
             hid = self.fc(gap, w_rd, b_rd, "relu")
             gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
-            if proj_kernel and cout in (112, 160) and mid <= 1024:
-                # the gated projection as a persistent per-face kernel too (csrc/k_mbx.h mbp_kernel, mode 4)
-                out = self.tensor(ti.H, ti.W, cout, name=out_name)
-                self._op(OP_MBX, [dwt, out, res, -1, gate] + common + [4, 8], [self._tb(dwt), self._tb(res), gate], [self._tb(out)])
-                return out
             return self.conv(dwt, w_pwl, b_pwl, "none", res=res, gate_buf=gate, out_name=out_name)
         out = self.tensor(ti.H, ti.W, cout, name=out_name)
         self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1, 16], [self._tb(x)], [gap])

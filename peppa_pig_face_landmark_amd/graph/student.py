@@ -121,7 +121,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
                           keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True, fuse_front: bool = False,
-                          fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16, mbx_proj: bool = True):
+                          fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
@@ -185,7 +185,7 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                     fcs = (rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"],
                            ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"])
                 x = pb.mbx(x, we, be, wd, bd, wl, bl, act, pad=pad, dil=cur_dil, res=inp if skip else -1, se_fcs=fcs,
-                           se_mode=mbx_se, waves=mbx_waves, proj_kernel=mbx_proj, out_name=f"{p}.out", dw_name=f"{p}.dw")
+                           se_mode=mbx_se, waves=mbx_waves, out_name=f"{p}.out", dw_name=f"{p}.dw")
             elif (fuse_mbconv and not se and pb.mbconv_supported(cin, k, s, cur_dil, cout)
                   and not pb.expdw_supported(pb.tensors[x].H, pb.tensors[x].W, k, s, pad, cur_dil)):
                 we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))

@@ -117,8 +117,6 @@ template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the 
 
 inline int pf_opaque(int v) { return v; }
 inline int pf_uniform_i32(int v) { return v; }
-inline void pf_wait_vm_all() {}
-inline void pf_barrier_lds() { __syncthreads(); }
 inline void pf_sched_fence() {}
 inline void pf_pin(unsigned&) {}
 inline unsigned long long pf_clock() { return 0; }

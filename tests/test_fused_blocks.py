@@ -77,7 +77,7 @@ def test_fused_blocks_match_unfused_gpu(gpu_engine, student_weights, size, batch
     _check(gpu_engine, student_weights, size, batch)
 
 
-def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=13, **mbx_kw):
+def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=8, **mbx_kw):
     """Stages 3-5 at 16 x 16 through the input-stationary block kernel (csrc/k_mbx.h, PF_OP_MBX: non-SE blocks in one launch, SE
     blocks as squeeze pass + FCs + either a recompute-gate-project pass or the layer-wise projection on the map the squeeze pass
     stored) against the same program with those blocks as expand + depthwise launch -> gated projection (fuse_mbx=False): the
@@ -117,9 +117,9 @@ def _mbx_vs_layerwise(eng, weights, batch, keep_all, on_gpu=False, n_mbx=13, **m
     assert np.isfinite(res[True][1]).all()
 
 
-_MBX_VARIANTS = [({}, 13),                                       # default: non-SE blocks in one launch; SE blocks squeeze-and-store + per-face gated projection
+_MBX_VARIANTS = [({}, 8),                                        # default: non-SE blocks in one launch, SE blocks squeeze-and-store + layer-wise projection
                  ({"mbx_se": "recompute"}, 13),                  # every SE block: squeeze pass + 8- / 16-wave recompute-gate-project pass
-                 ({"mbx_waves": 8, "mbx_proj": False}, 8)]       # the non-SE blocks on 8 waves, the stored maps through the layer-wise pointwise GEMM
+                 ({"mbx_waves": 8}, 8)]                          # the non-SE blocks on 8 waves
 
 
 @pytest.mark.parametrize("kw,n_mbx", [_MBX_VARIANTS[0], ({"mbx_se": "recompute", "mbx_waves": 8}, 13)])      # (the 16-wave recompute pass: GPU tier)
