@@ -15,7 +15,8 @@
 //   depthwise(t)  k x k taps (dilation DIL, zero padding) on E out of LDS, thread = (channel pair, image row, 64 / NW pixels of the row),
 //                 f32 fma in the order of the unfused kernel -- as SCALAR v_fma / v_fmac: this kernel lives in its own translation unit
 //                 (mbx_launch.cpp, built with -fno-slp-vectorize) because hipcc's SLP vectoriser packs the channel pair into
-//                 v_pk_fma_f32, which measured ~4x slower per flop here --, + bias, activation, then by MODE
+//                 v_pk_fma_f32 -- which costs as much as the two scalar fma it replaces -- and pays for it with a register shuffle
+//                 (v_mov) per operand: the stream doubles --, + bias, activation, then by MODE
 //                   0 / 2  (x SE gate) -> split hi / lo -> the pixel-operand planes D[t & 1] in LDS,
 //                   1 / 3  per-thread sums -> LDS -> per-face channel means (the SE squeeze); MODE 3 also stores the activated map (f32) for
 //                          the layer-wise gated projection;
@@ -36,7 +37,8 @@
 // What the first cuts taught (profiles/r05_run3 ... r05_run9):
 //   * 8 waves only (two per SIMD): a single wave issues one VALU instruction per ~4 cycles, so with its SIMD partner in a matrix job the
 //     VALU ran half empty -- depthwise 7 k cycles per tile and wave against 3.3 k of instruction issue;
-//   * v_pk_fma_f32 taps: ~4x slower per flop than scalar v_fmac;
+//   * v_pk_fma_f32 taps as the SLP vectoriser builds them: 200 packed fma + 210 v_mov per thread and tile instead of 400 scalar fma; written
+//     by hand on the natural pairs (no shuffles) they measure the same as the scalar form: a packed f32 fma costs two scalar ones;
 //   * breaking the vectoriser's pairs with asm statements in the fma stream gave RUN-TO-RUN DIFFERENT results on MI355X (the hazard
 //     recogniser does not see through asm statements); the translation-unit flag is the fix;
 //   * residual vectors added load by load between the stores of the epilogue: twenty dependent round trips (52 us per launch);

@@ -1,9 +1,10 @@
 // Translation unit of the input-stationary inverted-residual block kernel (k_mbx.h), built with -fno-slp-vectorize
-// (peppa_pig_face_landmark_amd/build.py; the CPU test build of the same sources does likewise): hipcc's SLP vectoriser packs the depthwise taps of a
-// thread's channel pair into v_pk_fma_f32, which runs far below two scalar v_fma_f32 on gfx950 (MI355X_MICROARCH.md: "an
-// anti-lever"; ~4x per flop measured in this kernel, profiles/r05_run3_mbx_phase_cycles_first_cut.txt).  Breaking the pairs with
-// asm statements inside the fma stream is NOT an option: with ~400 of them per phase the results differed from run to run on
-// MI355X (the hazard recogniser does not see through asm statements; profiles/r05_run5_mbx_determinism.txt, r05_run6).
+// (peppa_pig_face_landmark_amd/build.py; the CPU test build of the same sources does likewise): hipcc's SLP vectoriser packs the
+// depthwise taps of a thread's channel pair into v_pk_fma_f32 and shuffles registers to feed them -- 200 packed fma + 210 v_mov per
+// thread and tile where 400 scalar v_fmac do (a packed f32 fma costs two scalar ones on gfx950: MI355X_MICROARCH.md calls it an
+// anti-lever; profiles/r05_run17_mbx_ab_packed_taps.txt).  Breaking the pairs with asm statements inside the fma stream is NOT an
+// option: with ~400 of them per phase the results differed from run to run on MI355X (the hazard recogniser does not see through asm
+// statements; profiles/r05_run5_mbx_determinism.txt, r05_run6).
 #include "k_mbx.h"
 
 int pf_mbx_launch(const MbxArgs& a, int nw, int KS, int Cout, int K, int dil, int mode, int grid, hipStream_t stream) {
