@@ -16,8 +16,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpeppa_hip.so")
 SOURCES = ["engine.cpp", "mbx_launch.cpp"]
-# per-source extra flags: k_mbx.h's depthwise taps must stay scalar v_fma_f32 (see csrc/mbx_launch.cpp)
-SOURCE_FLAGS = {"mbx_launch.cpp": ["-fno-slp-vectorize"]}
+# No SLP vectoriser anywhere: on gfx950 a v_pk_fma_f32 costs what two v_fma_f32 cost, so pairing scalar f32 work buys nothing
+# and the v_mov shuffles that feed the pairs are pure loss (the VALU-heavy depthwise / unit kernels measure 5-13 % faster
+# without it, the whole pipeline ~2 %: profiles/r05_run19_noslp_whole_library.txt, r05_run20_noslp_headline_ab.txt).  For
+# k_mbx.h's depthwise taps it is a requirement, not a preference (see csrc/mbx_launch.cpp).
+COMMON_FLAGS = ["-fno-slp-vectorize"]
+SOURCE_FLAGS = {}            # per-source extras
 STAMP = os.path.join(HERE, "libpeppa_hip.srchash")
 
 
@@ -38,6 +42,7 @@ def source_hash() -> str:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
+    h.update(repr((COMMON_FLAGS, sorted(SOURCE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -69,7 +74,7 @@ def build_hip(force: bool = False, verbose: bool = True, ablate: bool = False, f
             return out
         if not flavour and not needs_build():
             return out
-    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC] + defs
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-I", CSRC] + COMMON_FLAGS + defs
     objs, procs = [], []
     for src in SOURCES:                       # one object per translation unit, compiled side by side, then one link
         obj = out + "." + os.path.splitext(src)[0] + ".o"

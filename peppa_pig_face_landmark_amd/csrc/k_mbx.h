@@ -13,8 +13,8 @@
 //   expand(t)     E = act(W1[t] . x + b1) on the matrix cores (3 x v_mfma_f32_16x16x32_f16 per product, f32 accumulate), the 32 x (KS x 32)
 //                 pre-split weight rows from an LDS stage (LDS-DMA), E -> LDS as f32 [256 px][ES];
 //   depthwise(t)  k x k taps (dilation DIL, zero padding) on E out of LDS, thread = (channel pair, image row, 64 / NW pixels of the row),
-//                 f32 fma in the order of the unfused kernel -- as SCALAR v_fma / v_fmac: this kernel lives in its own translation unit
-//                 (mbx_launch.cpp, built with -fno-slp-vectorize) because hipcc's SLP vectoriser packs the channel pair into
+//                 f32 fma in the order of the unfused kernel -- as SCALAR v_fma / v_fmac: the library is built with
+//                 -fno-slp-vectorize (build.py; see mbx_launch.cpp) because hipcc's SLP vectoriser packs the channel pair into
 //                 v_pk_fma_f32 -- which costs as much as the two scalar fma it replaces -- and pays for it with a register shuffle
 //                 (v_mov) per operand: the stream doubles --, + bias, activation, then by MODE
 //                   0 / 2  (x SE gate) -> split hi / lo -> the pixel-operand planes D[t & 1] in LDS,

@@ -1,5 +1,5 @@
 // Arguments and host-side launcher of the input-stationary inverted-residual block kernel (k_mbx.h).  The kernel itself is
-// compiled in its own translation unit (mbx_launch.cpp) with -fno-slp-vectorize -- see k_mbx.h -- so engine.cpp sees only this.
+// compiled in its own translation unit (mbx_launch.cpp; the two units build in parallel), so engine.cpp sees only this.
 #pragma once
 #include <hip/hip_runtime.h>
 

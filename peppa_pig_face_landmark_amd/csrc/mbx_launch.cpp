@@ -1,5 +1,6 @@
-// Translation unit of the input-stationary inverted-residual block kernel (k_mbx.h), built with -fno-slp-vectorize
-// (peppa_pig_face_landmark_amd/build.py; the CPU test build of the same sources does likewise): hipcc's SLP vectoriser packs the
+// Translation unit of the input-stationary inverted-residual block kernel (k_mbx.h).  It MUST be built with -fno-slp-vectorize
+// (peppa_pig_face_landmark_amd/build.py now passes it to every source of the library -- the other VALU-heavy kernels gain 5-13 % from
+// it too, profiles/r05_run19_noslp_whole_library.txt -- but here it is a requirement): hipcc's SLP vectoriser packs the
 // depthwise taps of a thread's channel pair into v_pk_fma_f32 and shuffles registers to feed them -- 200 packed fma + 210 v_mov per
 // thread and tile where 400 scalar v_fmac do (a packed f32 fma costs two scalar ones on gfx950: MI355X_MICROARCH.md calls it an
 // anti-lever; profiles/r05_run17_mbx_ab_packed_taps.txt).  Breaking the pairs with asm statements inside the fma stream is NOT an
