@@ -340,7 +340,7 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     Program& p = h->prog[slot];
     constexpr int VE = PfVec<T>::N;
     const bool guard = SPLIT && h->range_every > 0 && p.d_range != nullptr;     // every call, graph-captured ones included
-    auto slot_of = [&](size_t oi) -> unsigned* { return guard ? p.d_range + oi * PF_RANGE_SUBSLOTS : nullptr; };
+    auto slot_of = [&](size_t oi) -> unsigned* { return guard ? p.d_range + oi * PF_RANGE_OP_WORDS : nullptr; };
     for (size_t oi = 0; oi < p.ops.size(); ++oi) {
         const PfOpRec& op = p.ops[oi];
         const int32_t* f = op.f;
@@ -1137,7 +1137,7 @@ int pf_create(int device_id, pf_handle** out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus >= 8) h->num_cus = cus;
     }
     if constexpr (PF_ABLATE != 0) {      // ablation build only (libpeppa_hip_ablate.so): ablated kernels compute garbage, so the guard is off
-        if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg) h->range_every = 0; }
+        if (const char* v = getenv("PEPPA_DBG")) { h->dbg = atoi(v); if (h->dbg & 0xffff) h->range_every = 0; }   // bits >= 16 only re-schedule (wave priorities): results stay right, the guard stays on
         if (const char* v = getenv("PEPPA_DET_TILE")) { if (sscanf(v, "%d,%d", &g_det_tile_th, &g_det_tile_tw) != 2) g_det_tile_th = g_det_tile_tw = 0; }
     }
     bool masked = false;
@@ -1293,7 +1293,7 @@ int pf_load_program(pf_handle* h, int slot, const void* blob, size_t bytes, int 
     PF_HIP(h, hipMalloc((void**)&p.d_arena, p.arena_bytes + 256));          // + slack: masked pixel-operand units may read up to 124 bytes behind a tensor
     PF_HIP(h, hipMemset(p.d_arena, 0, p.arena_bytes + 256));
     if (hd.dtype == PF_DTYPE_F32_SPLIT) {
-        const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_SUBSLOTS * sizeof(unsigned);
+        const size_t rb = std::max<size_t>(hd.n_ops, 1) * PF_RANGE_OP_WORDS * sizeof(unsigned);
         PF_HIP(h, hipMalloc((void**)&p.d_range, rb + PF_RANGE_TAIL_WORDS * sizeof(unsigned)));
         PF_HIP(h, hipMemset(p.d_range, 0, rb + PF_RANGE_TAIL_WORDS * sizeof(unsigned)));
         PF_HIP(h, hipMemset((char*)p.d_range + rb, 0xFF, 8));       // the verdict key: all ones = no violation (range_verdict_kernel)

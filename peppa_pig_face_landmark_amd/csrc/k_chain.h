@@ -251,7 +251,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void
     if (a.range_slot) {
         if (vbad) vmax = __builtin_inff();
         for (int mask = 1; mask < 64; mask <<= 1) vmax = fmaxf(vmax, pf_shfl_xor_f32(vmax, mask));
-        if (lane == 0 && vmax != 0.f) { unsigned* w = a.range_slot + (((blockIdx.x << 4) + (threadIdx.x >> 6)) & (PF_RANGE_SUBSLOTS - 1)); if (__float_as_uint(vmax) > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, __float_as_uint(vmax)); }
+        if (lane == 0 && vmax != 0.f) { unsigned* w = pf_amax_word(a.range_slot); if (__float_as_uint(vmax) > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, __float_as_uint(vmax)); }
     }
 }
 
@@ -543,6 +543,6 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
     if (a.range_slot) {
         if (vbad) vmax = __builtin_inff();
         for (int mask = 1; mask < 64; mask <<= 1) vmax = fmaxf(vmax, pf_shfl_xor_f32(vmax, mask));
-        if (lane == 0 && vmax != 0.f) { unsigned* w = a.range_slot + (((blockIdx.x << 4) + (threadIdx.x >> 6)) & (PF_RANGE_SUBSLOTS - 1)); if (__float_as_uint(vmax) > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, __float_as_uint(vmax)); }
+        if (lane == 0 && vmax != 0.f) { unsigned* w = pf_amax_word(a.range_slot); if (__float_as_uint(vmax) > __atomic_load_n(w, __ATOMIC_RELAXED)) atomicMax(w, __float_as_uint(vmax)); }
     }
 }

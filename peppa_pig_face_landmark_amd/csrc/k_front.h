@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
     __shared__ __attribute__((aligned(16))) pf_half s_il[F32IN ? MAXIH * RS : 8];
     PF_EMU_POISON(s_ih); PF_EMU_POISON(s_il);
     unsigned amax = 0;
-    const unsigned amax_seen = pf_amax_seen(a.range_slot);
+    const unsigned amax_seen = pf_amax_seen<false>(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const int oy0 = ((int)blockIdx.x / a.tilesX) * a.TH, ox0 = ((int)blockIdx.x % a.tilesX) * a.TW;

@@ -192,7 +192,17 @@ __global__ __launch_bounds__(256) void gap_kernel(GapArgs a) {
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
     if (cv < CV) {
         const T* in = static_cast<const T*>(a.in) + (size_t)b * a.HW * a.ld + cv * VE;
-        for (int p = prow; p < a.HW; p += 32) {
+        int p = prow;
+        for (; p + 7 * 32 < a.HW; p += 8 * 32) {          // eight rows requested before the first is added (same order of additions)
+            vec_t x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = pf_ldv<T>(in + (size_t)(p + 32 * j) * a.ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) acc[e] += (float)x[j][e];
+        }
+        for (; p < a.HW; p += 32) {
             const vec_t x = pf_ldv<T>(in + (size_t)p * a.ld);
 #pragma unroll
             for (int e = 0; e < VE; ++e) acc[e] += (float)x[e];
@@ -245,20 +255,56 @@ __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
     const int ks = t >> 6;
     const int n = blockIdx.x * PF_FC_BN + nl;
     const int b0 = blockIdx.y * PF_FC_BB;
-    const bool nok = n < a.N;
     float acc[PF_FC_BB];
 #pragma unroll
     for (int i = 0; i < PF_FC_BB; ++i) acc[i] = 0.f;
     const int kround = (a.K + PF_FC_KT - 1) / PF_FC_KT * PF_FC_KT;
+    // one k round of this thread: 32 weights (rows past K: the clamped row's finite weight meets a zero of xs; columns past N: the
+    // clamped column's result is dropped at the store) x the 8 staged vectors
+    const int nc = min(n, a.N - 1);
+    auto load_w = [&](int k0, float (&wv)[32]) {
+#pragma unroll
+        for (int j = 0; j < 32; ++j) wv[j] = a.wt[(size_t)min(k0 + ks * 32 + j, a.K - 1) * a.N + nc];
+    };
+    auto mac = [&](int xk0, const float (&wv)[32]) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int i = 0; i < PF_FC_BB; ++i) {
+                const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[i][xk0 + ks * 32 + 4 * q]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i] = fmaf(wv[4 * q + j], xv[j], acc[i]);
+            }
+        }
+    };
     if constexpr (WHOLE_K) {
-        if ((a.K & 3) == 0) {                  // 16-byte loads, 4 per thread in flight
+        // The kernel is a chain of load round trips (64-480 workgroups of a few hundred loads): the weights of FOUR k rounds (512 of K)
+        // are requested in one go, the first four before the input vectors are even staged, so an SE bottleneck FC (K up to 960) is
+        // two round trips instead of nine.  Same k -> thread assignment and order of additions as round by round.
+        constexpr int NR = 4;
+        float wv[NR][32];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (r * PF_FC_KT < a.K) load_w(r * PF_FC_KT, wv[r]);
+        if ((a.K & 3) == 0) {
+            // 16-byte loads, ALL of the thread's (up to 8) requested before the first is stored: loads from clamped addresses and a
+            // select, no branch around a load -- with one the compiler waits for every load before the next (7 serialized round
+            // trips for the K = 960 squeeze vectors, most of the kernel's time)
             const int k4 = kround / 4;
-#pragma unroll 4
-            for (int i = t; i < PF_FC_BB * k4; i += 256) {
+            constexpr int NV = PF_FC_BB * PF_FC_MAXK / 4 / 256;
+            pf_f32x4 v[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = t + 256 * j;
                 const int bb = i / k4, kk = (i - bb * k4) * 4;
-                pf_f32x4 v = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                if (b0 + bb < a.B && kk < a.K) v = *reinterpret_cast<const pf_f32x4*>(a.x + (size_t)(b0 + bb) * a.K + kk);
-                *reinterpret_cast<pf_f32x4*>(&xs[bb][kk]) = v;
+                v[j] = *reinterpret_cast<const pf_f32x4*>(a.x + (size_t)min(b0 + bb, a.B - 1) * a.K + min(kk, a.K - 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = t + 256 * j;
+                const int bb = i / k4, kk = (i - bb * k4) * 4;
+                if (i < PF_FC_BB * k4)
+                    *reinterpret_cast<pf_f32x4*>(&xs[bb][kk]) = (b0 + bb < a.B && kk < a.K) ? v[j] : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
         } else {
             for (int i = t; i < PF_FC_BB * kround; i += 256) {
@@ -267,34 +313,28 @@ __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
             }
         }
         __syncthreads();
-    }
-    for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
-        if constexpr (!WHOLE_K) {
+        for (int kb = 0; kb < a.K; kb += NR * PF_FC_KT) {
+            if (kb) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (kb + r * PF_FC_KT < a.K) load_w(kb + r * PF_FC_KT, wv[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                if (kb + r * PF_FC_KT < a.K) mac(kb + r * PF_FC_KT, wv[r]);
+        }
+    } else {
+        for (int k0 = 0; k0 < a.K; k0 += PF_FC_KT) {
             for (int i = t; i < PF_FC_BB * PF_FC_KT; i += 256) {
                 const int bb = i / PF_FC_KT, kk = i - bb * PF_FC_KT;
                 xs[bb][kk] = (b0 + bb < a.B && k0 + kk < a.K) ? a.x[(size_t)(b0 + bb) * a.K + k0 + kk] : 0.f;
             }
             __syncthreads();
-        }
-        const int xk0 = WHOLE_K ? k0 : 0;
-        if (nok) {
-            // all 32 weights of this thread's k slice are requested before the first FMA: the kernel is a chain of
-            // load latencies otherwise (64-240 workgroups, a few hundred loads each)
             float wv[32];
-            const float* wp = a.wt + (size_t)(k0 + ks * 32) * a.N + n;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) wv[j] = (k0 + ks * 32 + j < a.K) ? wp[(size_t)j * a.N] : 0.f;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-#pragma unroll
-                for (int i = 0; i < PF_FC_BB; ++i) {
-                    const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[i][xk0 + ks * 32 + 4 * q]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i] = fmaf(wv[4 * q + j], xv[j], acc[i]);
-                }
-            }
+            load_w(k0, wv);
+            mac(0, wv);
+            __syncthreads();
         }
-        if constexpr (!WHOLE_K) __syncthreads();
     }
 #pragma unroll
     for (int i = 0; i < PF_FC_BB; ++i) red[(ks * PF_FC_BB + i) * PF_FC_BN + nl] = acc[i];
@@ -741,7 +781,7 @@ __global__ __launch_bounds__(256) void fuse_up_kernel(FuseUpArgs a) {
 // pf_common.h); at the end of EVERY forward this kernel compares the slots against [2^-10, 6e4], poisons the outputs with NaN
 // and records (op, value) on a violation -- no silent inf, no silent garbage, on any call -- and clears the slots for the next one.
 struct RangeVerdictArgs {
-    unsigned* slots;         // [n_ops][PF_RANGE_SUBSLOTS] raw bits of max |v|, 0 = not measured; cleared here.  Behind them: an 8-byte
+    unsigned* slots;         // [n_ops][PF_RANGE_SUBSLOTS] words PF_RANGE_STRIDE apart: raw bits of max |v|, 0 = not measured; cleared here.  Behind them: an 8-byte
                              // verdict key (all ones = no violation) and a 4-byte arrival ticket (pf_load_program initialises both)
     int n_ops;
     float lo, hi;            // accepted range of a tensor's max |x|
@@ -760,19 +800,19 @@ struct RangeVerdictArgs {
 __global__ __launch_bounds__(64) void range_verdict_kernel(RangeVerdictArgs a) {
     static_assert(PF_RANGE_SUBSLOTS == 256, "four words per lane");
     const int i = blockIdx.x, t = threadIdx.x;
-    unsigned* s = a.slots + (size_t)i * PF_RANGE_SUBSLOTS;
+    unsigned* s = a.slots + (size_t)i * PF_RANGE_OP_WORDS;
     unsigned m = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const unsigned v = s[t + 64 * k];
-        s[t + 64 * k] = 0;                                           // cleared for the next forward
+        const unsigned v = s[(t + 64 * k) * PF_RANGE_STRIDE];
+        s[(t + 64 * k) * PF_RANGE_STRIDE] = 0;                       // cleared for the next forward
         m = v > m ? v : m;
     }
     for (int mask = 1; mask < 64; mask <<= 1) {
         const unsigned o = (unsigned)pf_shfl_xor_i32((int)m, mask);
         m = o > m ? o : m;
     }
-    unsigned long long* key = reinterpret_cast<unsigned long long*>(a.slots + (size_t)a.n_ops * PF_RANGE_SUBSLOTS);
+    unsigned long long* key = reinterpret_cast<unsigned long long*>(a.slots + (size_t)a.n_ops * PF_RANGE_OP_WORDS);
     unsigned* ticket = reinterpret_cast<unsigned*>(key + 1);
     int last = 0;
     if (t == 0) {

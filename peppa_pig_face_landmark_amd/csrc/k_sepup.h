@@ -377,6 +377,10 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
         const int wm = rw & 3, wn = rw >> 2;
         const int frow = lane & 15, fchunk = lane >> 4;
         const int crow = fchunk * 4;
+        // the matrix waves go first whenever they can issue: each of their instructions keeps the matrix pipe busy for 8-16 cycles
+        // while the producers' VALU work fills the slots in between -- the other way round the producers starve them of issue slots
+        // (0.548 -> 0.528 ms per 256 faces at 64 x 64; producers first: 0.56; profiles/r05_run27_wave_priority_ab3.txt)
+        pf_setprio<3>();
 #pragma unroll
         for (int k = 0; k < D - 1; ++k)
             if (!W_BY_PROD && issued_w < S) { w_issue(issued_w); ++issued_w; }

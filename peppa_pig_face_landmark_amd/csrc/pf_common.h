@@ -30,12 +30,26 @@ __device__ __forceinline__ unsigned pf_amax(unsigned m, float v) {
 // serialises in the L2 at ~80 ns apiece (measured: +0.5 ms on an 8192-workgroup launch, +20 us on a 960-workgroup one even
 // with 16 words); spread over 256 words the first round of a launch puts ~16 on each and every later wave only loads.
 #define PF_RANGE_SUBSLOTS 256
+// words of one op are PF_RANGE_STRIDE words apart (32 = one word per 128-byte line: the 4096 commits of a 256-workgroup launch of
+// 16-wave workgroups all arrive within a microsecond, and atomics on the same LINE queue behind each other)
+#ifndef PF_RANGE_STRIDE
+#define PF_RANGE_STRIDE 32
+#endif
+#define PF_RANGE_OP_WORDS (PF_RANGE_SUBSLOTS * PF_RANGE_STRIDE)
 __device__ __forceinline__ unsigned* pf_amax_word(unsigned* slot) {
-    return slot + ((((blockIdx.x + 5 * blockIdx.y) << 4) + (threadIdx.x >> 6)) & (PF_RANGE_SUBSLOTS - 1));
+    return slot + ((((blockIdx.x + 5 * blockIdx.y) << 4) + (threadIdx.x >> 6)) & (PF_RANGE_SUBSLOTS - 1)) * PF_RANGE_STRIDE;
 }
 // at kernel entry: what the wave's word holds now (the load's latency hides behind the kernel body; a stale value only means an
 // atomic that was not needed)
-__device__ __forceinline__ unsigned pf_amax_seen(unsigned* slot) { return slot ? __atomic_load_n(pf_amax_word(slot), __ATOMIC_RELAXED) : 0u; }
+// -- but only where it pays: the words of an op sit in eight cache lines that every wave of the launch reads at the same moment,
+// and vector loads return in order, so the wave's first input data waits behind this load.  A launch of fewer than 4096
+// workgroups is about one generation of resident workgroups -- every wave reads "nothing committed yet" and commits anyway -- so
+// there the load is skipped (ShuffleNet units at 48 x 80: 0.122 -> 0.089 ms per 32 frames; LOAD = false is for kernels of many
+// SHORT workgroups that measured faster committing unconditionally: profiles/r05_run26_guard_load_variants.txt)
+template <bool LOAD = true> __device__ __forceinline__ unsigned pf_amax_seen(unsigned* slot) {
+    if constexpr (!LOAD) return 0u;
+    return (slot && gridDim.x * gridDim.y >= 4096u) ? __atomic_load_n(pf_amax_word(slot), __ATOMIC_RELAXED) : 0u;
+}
 __device__ __forceinline__ void pf_amax_commit(unsigned* slot, unsigned m, unsigned seen) {
     if (!slot) return;
     // wave maximum: four DPP exchanges inside each 16-lane row, then the four row results through SGPRs

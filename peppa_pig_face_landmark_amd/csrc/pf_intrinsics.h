@@ -118,6 +118,10 @@ __device__ __forceinline__ int pf_uniform_i32(int v) { return __builtin_amdgcn_r
 
 // a copy of v the compiler must assume is a different value (loop-invariant index arithmetic derived from it stays inside the loop)
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// s_setprio: issue priority of this wave among the waves of its SIMD (0 = default .. 3).  A wave about to run a stretch of VALU
+// work next to waves that feed the matrix pipe (whose instructions keep that pipe busy for 8-16 cycles each) gets its issue slots
+// first at a higher priority.
+template <int P> __device__ __forceinline__ void pf_setprio() { __builtin_amdgcn_s_setprio(P); }
 
 // shader clock (s_memtime), for the per-wave time accounting of the ablation build
 __device__ __forceinline__ unsigned long long pf_clock() { return __builtin_amdgcn_s_memtime(); }

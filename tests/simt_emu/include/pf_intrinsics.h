@@ -116,6 +116,7 @@ template <int OFF> inline void pf_glds16_raw_off(const void* gsrc, void* lds_lan
 template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the emulator's copies are synchronous
 
 inline int pf_opaque(int v) { return v; }
+template <int P> inline void pf_setprio() {}
 inline int pf_uniform_i32(int v) { return v; }
 inline void pf_sched_fence() {}
 inline void pf_pin(unsigned&) {}
