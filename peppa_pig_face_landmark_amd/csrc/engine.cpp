@@ -23,6 +23,7 @@
 #include "k_hrb.h"
 #include "k_hero.h"
 #include "k_sepup.h"
+#include "k_pwhead.h"
 #include "k_mbx_args.h"
 #include "k_jpeg.h"
 #include "k_prepost.h"
@@ -291,7 +292,18 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
     if (SPLIT && use_split && pointwise && cfg == 0 && a.amax_val && !a.store_out && !a.res && !a.fbias && !a.gate && a.act == PF_ACT_NONE &&
         (M % 128) == 0) {
         if constexpr (SPLIT) {
-            PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1>), grid, dim3(512), h->stream, a);
+            // 128 input channels (the Student's and the Teacher's head): the weight-stationary stream of k_pwhead.h
+            if (a.Cpad == 128 && a.inC == 128 && a.Npad <= 112 && ((a.outH * a.outW) % 128) == 0 && !(host_dbg(h) & 524288))
+            {
+                // work item = a run of tiles of one face; a face is split only while there are fewer faces than CUs
+                const int tpf = (a.outH * a.outW) / 128;
+                int segs = 1;
+                while (segs < tpf && (tpf % (2 * segs)) == 0 && B * segs < h->num_cus) segs *= 2;
+                a.head_segs = segs;
+                PF_LAUNCH((pw_head_kernel<4>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);
+            }
+            else if (a.Cpad == 128) PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1, 1, 0, 4>), grid, dim3(512), h->stream, a);   // K loop unrolled, two steps ahead
+            else PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1>), grid, dim3(512), h->stream, a);
             return 0;
         }
     }

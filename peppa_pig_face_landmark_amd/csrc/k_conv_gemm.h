@@ -41,6 +41,7 @@ struct ConvGemmArgs {
     int KH, KW, stride, pad, dil, Cpad;
     int act;
     int amaxN;
+    int head_segs;        // pw_head_kernel (k_pwhead.h): work items per face
     int store_out;
     float acc_scale;      // split-precision kernels: 1 / (power-of-two weight scale); 1 otherwise
     // fused "upsample x2 (bilinear) + concat + depthwise 3x3 + BN" producer of the pixel operand

@@ -192,17 +192,7 @@ __global__ __launch_bounds__(256) void gap_kernel(GapArgs a) {
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
     if (cv < CV) {
         const T* in = static_cast<const T*>(a.in) + (size_t)b * a.HW * a.ld + cv * VE;
-        int p = prow;
-        for (; p + 7 * 32 < a.HW; p += 8 * 32) {          // eight rows requested before the first is added (same order of additions)
-            vec_t x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = pf_ldv<T>(in + (size_t)(p + 32 * j) * a.ld);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int e = 0; e < VE; ++e) acc[e] += (float)x[j][e];
-        }
-        for (; p < a.HW; p += 32) {
+        for (int p = prow; p < a.HW; p += 32) {
             const vec_t x = pf_ldv<T>(in + (size_t)p * a.ld);
 #pragma unroll
             for (int e = 0; e < VE; ++e) acc[e] += (float)x[e];
