@@ -329,17 +329,16 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
     const float* in = a.in + (size_t)b * a.inH * a.inW * a.inLd;
     const int frow = lane & 15, fk = (lane >> 4) * 4;
-    auto split4 = [&](const pf_f32x4& v, float scale, pf_half4& hi, pf_half4& lo, bool track) {
+    auto split4 = [&](const pf_f32x4& v, pf_half4& hi, pf_half4& lo, bool track) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float x = v[e] * scale;
+            const float x = v[e];
             const pf_half hv = (pf_half)x;
             hi[e] = hv;
             lo[e] = (pf_half)(x - (float)hv);
             if (track) amax = pf_amax(amax, x);
         }
     };
-    const float up_exp = 1.f / a.scale_exp, up_pwl = 1.f / a.scale_pwl;     // powers of two: exact
 
     pf_f32x4 xf[MH][KK];
     unsigned inside = 0;
@@ -363,7 +362,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) split4(xf[mt][kk], 1.f, xh[mt][kk], xl[mt][kk], true);
+            for (int kk = 0; kk < KK; ++kk) split4(xf[mt][kk], xh[mt][kk], xl[mt][kk], true);
     }
     pf_f32x4 acc[MPW][MAXNT];
 #pragma unroll
@@ -376,12 +375,19 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     const unsigned poff = (unsigned)(frow * a.Mid16 + fk);
 
     // every weight set is requested right after the previous one's last use (latency hides behind the next phase)
+    // SP: the 16 bytes of four f32 weights hold their scaled split instead -- [hi x 4 | lo x 4] f16, made at pack time (ir.py::mbconv:
+    // same arithmetic as split4 below) -- so no wave splits weights (it was 66-88 of a chunk's ~330 VALU instructions, in every one of
+    // the 65 536 waves of a launch, and these kernels are VALU-bound: profiles/r05_run37_pmc_all_kernels.txt)
     pf_f32x4 wv[KK], be, pv[MAXNT];
+    pf_half8 wv8[SP ? KK : 1], pv8[SP ? MAXNT : 1];
     float wk[9], bd;
     auto fetch_expand = [&](int m) {
         if (m >= a.Mid16) return;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) wv[kk] = *reinterpret_cast<const pf_f32x4*>(a.w_exp32 + (size_t)m * CP + woff + kk * 16);
+        for (int kk = 0; kk < KK; ++kk) {
+            if constexpr (SP) wv8[kk] = *reinterpret_cast<const pf_half8*>(a.w_exp32 + (size_t)m * CP + woff + kk * 16);
+            else wv[kk] = *reinterpret_cast<const pf_f32x4*>(a.w_exp32 + (size_t)m * CP + woff + kk * 16);
+        }
         be = *reinterpret_cast<const pf_f32x4*>(a.b_exp + m + (unsigned)fk);
     };
     auto fetch_dw = [&](int m) {
@@ -394,7 +400,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
         if (m >= a.Mid16) return;
 #pragma unroll
         for (int nt = 0; nt < MAXNT; ++nt)
-            if (nt < NTC) pv[nt] = *reinterpret_cast<const pf_f32x4*>(a.w_pwl32 + (size_t)nt * 16 * a.Mid16 + m + poff);
+            if (nt < NTC) {
+                if constexpr (SP) pv8[nt] = *reinterpret_cast<const pf_half8*>(a.w_pwl32 + (size_t)nt * 16 * a.Mid16 + m + poff);
+                else pv[nt] = *reinterpret_cast<const pf_f32x4*>(a.w_pwl32 + (size_t)nt * 16 * a.Mid16 + m + poff);
+            }
     };
     if constexpr (!NOEXP) fetch_expand(0);
     fetch_dw(0);
@@ -412,8 +421,8 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
                 if constexpr (SP) {
 #pragma unroll
                     for (int kk = 0; kk < KK; ++kk) {
-                        pf_half4 wh, wl;
-                        split4(wv[kk], up_exp, wh, wl, false);
+                        const pf_half4 wh = pf_half4{wv8[kk][0], wv8[kk][1], wv8[kk][2], wv8[kk][3]};
+                        const pf_half4 wl = pf_half4{wv8[kk][4], wv8[kk][5], wv8[kk][6], wv8[kk][7]};
                         e = pf_mfma_16x16x16_f16(wl, xh[mt][kk], e);
                         e = pf_mfma_16x16x16_f16(wh, xl[mt][kk], e);
                         e = pf_mfma_16x16x16_f16(wh, xh[mt][kk], e);
@@ -459,12 +468,12 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
             const pf_f32x4 d4 = *reinterpret_cast<const pf_f32x4*>(ds + (mt * 16 + frow) * 16 + fk);
             if constexpr (SP) {
                 pf_half4 dh, dl;
-                split4(d4, 1.f, dh, dl, true);
+                split4(d4, dh, dl, true);
 #pragma unroll
                 for (int nt = 0; nt < MAXNT; ++nt)
                     if (nt < NTC) {
-                        pf_half4 ph, pl;
-                        split4(pv[nt], up_pwl, ph, pl, false);
+                        const pf_half4 ph = pf_half4{pv8[nt][0], pv8[nt][1], pv8[nt][2], pv8[nt][3]};
+                        const pf_half4 pl = pf_half4{pv8[nt][4], pv8[nt][5], pv8[nt][6], pv8[nt][7]};
                         acc[mt][nt] = pf_mfma_16x16x16_f16(pl, dh, acc[mt][nt]);
                         acc[mt][nt] = pf_mfma_16x16x16_f16(ph, dl, acc[mt][nt]);
                         acc[mt][nt] = pf_mfma_16x16x16_f16(ph, dh, acc[mt][nt]);

@@ -271,6 +271,20 @@ class ProgramBuilder:
         wmax = float(np.abs(w).max())
         return 1.0 if wmax == 0.0 else float(2.0 ** (-int(np.floor(np.log2(16384.0 / wmax)))))
 
+    def _f32_or_presplit(self, w: np.ndarray, unscale: float) -> int:
+        """Weights of the exact-f32 block kernels (k_mbconv.h mbconv_wave_f32_kernel).  f32 programs: plain f32.  Split programs: the
+        16 bytes of every four consecutive weights of a row hold their scaled split instead, [hi x 4 | lo x 4] f16 with
+        x = w / unscale (a power of two: exact), hi = f16(x), lo = f16(x - hi) -- what the kernel used to compute in every wave."""
+        w32 = np.ascontiguousarray(w, dtype=np.float32)
+        if not self.split:
+            return self.const_f32(w32)
+        assert w32.ndim == 2 and w32.shape[1] % 4 == 0
+        xs = w32 * np.float32(1.0 / unscale)
+        hi = xs.astype(np.float16)
+        lo = (xs - hi.astype(np.float32)).astype(np.float16)
+        packed = np.concatenate([hi.reshape(w32.shape[0], -1, 4), lo.reshape(w32.shape[0], -1, 4)], axis=2)   # [rows][cols / 4][8]
+        return self.const(np.ascontiguousarray(packed))
+
     def mbconv(self, x: int, w_exp: np.ndarray, b_exp: np.ndarray, w_dw: np.ndarray, b_dw: np.ndarray,
                w_pwl: np.ndarray, b_pwl: np.ndarray, act: str, *, stride: int, pad: int, dil: int = 1,
                res: int = -1, out_name: str = "") -> int:
@@ -295,9 +309,10 @@ class ProgramBuilder:
             bd = np.zeros(mid16); bd[:mid] = b_dw
             wp = np.zeros((coutp, mid16)); wp[:cout, :mid] = w_pwl.reshape(cout, mid)
             bp = np.zeros(coutp); bp[:cout] = b_pwl
-            self._op(OP_MBCONV, [x, out, res, self.const_f32(we), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
-                                 self.const_f32(wp), self.const_f32(bp), k, stride, pad, dil, ACT[act], mid16, cp, coutp, cout,
-                                 mid16, fbits(self._pow2_unscale(we)), fbits(self._pow2_unscale(wp)), 1],
+            se, sp = self._pow2_unscale(we), self._pow2_unscale(wp)
+            self._op(OP_MBCONV, [x, out, res, self._f32_or_presplit(we, se), self.const_f32(be), self.const_f32(wd), self.const_f32(bd),
+                                 self._f32_or_presplit(wp, sp), self.const_f32(bp), k, stride, pad, dil, ACT[act], mid16, cp, coutp, cout,
+                                 mid16, fbits(se), fbits(sp), 1],
                      [self._tb(x), self._tb(res)], [self._tb(out)])
             return out
         midp, cp = _round_up(mid, 32), _round_up(cin, 32)
