@@ -20,7 +20,10 @@ SOURCES = ["engine.cpp", "mbx_launch.cpp"]
 # and the v_mov shuffles that feed the pairs are pure loss (the VALU-heavy depthwise / unit kernels measure 5-13 % faster
 # without it, the whole pipeline ~2 %: profiles/r05_run19_noslp_whole_library.txt, r05_run20_noslp_headline_ab.txt).  For
 # k_mbx.h's depthwise taps it is a requirement, not a preference (see csrc/mbx_launch.cpp).
-COMMON_FLAGS = ["-fno-slp-vectorize"]
+COMMON_FLAGS = ["-fno-slp-vectorize",
+                # no mixed-precision fma instructions (v_fma_mix*): with them selected by the compiler the DETECTOR kernels measured
+                # 6e-4 of their range against the oracle instead of 5e-5 (csrc/pf_intrinsics.h pf_split_lo; tools/det_parity.py)
+                "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 SOURCE_FLAGS = {}            # per-source extras
 STAMP = os.path.join(HERE, "libpeppa_hip.srchash")
 

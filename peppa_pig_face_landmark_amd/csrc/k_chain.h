@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 4) void
                     const float x = v[j][i][r];
                     const pf_half hv = (pf_half)x;
                     hi[r] = hv;
-                    lo[r] = (pf_half)(x - (float)hv);
+                    lo[r] = pf_split_lo(x, hv);
                     const float ax = fabsf(x);
                     vbad |= !(ax == ax);
                     vmax = fmaxf(vmax, ax);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
             const float v = xreg[u][e >> 2][e & 3];
             const pf_half hv = (pf_half)v;
             hi[e] = hv;
-            lo[e] = (pf_half)(v - (float)hv);
+            lo[e] = pf_split_lo(v, hv);
             const float av = fabsf(v);
             vbad |= !(av == av);
             vmax = fmaxf(vmax, av);
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(512, 4) void basic_block_kernel(BlockArgs a) {
                     if (!inside) v = 0.f;
                     const pf_half hv = (pf_half)v;
                     hi[e] = hv;
-                    lo[e] = (pf_half)(v - (float)hv);
+                    lo[e] = pf_split_lo(v, hv);
                     const float av = fabsf(v);
                     vbad |= !(av == av);
                     vmax = fmaxf(vmax, av);

@@ -842,7 +842,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
                 if constexpr (PW2) { if (!(xvalid[u] && cb * 32 + xc * 8 + (e & 4) < a.inC)) v = 0.f; }
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
+                lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off(xrow0 + XROWSTEP * u, xc);
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
                     const float v = e < 4 ? v0[e & 3] : v1[e & 3];
                     const pf_half hv = (pf_half)v;
                     xh[e] = hv;
-                    xl[e] = (pf_half)(v - (float)hv);
+                    xl[e] = pf_split_lo(v, hv);
                     amax = pf_amax(amax, v);
                 }
                 acc = pf_mfma_16x16x32_f16(wlf[ks], xh, acc);
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
                 const float v = e < 4 ? v0[e & 3] : v1[e & 3];
                 const pf_half hv = (pf_half)v;
                 xhf[e] = hv;
-                xlf[e] = (pf_half)(v - (float)hv);
+                xlf[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, WARPS_M * WARPS_N / 2) void
                 const float v = xreg[u][e >> 2][e & 3];
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
+                lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off(xhp[u], xc);
@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
             for (int e = 0; e < 8; ++e) {
                 const pf_half hv = (pf_half)o[e];
                 hi[e] = hv;
-                lo8[e] = (pf_half)(o[e] - (float)hv);
+                lo8[e] = pf_split_lo(o[e], hv);
                 amax = pf_amax(amax, o[e]);
             }
             *reinterpret_cast<pf_half8*>(xh + xrow_off) = hi;

@@ -59,7 +59,7 @@ __device__ __forceinline__ void det_park4(unsigned char* base, int MR, int row, 
     for (int e = 0; e < 4; ++e) {
         const pf_half hv = (pf_half)v[e];
         hi[e] = hv;
-        lo[e] = (pf_half)(v[e] - (float)hv);
+        lo[e] = pf_split_lo(v[e], hv);
         amax = pf_amax(amax, v[e]);
     }
     unsigned char* p = det_plane(base, MR, c4 >> 3) + pf_lds_chunk_off(row, (c4 >> 1) & 3) + (c4 & 1) * 8;
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = inf[((size_t)ci * a.H + iy) * a.W + ix];
             const pf_half hv = (pf_half)v;
             s_ih[ry * RS + x3 + 4] = hv;
-            s_il[ry * RS + x3 + 4] = (pf_half)(v - (float)hv);
+            s_il[ry * RS + x3 + 4] = pf_split_lo(v, hv);
             amax = pf_amax(amax, v);
         }
     }
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
         for (int e = 0; e < 4; ++e) {
             const pf_half hv = (pf_half)v[e];
             hi[e] = hv;
-            lo[e] = (pf_half)(v[e] - (float)hv);
+            lo[e] = pf_split_lo(v[e], hv);
             amax = pf_amax(amax, v[e]);
         }
         // channels g4 .. g4 + 3: slot (g >> 1) holds hi of channels 8 (g >> 1) .. + 7, slot 2 + (g >> 1) the lo halves
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const pf_half hv = (pf_half)v[e];
                 hi[e] = hv;
-                lo[e] = (pf_half)(v[e] - (float)hv);
+                lo[e] = pf_split_lo(v[e], hv);
                 amax = pf_amax(amax, v[e]);
             }
             *reinterpret_cast<pf_half4*>(s_p2 + r * 32 + g * 8) = hi;

@@ -35,7 +35,7 @@ __device__ __forceinline__ void lmf_park16(unsigned char* base, int row, int g, 
     for (int e = 0; e < 4; ++e) {
         const pf_half hv = (pf_half)v[e];
         hi[e] = hv;
-        lo[e] = (pf_half)(v[e] - (float)hv);
+        lo[e] = pf_split_lo(v[e], hv);
         amax = pf_amax(amax, v[e]);
     }
     *reinterpret_cast<pf_half4*>(base + pf_lds_chunk_off(row, g >> 1) + (g & 1) * 8) = hi;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = inf[((size_t)ci * a.H + iy) * a.W + ix];
             const pf_half hv = (pf_half)v;
             s_ih[ry * RS + x3 + mis + 1] = hv;
-            s_il[ry * RS + x3 + mis + 1] = (pf_half)(v - (float)hv);
+            s_il[ry * RS + x3 + mis + 1] = pf_split_lo(v, hv);
             amax = pf_amax(amax, v);
         }
     }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
             if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) v = inf[((size_t)ci * a.H + iy) * a.W + ix];
             const pf_half hv = (pf_half)v;
             s_ih[ry * RS + x3 + mis + 1] = hv;
-            s_il[ry * RS + x3 + mis + 1] = (pf_half)(v - (float)hv);
+            s_il[ry * RS + x3 + mis + 1] = pf_split_lo(v, hv);
             amax = pf_amax(amax, v);
         }
     }

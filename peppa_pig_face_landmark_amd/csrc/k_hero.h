@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
                 const float v = xok[u] ? xreg[u][e >> 2][e & 3] : 0.f;
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
+                lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off((t >> 2) + (NTHR / 4) * u, xc);

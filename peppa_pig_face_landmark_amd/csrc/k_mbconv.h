@@ -50,7 +50,7 @@ __device__ __forceinline__ void pf_split8(const pf_f32x4& v0, const pf_f32x4& v1
         const float v = e < 4 ? v0[e & 3] : v1[e & 3];
         const pf_half hv = (pf_half)v;
         hi[e] = hv;
-        lo[e] = (pf_half)(v - (float)hv);
+        lo[e] = pf_split_lo(v, hv);
         amax = pf_amax(amax, v);                 // range guard (pf_common.h)
     }
 }
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
             const float x = v[e];
             const pf_half hv = (pf_half)x;
             hi[e] = hv;
-            lo[e] = (pf_half)(x - (float)hv);
+            lo[e] = pf_split_lo(x, hv);
             if (track) amax = pf_amax(amax, x);
         }
     };

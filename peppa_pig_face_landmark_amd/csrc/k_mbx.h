@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                         if (!(c0 + (e & 4) < a.inC)) v = 0.f;
                         const pf_half hv = (pf_half)v;
                         xh[i][s][e] = hv;
-                        xl[i][s][e] = (pf_half)(v - (float)hv);
+                        xl[i][s][e] = pf_split_lo(v, hv);
                         amax = pf_amax(amax, v);
                     }
                 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                     const float v0 = MODE == 2 ? of[2 * x] * g0 : of[2 * x], v1 = MODE == 2 ? of[2 * x + 1] * g1 : of[2 * x + 1];
                     pf_half2 hi, lo;
                     hi[0] = (pf_half)v0; hi[1] = (pf_half)v1;
-                    lo[0] = (pf_half)(v0 - (float)hi[0]); lo[1] = (pf_half)(v1 - (float)hi[1]);
+                    lo[0] = pf_split_lo(v0, hi[0]); lo[1] = pf_split_lo(v1, hi[1]);
                     amax = pf_amax(pf_amax(amax, v0), v1);
                     unsigned char* q = (x < 4 ? dp0 : dp1) + x * 64;
                     *reinterpret_cast<pf_half2*>(q) = hi;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void pw_head_kernel(ConvGemmArgs a) {
                 const float v = xr[s][e >> 2][e & 3];
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = (pf_half)(v - (float)hv);
+                lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             *reinterpret_cast<pf_half8*>(base + s * PLANE) = hi;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void sepup_skip_kernel(SepupArgs a) {
         for (int e = 0; e < 8; ++e) {
             const pf_half hv = (pf_half)o[e];
             hi[e] = hv;
-            lo8[e] = (pf_half)(o[e] - (float)hv);
+            lo8[e] = pf_split_lo(o[e], hv);
             amax = pf_amax(amax, o[e]);
         }
         unsigned char* dst = a.skipx + ((size_t)tb * nskip + sc) * 16384 + pf_lds_chunk_off(prow, xc);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
                             for (int e = 0; e < 2; ++e) {
                                 const pf_half hv = (pf_half)o[dy][dx][e];
                                 hi[e] = hv;
-                                lo2[e] = (pf_half)(o[dy][dx][e] - (float)hv);
+                                lo2[e] = pf_split_lo(o[dy][dx][e], hv);
                                 amax = pf_amax(amax, o[dy][dx][e]);
                             }
                             *reinterpret_cast<pf_half2*>(xdst + xoff[dy][dx]) = hi;

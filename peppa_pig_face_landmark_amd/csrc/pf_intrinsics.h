@@ -118,6 +118,17 @@ __device__ __forceinline__ int pf_uniform_i32(int v) { return __builtin_amdgcn_r
 
 // a copy of v the compiler must assume is a different value (loop-invariant index arithmetic derived from it stays inside the loop)
 __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// The low half of the f32s split: lo = f16(v - f32(hi)).
+// Round 5 tried to have it selected as ONE v_fma_mixlo / mixhi_f16 (f16 source, f32 addend, f16 result: 2.5 instead of 4 VALU
+// instructions per element) by writing it fma(f32(hi), m, v) with m = -1 out of a scalar register the compiler cannot see through.
+// The values are identical (a micro-test over 2^20 inputs and the Student / Teacher outputs bit for bit:
+// profiles/r05_run39_split_mix_vs_sub_bitwise.txt, r05_run42_fma_mix_vs_sub.txt) and the pipeline gained 0.5 % -- but the same round
+// found the detector at 6e-4 of its range against the oracle instead of 5e-5 whenever the compiler selects mixed-precision fma
+// instructions ON ITS OWN in the detector kernels (it does once the SLP vectoriser is off: hi = mixlo(x, r, 0), lo = mixlo(x, r, -hi)
+// behind the SiLU), and at 5e-5 again with the instruction family switched off (profiles/r05_run44 ... r05_run47: the isolated
+// pattern is exact, the kernels are not -- not root-caused).  The library is therefore built with -fma-mix-insts (build.py), and
+// the split is the plain subtraction everywhere.
+__device__ __forceinline__ pf_half pf_split_lo(float v, pf_half hi) { return (pf_half)(v - (float)hi); }
 // s_setprio: issue priority of this wave among the waves of its SIMD (0 = default .. 3).  A wave about to run a stretch of VALU
 // work next to waves that feed the matrix pipe (whose instructions keep that pipe busy for 8-16 cycles each) gets its issue slots
 // first at a higher priority.

@@ -117,6 +117,7 @@ template <int N> inline void pf_wait_vm_barrier() { __syncthreads(); }   // the 
 
 inline int pf_opaque(int v) { return v; }
 template <int P> inline void pf_setprio() {}
+inline pf_half pf_split_lo(float v, pf_half hi) { return (pf_half)(v - (float)hi); }
 inline int pf_uniform_i32(int v) { return v; }
 inline void pf_sched_fence() {}
 inline void pf_pin(unsigned&) {}

@@ -71,3 +71,39 @@ def test_production_library_has_no_ablation_switch():
         blob = f.read()
     assert b"PEPPA_DBG" not in blob
     assert b"PEPPA_RCCL_LIBRARY" in blob          # sanity: environment names the library does read are visible this way
+
+
+def test_hand_counted_vmcnt_kernels_use_no_scratch(hip_library, tmp_path):
+    """The kernels that order their LDS-DMA rings with hand-counted ``s_waitcnt vmcnt(N)`` (k_hero.h, k_sepup.h, k_chain.h, k_hrb.h,
+    the unrolled pointwise GEMM) assume that NOTHING but their own requests sits in the vector-memory queue: a register spill puts a
+    scratch store / reload there and shifts every count by one (round 5: the mixed-precision split form spilled ONE register of the
+    hero kernel).  The code object's metadata must show a zero private segment for every instance of them."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf)):
+        pytest.skip("llvm-objdump / llvm-readelf not found")
+    lib = tmp_path / "lib.so"                         # --offloading extracts next to its input
+    shutil.copy(hip_library, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs, "no gfx950 code object in the library"
+    seen, bad = 0, []
+    for co in objs:
+        notes = subprocess.run([readelf, "--notes", str(co)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+            if m and name:
+                counted = (name.startswith("_Z19conv3x3_hero_kernelILi4ELb1E") or "sepup_pipe_kernel" in name or "basic_chain_kernel" in name
+                           or "hr_bottleneck_kernel" in name or re.search(r"conv_gemm_split_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi1ELi0ELin?\d+ELi1ELi0ELi[1-9]", name))
+                if counted:
+                    seen += 1
+                    if int(m.group(1)) != 0:
+                        bad.append((name, int(m.group(1))))
+    assert seen >= 8, "kernel names changed? only %d hand-counted kernels recognised" % seen
+    assert not bad, "hand-counted vmcnt kernels with scratch: %s" % bad
