@@ -107,3 +107,23 @@ def test_hand_counted_vmcnt_kernels_use_no_scratch(hip_library, tmp_path):
                         bad.append((name, int(m.group(1))))
     assert seen >= 8, "kernel names changed? only %d hand-counted kernels recognised" % seen
     assert not bad, "hand-counted vmcnt kernels with scratch: %s" % bad
+
+
+def test_library_has_no_mixed_precision_fma(hip_library, tmp_path):
+    """Round 5: with v_fma_mix* selected by the compiler the detector kernels lost the low halves of their splits on MI355X
+    (6e-4 of the tensor range against the oracle instead of 5e-5; csrc/pf_intrinsics.h pf_split_lo).  build.py switches the instruction
+    family off; this is the check that the flag reached every translation unit."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    lib = tmp_path / "lib.so"
+    shutil.copy(hip_library, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs
+    for co in objs:
+        asm = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
+        assert "v_mfma_f32_16x16x32" in asm or "s_endpgm" in asm
+        assert "v_fma_mix" not in asm, "%s contains mixed-precision fma instructions" % co.name
