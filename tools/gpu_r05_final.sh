@@ -29,9 +29,10 @@ json.dump({"_meta": {"round": 5, "faces_per_launch": 256, "tool": "tools/pmc_ker
 print("hero", {c: rec.get(c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA")})
 PY
 timeout 300 python tools/pmc_groups.py gpurun_out/${T}_pmc_groups.json
-timeout 300 python tools/pmc_groups.py gpurun_out/${T}_pmc_groups_recompute.json --mbx recompute
 timeout 300 python tools/pmc_kernel.py "mbx_kernel<16, 5, 10, 5, 2, 3>" --out=${T}_pmc_mbxS_sq > /dev/null 2>&1; python -c "
 import json; d=json.load(open('gpurun_out/${T}_pmc_mbxS_sq.json')); [print(k[:60], {c: int(v) for c, v in r.items()}) for k, r in d.items()]"
+timeout 300 python tools/pmc_kernel.py pw_head_kernel --out=${T}_pmc_pw_head_sq > /dev/null 2>&1
+timeout 300 python tools/pmc_all.py gpurun_out/${T}_pmc_all_kernels.json > gpurun_out/${T}_pmc_all_kernels.txt 2>&1; head -14 gpurun_out/${T}_pmc_all_kernels.txt
 timeout 400 python bench.py --model teacher --frame-hw 2160 3840 --faces-per-frame 32 --frames 12 --steps 8 --warmup 2 --no-cpu-baseline --no-probes > gpurun_out/${T}_bench_c5_teacher_f12.json 2>/dev/null
 python -c "
 import json; d=json.loads(open('gpurun_out/${T}_bench_c5_teacher_f12.json').read().strip().splitlines()[-1]); print('C5 teacher frames 12:', d['value'], d['ms_per_step'], d['roofline'] and (d['roofline']['kernel'], d['roofline']['frac']))"

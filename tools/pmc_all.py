@@ -19,18 +19,22 @@ for gi, grp in enumerate(GROUPS):
         for row in csv.DictReader(open(fn)):
             res[row["Kernel_Name"][:110]][row["Counter_Name"]].append(float(row["Counter_Value"]))
 table = {}
+CLK_MHZ = 2400.0          # busy time = busy cycles per SIMD (or per CU for the LDS) / clock; a launch's wall time under the counter passes is
+                          # NOT its real duration (GRBM_GUI_ACTIVE includes the profiler's serialisation), so busy TIMES are reported and
+                          # compared with the durations of bench.py's kernel table
 for k, cs in res.items():
     c = {n: sum(v) / len(v) for n, v in cs.items()}
     n = len(next(iter(cs.values())))
-    gui = c.get("GRBM_GUI_ACTIVE", 0.0)
-    if gui <= 0: continue
-    simd_cycles = gui * 1024.0                         # 256 CUs x 4 SIMDs
-    table[k] = {"launches": n, "gpu_cycles": round(gui), "valu_busy": round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0) / simd_cycles, 3),
-                "mfma_busy": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / simd_cycles, 3),
-                "lds_busy": round(4.0 * c.get("SQ_ACTIVE_INST_LDS", 0) / (gui * 256.0), 3),
+    if k.startswith("void at::") or k.startswith("__amd") or not c.get("SQ_WAVES"):
+        continue
+    table[k] = {"launches": n, "valu_busy_us": round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0) / 1024.0 / CLK_MHZ, 1),
+                "mfma_busy_us": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / CLK_MHZ, 1),
+                "lds_busy_us": round(4.0 * c.get("SQ_ACTIVE_INST_LDS", 0) / 256.0 / CLK_MHZ, 1),
                 "valu_per_wave": round(c.get("SQ_INSTS_VALU", 0) / max(c.get("SQ_WAVES", 1), 1)),
                 "salu_per_wave": round(c.get("SQ_INSTS_SALU", 0) / max(c.get("SQ_WAVES", 1), 1)), "waves": round(c.get("SQ_WAVES", 0))}
-json.dump({"_meta": {"bench_args": bench_args, "note": "busy = fraction of the launch's GPU cycles (GRBM_GUI_ACTIVE) x 1024 SIMDs; VALU at 4 cycles per instruction"}, "kernels": table},
-          open(out, "w"), indent=1)
-for k, t in sorted(table.items(), key=lambda kv: -kv[1]["gpu_cycles"] * kv[1]["launches"])[:45]:
-    print("%-92s x%-3d %8d cyc  valu %4.0f%%  mfma %4.0f%%  lds %4.0f%%  valu/wave %6d" % (k[:92], t["launches"], t["gpu_cycles"], 100 * t["valu_busy"], 100 * t["mfma_busy"], 100 * t["lds_busy"], t["valu_per_wave"]))
+json.dump({"_meta": {"bench_args": bench_args, "note": "per launch, averaged over the launches of a kernel: busy time of the VALU (4 cycles per instruction) and of the matrix pipe "
+                     "averaged over the 1024 SIMDs, of the LDS averaged over the 256 CUs, at 2.4 GHz -- compare with the launch durations of bench.py's kernel table"},
+           "kernels": table}, open(out, "w"), indent=1)
+print("%-84s %4s %9s %9s %9s %10s %8s" % ("kernel", "n", "VALU us", "MFMA us", "LDS us", "VALU/wave", "waves"))
+for k, t in sorted(table.items(), key=lambda kv: -kv[1]["valu_busy_us"] * kv[1]["launches"])[:48]:
+    print("%-84s %4d %9.1f %9.1f %9.1f %10d %8d" % (k[:84], t["launches"], t["valu_busy_us"], t["mfma_busy_us"], t["lds_busy_us"], t["valu_per_wave"], t["waves"]))
