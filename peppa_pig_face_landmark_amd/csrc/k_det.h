@@ -156,6 +156,7 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
     const bool prof = PF_ABLATE != 0 && a.prof != nullptr;             // constant false in the production library
     const unsigned long long t0 = prof ? pf_clock() : 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned m_tw = pf_div_magic(a.TW);               // p / TW of the per-lane tile arithmetic (pf_common.h pf_div_small)
     // dispatch order (tiles of a frame on consecutive workgroups = on different XCDs).  Giving each XCD a contiguous run of tiles, so
     // that shared halo rows hit its own L2, measured 3-15 % SLOWER per launch (profiles/r04_run16_*): these launches are
     // latency-bound, not fabric-bound
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
 #pragma unroll
         for (int j = 0; j < MAXT; ++j) {
             const int p = (mg + j * MG) * 16 + (lane & 15);
-            const int py = p / a.TW, px = p - py * a.TW;
+            const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
             const int oy = oy0 + py, ox = ox0 + px;
             evn[j] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             if (p < P && oy < a.outH && ox < a.outW) evn[j] = *reinterpret_cast<const pf_f32x4*>(in + ((size_t)oy * a.inW + ox) * a.inLd + nt * 16 + g4);
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
             pf_f32x4 sum = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             if (p < P && 4 * c4 < a.Cin) {
                 sum = bb;
-                const int py = p / a.TW, px = p - py * a.TW;
+                const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
         pf_f32x4 sum = pf_f32x4{0.f, 0.f, 0.f, 0.f};
         if (p < P) {
             sum = bdv;
-            const int py = p / a.TW, px = p - py * a.TW;
+            const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
             const float* e0 = s_e + ((py * S) * RW + px * S) * ES + 4 * dc4;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(NTHR, WPS) void det_unit_kernel(DetUnitArgs a) {
         const int mt = mg + j * MG;
         if (mt >= MRD / 16) break;
         const int p = mt * 16 + (lane & 15);
-        const int py = p / a.TW, px = p - py * a.TW;
+        const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         const bool ok = p < P && oy < a.outH && ox < a.outW;
         const int n = nt * 16 + g4;
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned m_tw = pf_div_magic(a.TW);               // p / TW of the per-lane tile arithmetic (pf_common.h pf_div_small)
     const int tile = blockIdx.x;                                     // dispatch order, see det_unit_kernel
     const int b = tile / a.tpf, tt = tile - b * a.tpf;
     const int oy0 = (tt / a.tilesX) * a.TH, ox0 = (tt % a.tilesX) * a.TW;
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
     for (int mt = wave >> 1; mt < MRD / 16; mt += NW / 2) {
         const int p = mt * 16 + (lane & 15);
         const int pc = p < P ? p : 0;
-        const int py = pc / a.TW, px = pc - py * a.TW;
+        const int py = pf_div_small(pc, m_tw), px = pc - py * a.TW;
         pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -497,7 +499,7 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
         pf_f32x4 v = det_silu4(det_tile<2>(s_c, MRD, mt * 16, lane, wDh, wDl), a.sD, bDv);
         const int p = mt * 16 + (lane & 15);
         if (p >= P) v = pf_f32x4{0.f, 0.f, 0.f, 0.f};          // pixel padding of the last tile
-        const int py = p / a.TW, px = p - py * a.TW;
+        const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         if (outp && p < P && oy < a.H && ox < a.W) *reinterpret_cast<pf_f32x4*>(outp + ((size_t)oy * a.W + ox) * a.outLd + ntD * 16 + g4) = v;
         if constexpr (TAIL != 0) det_park4(s_o, MRD, p, ntD * 4 + (lane >> 4), v, amax);
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(NTHR) void det_c3_kernel(DetC3Args a) {
             for (int mt = wave / NTE; mt < MRD / 16; mt += NW / NTE) {
                 const pf_f32x4 acc = det_tile<2>(s_o, MRD, mt * 16, lane, wEh, wEl);
                 const int p = mt * 16 + (lane & 15);
-                const int py = p / a.TW, px = p - py * a.TW;
+                const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
                 const int oy = oy0 + py, ox = ox0 + px;
                 if (!(p < P && oy < a.H && ox < a.W)) continue;
                 if constexpr (TAIL == 1) {
@@ -593,6 +595,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned m_tw = pf_div_magic(a.TW);               // p / TW of the per-lane tile arithmetic (pf_common.h pf_div_small)
     const int SRW = 2 * a.TW + 1, SRH = 2 * a.TH + 1, S1R = SRH * SRW, MR1 = (S1R + 15) & ~15;
     const int IRW = 2 * SRW + 1, IRH = 2 * SRH + 1;
     const int P = a.TH * a.TW, MRD = (P + 15) & ~15;
@@ -602,6 +605,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     // opened with a ~5 us wait for its 4 KB of pixels (133 us per 32 frames at three workgroups per CU).
     const int tiles_y = (a.OH + a.TH - 1) / a.TH, tpf = a.tilesX * tiles_y, ntiles = tpf * a.B;
     const int nwd = (IRW * 3 + 3 + 3) / 4;                    // aligned words covering one region row (the row starts at byte 3 of a word)
+    const unsigned m_nwd = pf_div_magic(nwd);
     const int rowb = a.W * 3;
     constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
     unsigned wv[ITW];
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             const int iy = iy0 + ry, bw = wb + 4 * w;
             wv[it] = 0u;
             if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             if (ry < IRH) {
                 pf_half* q = s_ih + ry * RS + 4 * w + 1;          // halves 4 w + 1 .. 4 w + 4
                 q[0] = (pf_half)(unsigned short)(wv[it] & 0xffu);
@@ -657,8 +661,9 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     } else {
         const float* inf = static_cast<const float*>(a.in) + (size_t)b * 3 * a.H * a.W;
         const int row_elems = IRW * 3;
+        const unsigned m_row = pf_div_magic(row_elems);
         for (int i = tid; i < IRH * row_elems; i += NTHR) {
-            const int ry = i / row_elems, x3 = i - ry * row_elems;
+            const int ry = pf_div_small(i, m_row), x3 = i - ry * row_elems;
             const int rx = x3 / 3, ci = x3 - rx * 3;
             const int iy = iy0 + ry, ix = ix0 + rx;
             float v = 0.f;
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     for (int mt = wave; mt < MRD / 16; mt += NW) {
         const int p = mt * 16 + frow;
         const int pc = p < P ? p : 0;
-        const int py = pc / a.TW, px = pc - py * a.TW;
+        const int py = pf_div_small(pc, m_tw), px = pc - py * a.TW;
         pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
         const int p = i >> 2, cg = i & 3;                     // 4 channels 4 cg .. 4 cg + 3 of output pixel p
         pf_half4 bh = pf_half4{(pf_half)0, (pf_half)0, (pf_half)0, (pf_half)0}, bl = bh;
         if (p < P) {
-            const int py = p / a.TW, px = p - py * a.TW;
+            const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
             float best[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(NTHR) void det_stem_kernel(DetStemArgs a) {
     for (int mt = wave; mt < MRD / 16; mt += NW) {
         const pf_f32x4 v = det_silu4(det_tile<1>(s_cat, MRD, mt * 16, lane, w3h, w3l), a.s3, b3v);
         const int p = mt * 16 + frow;
-        const int py = p / a.TW, px = p - py * a.TW;
+        const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         if (p < P && oy < a.OH && ox < a.OW) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.OW + ox) * a.outLd + g4) = v;
     }

@@ -84,6 +84,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned m_tw = pf_div_magic(a.TW);               // p / TW of the per-lane tile arithmetic (pf_common.h pf_div_small)
     const int YRW = 2 * a.TW + 1, YRH = 2 * a.TH + 1, YR = YRH * YRW, MRY = (YR + 15) & ~15;      // y0 region
     const int SRW = YRW + 2, SRH = YRH + 2, SR = SRH * SRW, MRS = (SR + 15) & ~15;                // stem region
     const int IRW = 2 * SRW + 1, IRH = 2 * SRH + 1;                                               // image region
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
     // persistent workgroups: tiles t = blockIdx.x, + gridDim.x, ...; the next tile's image words are requested before this one is computed
     const int tiles_y = (a.OH + a.TH - 1) / a.TH, tpf = a.tilesX * tiles_y, ntiles = tpf * a.B;
     const int nwd = (IRW * 3 + mis + 3) / 4;
+    const unsigned m_nwd = pf_div_magic(nwd);
     const int rowb = a.W * 3;
     constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
     unsigned wv[ITW];
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             const int iy = iy0 + ry, bw = wb + 4 * w;
             wv[it] = 0u;
             if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             if (ry < IRH) {
                 pf_half* q = s_ih + ry * RS + 4 * w + 1;          // halves 4 w + 1 .. 4 w + 4
                 q[0] = (pf_half)(unsigned short)(wv[it] & 0xffu);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
         const float* inf = static_cast<const float*>(a.in) + (size_t)b * 3 * a.H * a.W;
         const int row_elems = IRW * 3;
         for (int i = tid; i < IRH * row_elems; i += NTHR) {
-            const int ry = i / row_elems, x3 = i - ry * row_elems;
+            const int ry = i / row_elems, x3 = i - ry * row_elems;      // (i reaches 23 x 219 here: outside pf_div_small's exact range)
             const int rx = x3 / 3, ci = x3 - rx * 3;
             const int iy = iy0 + ry, ix = ix0 + rx;
             float v = 0.f;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
             pf_f32x4 sum = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             if (p < P) {
                 sum = bd1;
-                const int py = p / a.TW, px = p - py * a.TW;
+                const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
                 const float* e0 = s_e + ((2 * py) * YRW + 2 * px) * 20 + 4 * c4;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(NTHR, WPS) void lm_front_kernel(LmFrontArgs a) {   
         det_wfrag<2>(a.w_prj + zt, nt, lane, wjh, wjl);
         const pf_f32x4 acc = det_tile<2>(s_d, MRD, mt * 16, lane, wjh, wjl);
         const int p = mt * 16 + frow;
-        const int py = p / a.TW, px = p - py * a.TW;
+        const int py = pf_div_small(p, m_tw), px = p - py * a.TW;
         const int oy = oy0 + py, ox = ox0 + px;
         const int n = nt * 16 + g4;
         if (p < P && oy < a.OH && ox < a.OW && n < 24) {
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
     unsigned amax = 0;
     const unsigned amax_seen = pf_amax_seen<false>(a.range_slot);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned m_tw = pf_div_magic(a.TW);               // p / TW of the per-lane tile arithmetic (pf_common.h pf_div_small)
     const int b = blockIdx.y;
     const int oy0 = ((int)blockIdx.x / a.tilesX) * a.TH, ox0 = ((int)blockIdx.x % a.tilesX) * a.TW;
     const int IRW = 2 * a.TW + 1, IRH = 2 * a.TH + 1;
@@ -384,12 +387,13 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
     if constexpr (!F32IN) {
         const unsigned char* in8 = static_cast<const unsigned char*>(a.in) + (size_t)b * a.H * a.W * 3;
         const int nwd = (IRW * 3 + mis + 3) / 4, rowb = a.W * 3;
+        const unsigned m_nwd = pf_div_magic(nwd);
         constexpr int ITW = (MAXIH * (RS / 4) + NTHR - 1) / NTHR;
         unsigned wv[ITW];
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             const int iy = iy0 + ry, bw = wb + 4 * w;
             wv[it] = 0u;
             if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
             const int i = tid + it * NTHR;
-            const int ry = i / nwd, w = i - ry * nwd;
+            const int ry = pf_div_small(i, m_nwd), w = i - ry * nwd;
             if (ry < IRH) {
                 pf_half* q = s_ih + ry * RS + 4 * w + 1;
                 q[0] = (pf_half)(unsigned short)(wv[it] & 0xffu);
@@ -412,8 +416,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
     } else {
         const float* inf = static_cast<const float*>(a.in) + (size_t)b * 3 * a.H * a.W;
         const int row_elems = IRW * 3;
+        const unsigned m_row = pf_div_magic(row_elems);
         for (int i = tid; i < IRH * row_elems; i += NTHR) {
-            const int ry = i / row_elems, x3 = i - ry * row_elems;
+            const int ry = pf_div_small(i, m_row), x3 = i - ry * row_elems;
             const int rx = x3 / 3, ci = x3 - rx * 3;
             const int iy = iy0 + ry, ix = ix0 + rx;
             float v = 0.f;
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemMfmaArgs a) {
     for (int mt = wave; mt < (P + 15) / 16; mt += NW) {
         const int p = mt * 16 + frow;
         const int pc = p < P ? p : 0;
-        const int py = pc / a.TW, px = pc - py * a.TW;
+        const int py = pf_div_small(pc, m_tw), px = pc - py * a.TW;
         pf_half8 xh, xl;
         {
             const int base = (2 * py + (g < 3 ? g : 0)) * RS + 6 * px + mis + 1;

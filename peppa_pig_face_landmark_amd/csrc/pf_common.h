@@ -64,6 +64,14 @@ __device__ __forceinline__ void pf_amax_commit(unsigned* slot, unsigned m, unsig
     if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(pf_amax_word(slot), m);
 }
 
+// x / d for the per-lane tile arithmetic of the stem / detector kernels (pixel -> (row, column) of a tile whose width is a launch
+// argument): a 32-bit integer division is ~25 VALU instructions on this chip (no divider: reciprocal + corrections) and these kernels
+// are bound by VALU issue (4 cycles per instruction).  One multiply and a shift with m = 2^20 / d + 1, computed once per thread; exact
+// for 0 <= x < min(4096, 2^20 / d) (checked exhaustively for d <= 1024).  Worth 2-4 % on the stem and ShuffleNet-unit kernels
+// (profiles/r05_run52: stem conv 0.097 -> 0.094 ms, units at 24 x 40 0.124 -> 0.120): the divisions were fewer than they looked.
+__device__ __forceinline__ unsigned pf_div_magic(int d) { return (1u << 20) / (unsigned)d + 1u; }
+__device__ __forceinline__ int pf_div_small(int x, unsigned m) { return (int)(((unsigned)x * m) >> 20); }
+
 enum PfAct : int { PF_ACT_NONE = 0, PF_ACT_RELU = 1, PF_ACT_HSWISH = 2, PF_ACT_SILU = 3, PF_ACT_SIGMOID = 4,
                    PF_ACT_HSIGMOID = 5 };
 
