@@ -514,13 +514,18 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(CropResizeArgs a) {
         }
         *reinterpret_cast<unsigned*>(s_src + (size_t)r * lds_stride + 4 * wd) = v;
     }
+    // the vertical taps of the tile's rows, once per ROW instead of once per pixel (round 5): two double-precision operations and a
+    // floor each, identical for the 256 pixels of a row -- and this kernel is VALU-bound (83 % busy, profiles/r05_run37)
+    __shared__ LinTap s_ty[PF_CROP_TY];
+    if (!exact2 && t < rows_out) s_ty[t] = pf_cv_tap_v(oy0 + t, scale_y, hc);
     __syncthreads();
     // 256 % S == 0 (host): a thread keeps its output column for every row it computes, so its horizontal taps (two
     // double-precision operations each, like OpenCV derives them) are computed once
     const int dx = t % S;
     const LinTap tx = pf_cv_tap_h(dx, scale_x, wc);
+    const unsigned m_s = pf_div_magic(S);                // i < PF_CROP_TY * 256, S <= 256: inside pf_div_small's exact range
     for (int i = t; i < rows_out * S; i += 256) {
-        const int dy = i / S;
+        const int dy = pf_div_small(i, m_s);
         unsigned char* o = s_out + (size_t)i * 3;
         if (exact2) {
             const unsigned char* p0 = s_src + (size_t)(2 * dy) * lds_stride + shift + (2 * dx) * 3;   // r0 = 2 * oy0
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(CropResizeArgs a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) o[c] = (unsigned char)((p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2);
         } else {
-            const LinTap ty = pf_cv_tap_v(oy0 + dy, scale_y, hc);
+            const LinTap ty = s_ty[dy];
             const unsigned char* q0 = s_src + (size_t)(ty.i0 - r0) * lds_stride + shift;
             const unsigned char* q1 = s_src + (size_t)(ty.i1 - r0) * lds_stride + shift;
 #pragma unroll
