@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
     __shared__ __attribute__((aligned(16))) float es[HW * RS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.x, n0 = blockIdx.y * CB;
+    const bool track = blockIdx.y == 0;
     const int frow = lane & 15, kg = lane >> 4;
     const int ksteps = a.Cpad / 32;
     const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)b * HW * HW * a.inLd;
@@ -1095,7 +1096,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
                     const pf_half hv = (pf_half)v;
                     xh[e] = hv;
                     xl[e] = pf_split_lo(v, hv);
-                    amax = pf_amax(amax, v);
+                }
+                if (track) {                    // (wave-uniform) the eight channel tiles of an image split the SAME input: one of them reports its range
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) amax = pf_amax(amax, e < 4 ? v0[e & 3] : v1[e & 3]);
                 }
                 acc = pf_mfma_16x16x32_f16(wlf[ks], xh, acc);
                 acc = pf_mfma_16x16x32_f16(whf[ks], xl, acc);
@@ -1152,7 +1156,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
             rs += o[x];
         }
     }
-    pf_amax_commit(a.range_slot, amax, amax_seen);
+    if (track) pf_amax_commit(a.range_slot, amax, amax_seen);
     if (a.gap_out) {
         __syncthreads();                        // E is dead: its LDS becomes the row-sum scratch
         es[y * CB + c] = rs;
@@ -1185,6 +1189,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
     __shared__ __attribute__((aligned(16))) float es[R * RS];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int b = blockIdx.x, n0 = blockIdx.y * CB;
+    const bool track = blockIdx.y == 0;
     const int frow = lane & 15, kg = lane >> 4;
     const float* __restrict__ in = static_cast<const float*>(a.in) + (size_t)b * IN * IN * a.inLd;
     const unsigned char* __restrict__ wt = static_cast<const unsigned char*>(a.wt);
@@ -1226,7 +1231,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
                 const pf_half hv = (pf_half)v;
                 xhf[e] = hv;
                 xlf[e] = pf_split_lo(v, hv);
-                amax = pf_amax(amax, v);
+            }
+            if (track) {                        // (wave-uniform) one channel tile per image reports the range of the shared input
+#pragma unroll
+                for (int e = 0; e < 8; ++e) amax = pf_amax(amax, e < 4 ? v0[e & 3] : v1[e & 3]);
             }
             pf_f32x4 acc = pf_f32x4{0.f, 0.f, 0.f, 0.f};
             acc = pf_mfma_16x16x32_f16(wlf, xhf, acc);
@@ -1268,7 +1276,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
         }
         __syncthreads();                        // the next quadrant overwrites the region
     }
-    pf_amax_commit(a.range_slot, amax, amax_seen);
+    if (track) pf_amax_commit(a.range_slot, amax, amax_seen);
     if (a.gap_out) {
         es[(t >> 4) * CB + c] = rs;             // 32 partial sums per channel
         __syncthreads();
