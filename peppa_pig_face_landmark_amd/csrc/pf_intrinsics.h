@@ -125,9 +125,13 @@ __device__ __forceinline__ int pf_opaque(int v) { asm volatile("" : "+v"(v)); re
 // profiles/r05_run39_split_mix_vs_sub_bitwise.txt, r05_run42_fma_mix_vs_sub.txt) and the pipeline gained 0.5 % -- but the same round
 // found the detector at 6e-4 of its range against the oracle instead of 5e-5 whenever the compiler selects mixed-precision fma
 // instructions ON ITS OWN in the detector kernels (it does once the SLP vectoriser is off: hi = mixlo(x, r, 0), lo = mixlo(x, r, -hi)
-// behind the SiLU), and at 5e-5 again with the instruction family switched off (profiles/r05_run44 ... r05_run47: the isolated
-// pattern is exact, the kernels are not -- not root-caused).  The library is therefore built with -fma-mix-insts (build.py), and
-// the split is the plain subtraction everywhere.
+// behind the SiLU), and at 5e-5 again with the instruction family switched off (profiles/r05_run44 ... r05_run47).  The cause
+// (profiles/r05_run57_fma_mix_rounding.txt, tools/fma_mix_rounding.hip): v_fma_mixlo_f16(x, r, 0) rounds the EXACT product to f16
+// ONCE, (half)(float)(x * r) rounds twice, and they differ for 1 input in 15 000 -- and the compiler computes the one source-level
+// value hi = (half)(x * r) BOTH ways: v_mul_f32 + v_cvt_pk_f16_f32 for the high half that is stored (the f32 product exists anyway,
+// for the range guard), the mixed instruction for the one the low half is taken against.  For those inputs hi + lo is off by an
+// f16 ulp (2^-11).  The library is therefore built with -fma-mix-insts (build.py), and the split is the plain subtraction
+// everywhere.
 __device__ __forceinline__ pf_half pf_split_lo(float v, pf_half hi) { return (pf_half)(v - (float)hi); }
 // s_setprio: issue priority of this wave among the waves of its SIMD (0 = default .. 3).  A wave about to run a stretch of VALU
 // work next to waves that feed the matrix pipe (whose instructions keep that pipe busy for 8-16 cycles each) gets its issue slots
