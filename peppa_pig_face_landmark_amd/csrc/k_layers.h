@@ -223,14 +223,14 @@ struct FcArgs {
     int B, K, N, act, act2;
 };
 
-// Block = 64 outputs x 16 batch items; the 4 waves split every 128-wide K chunk four ways (32 k
-// each) so four times as many weight loads are in flight per CU; every weight is read once per 16
+// Block = 64 outputs x 8 batch items; the 4 waves split every 128-wide K chunk four ways (32 k
+// each) so four times as many weight loads are in flight per CU; every weight is read once per 8
 // items (consecutive lanes -> consecutive n, coalesced); x is staged through LDS and read as float4.
 #define PF_FC_BN 64
 #define PF_FC_BB 8
 #define PF_FC_MAXK 1024   // largest K staged whole (64 KB of LDS)
 #define PF_FC_KT 128
-// WHOLE_K: the 16 input vectors are staged in LDS once for all of K (K <= PF_FC_MAXK), so the k loop has
+// WHOLE_K: the 8 input vectors are staged in LDS once for all of K (K <= PF_FC_MAXK), so the k loop has
 // no barrier and the weight loads pipeline freely -- the SE bottleneck FCs (K up to 960, 64-240 blocks in
 // flight) were pure load-latency chains with the tile-by-tile version.  Same k -> thread assignment and
 // summation order in both variants.
