@@ -511,18 +511,21 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         a.w_pwl32 = (const float*)p.cptr(f[7]);
                         if (S != 1 || a.Cin != 16 || a.Mid16 != 16 || a.MidPad != 16 || a.CoutPad > 32) PF_FAIL(h, "dsconv: unsupported block shape");
                         // (exact f32 in f32s programs too: with no expand conv the block is bandwidth-bound, the split flavour measured 0.17 vs 0.16 ms)
-                        PF_LAUNCH((mbconv_wave_f32_kernel<1, 16, 4, 8, true>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
+                        if (a.act == PF_ACT_RELU) PF_LAUNCH((mbconv_wave_f32_kernel<1, 16, 4, 8, true, false, PF_ACT_RELU>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
+                        else PF_LAUNCH((mbconv_wave_f32_kernel<1, 16, 4, 8, true>), dim3(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B), dim3(256), h->stream, a);
                     } else if (f[21] == 1) {   // exact-f32 variant (high-resolution blocks), weights packed as f32
                         a.w_exp32 = (const float*)p.cptr(f[3]); a.w_pwl32 = (const float*)p.cptr(f[7]);
                         const int CP = f[15];
                         if (a.MidPad != a.Mid16 || a.CoutPad > 32) PF_FAIL(h, "mbconv(f32): unsupported block shape");
                         if (S == 2 && CP == 16) {
                             const dim3 g(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 4), 4), B);
-                            if (SPLIT) PF_LAUNCH((mbconv_wave_f32_kernel<2, 16, 4, 4, false, true>), g, dim3(256), h->stream, a);
+                            if (SPLIT && a.act == PF_ACT_RELU) PF_LAUNCH((mbconv_wave_f32_kernel<2, 16, 4, 4, false, true, PF_ACT_RELU>), g, dim3(256), h->stream, a);
+                            else if (SPLIT) PF_LAUNCH((mbconv_wave_f32_kernel<2, 16, 4, 4, false, true>), g, dim3(256), h->stream, a);
                             else PF_LAUNCH((mbconv_wave_f32_kernel<2, 16, 4, 4>), g, dim3(256), h->stream, a);
                         } else if (S == 1 && CP == 32) {
                             const dim3 g(pf_div_up(pf_div_up(to.H, 4) * pf_div_up(to.W, 8), 4), B);
-                            if (SPLIT) PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8, false, true>), g, dim3(256), h->stream, a);
+                            if (SPLIT && a.act == PF_ACT_RELU) PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8, false, true, PF_ACT_RELU>), g, dim3(256), h->stream, a);
+                            else if (SPLIT) PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8, false, true>), g, dim3(256), h->stream, a);
                             else PF_LAUNCH((mbconv_wave_f32_kernel<1, 32, 4, 8>), g, dim3(256), h->stream, a);
                         }
                         else PF_FAIL(h, "mbconv(f32): no kernel for stride %d, %d input channels", S, a.Cin);

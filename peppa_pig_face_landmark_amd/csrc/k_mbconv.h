@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256, MSPLIT > 1 ? 2 : 4) void mbconv_wave_kernel(Mb
 // and hi + lo fragments in the registers one f32 fragment took): 3 x 16 cycles instead of 4 x 32 per K block.  Weights are
 // scaled by a power of two and split when fetched (a.scale_exp / a.scale_pwl = 2^-s undo the scaling), activations are split
 // once per patch / per 16 depthwise channels.
-template <int S, int CP, int PH, int PW, bool NOEXP = false, bool SP = false>
+// ACT >= 0: the block's activation at compile time (round 5).  With the run-time switch every 16-pixel tile of the expand loop sat
+// between two scalar branches, so each tile's three dependent MFMAs ran to completion (s_nop 6) before its epilogue started and no
+// tile overlapped the next; without branches the compiler interleaves them.  The Student's three blocks here are all ReLU.
+template <int S, int CP, int PH, int PW, bool NOEXP = false, bool SP = false, int ACT = -1>
 __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
     unsigned amax = 0;                         // range guard (pf_common.h): only the SP variant splits anything
     const unsigned amax_seen = SP ? pf_amax_seen(a.range_slot) : 0u;
@@ -435,7 +438,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
                         for (int j = 0; j < 4; ++j) e = pf_mfma_16x16x4_f32(wv[kk][j], xf[mt][kk][j], e);
                 }
                 pf_f32x4 o = e + be;
-                pf_act_rh<4>(o, a.act);
+                if constexpr (ACT >= 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = pf_act_c<ACT>(o[r]);
+                } else pf_act_rh<4>(o, a.act);
                 *reinterpret_cast<pf_f32x4*>(es + (mt * 16 + frow) * EST + fk) = ((inside >> mt) & 1u) ? o : pf_f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -454,7 +460,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_wave_f32_kernel(MbconvArgs a) {
                     s = fmaf(wk[ky * 3 + kx], es[((py * S + ky) * HW + px * S + kx) * EST + dc], s);
             dv[i] = s;
         }
-        pf_act_rh<PP / 4>(dv, a.act);
+        if constexpr (ACT >= 0) {
+#pragma unroll
+            for (int i = 0; i < PP / 4; ++i) dv[i] = pf_act_c<ACT>(dv[i]);
+        } else pf_act_rh<PP / 4>(dv, a.act);
 #pragma unroll
         for (int i = 0; i < PP / 4; ++i) {
             const int px = PW == 4 ? dg : dg + 4 * (i & 1);

@@ -86,7 +86,7 @@ template <> struct PfVec<float> {
 };
 
 template <int ACT> __device__ __forceinline__ float pf_act_c(float v) {
-    if constexpr (ACT == PF_ACT_RELU) return v > 0.f ? v : 0.f;
+    if constexpr (ACT == PF_ACT_RELU) return __builtin_fmaxf(v, 0.f);   // ONE v_max_f32 (the select form compiles to a canonicalising v_max(v, v) plus the max; NaN -> 0 either way)
     else if constexpr (ACT == PF_ACT_HSWISH || ACT == PF_ACT_HSIGMOID) {
         // x * relu6(x + 3) / 6 with the division as a multiplication (onnxruntime's HardSigmoid alpha = 1/6 form)
         float r = v + 3.f;
