@@ -826,7 +826,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         tagbuf2[0] = 0;
                         if (h->profiling) snprintf(tagbuf2, sizeof(tagbuf2), "expdw%dx%ds2_c%d_n%d_%dx%d", K, K, a.inC, a.N, to.H, to.W);
                         ProfScope ps2(h, tagbuf2);
-                        PF_LAUNCH((expdw_image_s2_kernel<5>), dim3(B, pf_div_up(a.N, 16)), dim3(512), h->stream, a);
+                        if (a.act == PF_ACT_RELU) PF_LAUNCH((expdw_image_s2_kernel<5, PF_ACT_RELU>), dim3(B, pf_div_up(a.N, 16)), dim3(512), h->stream, a);
+                        else PF_LAUNCH((expdw_image_s2_kernel<5>), dim3(B, pf_div_up(a.N, 16)), dim3(512), h->stream, a);
                         break;
                     }
                     if (to.H == 32 && to.W == 32 && ti.H == 32 && ti.W == 32) {   // whole 32 x 32 image per workgroup, GEMM straight from global
@@ -837,7 +838,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         if (h->profiling) snprintf(tagbuf2, sizeof(tagbuf2), "expdw%dx%dd%d_c%d_n%d_%dx%d", K, K, dil, a.inC, a.N, to.H, to.W);
                         ProfScope ps2(h, tagbuf2);
                         dim3 g2(B, pf_div_up(a.N, 16));
-                        if (K == 5 && dil == 1) PF_LAUNCH((expdw_image_kernel<5, 1>), g2, dim3(512), h->stream, a);
+                        if (K == 5 && dil == 1 && a.act == PF_ACT_RELU) PF_LAUNCH((expdw_image_kernel<5, 1, PF_ACT_RELU>), g2, dim3(512), h->stream, a);
+                        else if (K == 5 && dil == 1) PF_LAUNCH((expdw_image_kernel<5, 1>), g2, dim3(512), h->stream, a);
                         else if (K == 3 && dil == 1) PF_LAUNCH((expdw_image_kernel<3, 1>), g2, dim3(512), h->stream, a);
                         else PF_FAIL(h, "expdw(32x32): no kernel for k%d dil %d", K, dil);
                         break;

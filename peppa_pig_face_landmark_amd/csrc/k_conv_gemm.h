@@ -1039,7 +1039,9 @@ __global__ __launch_bounds__(WARPS_M * WARPS_N * 64, BN >= 256 ? WARPS_M * WARPS
 // global memory (the image's 160 KB of input is re-read by the 8 channel tiles out of L2), splits them and runs
 // 3 MFMAs per 16 x 16 tile; the activated 32 x 32 x 16 tile (67 KB, rows padded so four rows land in different banks)
 // lives in LDS and the depthwise conv reads it there, thread = (channel, image row), as in the 16 x 16 kernel.
-template <int K, int DIL>
+// ACT >= 0: the activation at compile time (as in k_mbconv.h: the run-time switch put two scalar branches behind every 16-pixel tile of
+// the expand loop and the tiles could not overlap).
+template <int K, int DIL, int ACT = -1>
 __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
     unsigned amax = 0;                                 // range guard (pf_common.h)
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
@@ -1109,7 +1111,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
         pf_f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[r], a.acc_scale, bv[r]);
-        pf_act_rh<4>(v, a.act);
+        if constexpr (ACT >= 0) {
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) v[q_] = pf_act_c<ACT>(v[q_]);
+        } else pf_act_rh<4>(v, a.act);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (n0 + cch + r >= a.N) v[r] = 0.f;
@@ -1146,7 +1151,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
             }
         }
     }
-    pf_act_rh<HW>(o, a.act);
+    if constexpr (ACT >= 0) {
+#pragma unroll
+        for (int q_ = 0; q_ < HW; ++q_) o[q_] = pf_act_c<ACT>(o[q_]);
+    } else pf_act_rh<HW>(o, a.act);
     float rs = 0.f;
     if (cok) {
         float* out = static_cast<float*>(a.out) + ((size_t)b * HW * HW + (size_t)y * HW) * a.outLd + n;
@@ -1176,7 +1184,7 @@ __global__ __launch_bounds__(512, 4) void expdw_image_kernel(ConvGemmArgs a) {
 // pixels outside the image forced to 0 = the depthwise conv's zero padding), parked in LDS (78 KB) and consumed by the
 // strided depthwise conv, thread = (channel, output row, half row).  The SE squeeze is complete per workgroup because it
 // visits all four quadrants.  Input channels <= 32 (one K step).
-template <int K>
+template <int K, int ACT = -1>
 __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) {
     unsigned amax = 0;                                 // range guard (pf_common.h)
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
@@ -1243,7 +1251,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
             pf_f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[r], a.acc_scale, bv[r]);
-            pf_act_rh<4>(v, a.act);
+            if constexpr (ACT >= 0) {
+#pragma unroll
+                for (int q_ = 0; q_ < 4; ++q_) v[q_] = pf_act_c<ACT>(v[q_]);
+            } else pf_act_rh<4>(v, a.act);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (!ok || n0 + cch + r >= a.N) v[r] = 0.f;        // zero padding of the EXPANDED map / padding channels
@@ -1265,7 +1276,10 @@ __global__ __launch_bounds__(512, 4) void expdw_image_s2_kernel(ConvGemmArgs a) 
 #pragma unroll
                 for (int x = 0; x < OX; ++x) o[x] = fmaf(wk[ky * K + kx], iv[2 * x + kx], o[x]);
         }
-        pf_act_rh<OX>(o, a.act);
+        if constexpr (ACT >= 0) {
+#pragma unroll
+            for (int q_ = 0; q_ < OX; ++q_) o[q_] = pf_act_c<ACT>(o[q_]);
+        } else pf_act_rh<OX>(o, a.act);
         if (cok) {
             float* out = static_cast<float*>(a.out) + ((size_t)b * OUT * OUT + (size_t)(oy0 + y) * OUT + ox0 + xh * OX) * a.outLd + n;
 #pragma unroll
