@@ -298,7 +298,12 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
                 // work item = a run of tiles of one face; a face is split only while there are fewer faces than CUs
                 const int tpf = (a.outH * a.outW) / 128;
                 int segs = 1;
-                while (segs < tpf && (tpf % (2 * segs)) == 0 && B * segs < h->num_cus) segs *= 2;
+#ifdef PF_SIMT_EMULATION
+                const int fill = 8;                 // CPU test build: a few faces must still exercise items of SEVERAL tiles and several items per face
+#else
+                const int fill = h->num_cus;
+#endif
+                while (segs < tpf && (tpf % (2 * segs)) == 0 && B * segs < fill) segs *= 2;
                 a.head_segs = segs;
                 PF_LAUNCH((pw_head_kernel<4>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);
             }
