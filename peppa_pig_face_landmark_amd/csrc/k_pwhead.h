@@ -178,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void pw_head_kernel(ConvGemmArgs a) {
     // register copies right behind the request -- which wait for the data and undo the look-ahead ------------------------------------
     const int my_items = (nitems - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // host: grid <= nitems
     const int total = my_items * tps;               // tiles this workgroup visits, q = 0 .. total - 1
+    if (total <= 0) return;                         // (a grid larger than the item list: nothing to do, and no barrier has been reached yet)
     auto tile_of = [&](int q, int& face, int& seg, int& kk) {
         const int item = blockIdx.x + (q / tps) * gridDim.x;
         kk = q - (q / tps) * tps;
