@@ -340,10 +340,13 @@ class BatchPipelineWorkload:
     ROWS = 15120
 
     def __init__(self, batch, dev, frames: int, faces_per_frame: int, seed: int, lanes: int,
-                 graph: bool = True, frame_hw: Tuple[int, int] = (1080, 1920)):
+                 graph: bool = True, frame_hw: Tuple[int, int] = (1080, 1920), front: bool = True):
         import torch
         assert frames % lanes == 0
         self.batch, self.F, self.K, self.L = batch, frames, faces_per_frame, lanes
+        self.front = bool(front)
+        self.front_prof = {}
+        batch.set_option(_native.PF_OPT_BATCH_FRONT, 1 if front else 0)
         self.per = frames // lanes
         self.H, self.W = frame_hw
         self.graph = bool(graph)
@@ -406,9 +409,25 @@ class BatchPipelineWorkload:
                     d_scores=self.scores[f0 * self.K:].data_ptr())
 
     def profile(self, steps: int):
-        """Per-kernel HIP-event times of lane 0 running ALONE on its slice (profiling serialises its launches)."""
+        """Per-kernel HIP-event times.  Front mode (PF_OPT_BATCH_FRONT, the default): `steps` whole batch calls with profiling on
+        the front engine (letterbox + detector + NMS of ALL frames: ``self.front_prof``) and on lane 0 (crop + landmarks of its
+        slice: the return value); profiling serialises a handle's launches, the other lanes run alongside.  Per-lane mode: lane 0
+        running ALONE on its slice, everything in the return value and ``front_prof`` empty."""
         self.batch.sync()
         eng = self.batch.lane(0)
+        self.front_prof = {}
+        if self.front:
+            fr = self.batch.front()
+            fr.profile_enable(True)
+            eng.profile_enable(True)
+            for _ in range(steps):
+                self._run(False)
+                self.batch.sync()
+            self.front_prof = fr.profile_fetch()
+            prof = eng.profile_fetch()
+            fr.profile_enable(False)
+            eng.profile_enable(False)
+            return prof
         eng.profile_enable(True)
         for _ in range(steps):
             eng.run_frames_device(self.frames.data_ptr(), self.per, self.H, self.W, 0.5, 0.3, 1600.0, self.K, **self._lane_args(0))

@@ -238,13 +238,15 @@ int pf_comm_destroy(pf_handle* h);
  * out_mem == PF_MEM_DEVICE / PF_MEM_HOST_PINNED the call returns after enqueueing (results complete after pf_batch_sync);
  * with PF_MEM_HOST it synchronises.  pf_batch_lane() exposes a lane's handle (owned by the batch) for pf_profile_* and
  * the stage-level entry points; max_batch_per_lane of pf_batch_load_program bounds the frames (detector slot) / faces
- * (landmark slot) of ONE lane's slice. */
+ * (landmark slot) of ONE lane's slice; the front engine's detector copy is sized for lanes x that many frames. */
 typedef struct pf_batch pf_batch;
 int pf_batch_create(int device_id, int lanes, pf_batch** out);
 void pf_batch_destroy(pf_batch* b);
 const char* pf_batch_last_error(pf_batch* b);
 int pf_batch_lanes(pf_batch* b);
 pf_handle* pf_batch_lane(pf_batch* b, int lane);
+/* the engine that runs the detector + NMS half of a call for all lanes (PF_OPT_BATCH_FRONT; owned by the batch) -- for pf_profile_* */
+pf_handle* pf_batch_front(pf_batch* b);
 int pf_batch_load_program(pf_batch* b, int slot, const void* blob, size_t bytes, int max_batch_per_lane);
 int pf_batch_set_option(pf_batch* b, int option, int value);
 int pf_batch_sync(pf_batch* b);
@@ -270,7 +272,12 @@ enum { PF_OPT_HIP_GRAPH = 1,
        /* Synchronisation rounds queued by the self-synchronising sub-sequence decoder (1 .. 10; 0 = all 10).  Fewer rounds save
         * empty launches on ordinary photographs; a stream that needs more is decoded again on the host (synchronous call) or
         * reported at the next synchronisation (pf_decode_jpeg_batch) -- never passed on. */
-       PF_OPT_JPEG_SYNC_ROUNDS = 4 };
+       PF_OPT_JPEG_SYNC_ROUNDS = 4,
+       /* pf_batch_set_option only.  1 (default): a pf_batch_run_frames call on device-resident frames runs letterbox + detector +
+        * NMS / top-k ONCE, on all of its frames, on the batch's front engine, and the lanes run crop + landmarks of their slices
+        * behind it (the detector's launches are latency-bound: 96 frames cost 2.3 x what 32 do).  0: every lane detects its own
+        * slice (the only path for host-resident frames). */
+       PF_OPT_BATCH_FRONT = 5 };
 int pf_set_option(pf_handle* h, int option, int value);
 
 /* Per-kernel device time of the last call, accumulated with HIP events on the handle's stream

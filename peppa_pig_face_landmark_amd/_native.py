@@ -18,6 +18,7 @@ PF_INPUT_U8_NHWC, PF_INPUT_F32_NCHW = 0, 1
 PF_OPT_HIP_GRAPH = 1
 PF_OPT_RANGE_CHECK = 2
 PF_OPT_JPEG_ENTROPY, PF_OPT_JPEG_SYNC_ROUNDS = 3, 4       # entropy decoding: 0 automatic / 1 host / 2 device; sync rounds 1..10 (0 = all)
+PF_OPT_BATCH_FRONT = 5      # BatchEngine.set_option only: 1 (default) detector + NMS once per call on the front engine, 0 per lane
 PF_COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -89,6 +90,8 @@ def _declare(lib):
     lib.pf_batch_lanes.argtypes = [vp]
     lib.pf_batch_lane.argtypes = [vp, i]
     lib.pf_batch_lane.restype = vp
+    lib.pf_batch_front.argtypes = [vp]
+    lib.pf_batch_front.restype = vp
     lib.pf_batch_load_program.argtypes = [vp, i, vp, sz, i]
     lib.pf_batch_set_option.argtypes = [vp, i, i]
     lib.pf_batch_sync.argtypes = [vp]
@@ -611,6 +614,14 @@ class BatchEngine:
             e.lib, e.h, e.device, e._programs, e._borrowed = self.lib, C.c_void_p(h), self.device, {}, True
             self._lane_engines[i] = e
         return self._lane_engines[i]
+
+    def front(self) -> "Engine":
+        """The engine that runs letterbox + detector + NMS of a whole call (``PF_OPT_BATCH_FRONT``), for profiling."""
+        if "front" not in self._lane_engines:
+            e = Engine.__new__(Engine)
+            e.lib, e.h, e.device, e._programs, e._borrowed = self.lib, C.c_void_p(self.lib.pf_batch_front(self.b)), self.device, {}, True
+            self._lane_engines["front"] = e
+        return self._lane_engines["front"]
 
     def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
         return self._host.pinned_empty(shape, dtype)

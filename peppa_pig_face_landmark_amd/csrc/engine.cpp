@@ -72,7 +72,7 @@ struct Program {
 
 struct ProfEntry { double ms = 0; int count = 0; };
 
-struct GraphKey { const void* p[6]; int i[5]; float f[3]; unsigned long long epoch; };
+struct GraphKey { const void* p[6]; int i[6]; float f[3]; unsigned long long epoch; };      // i[5]: 0 whole pf_run_frames call, 1 front half, 2 tail half (pipeline.inl)
 struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
 
 }  // namespace
@@ -196,6 +196,12 @@ static void det_pick_tile(int num_cus, int outH, int outW, int S, int max_rows, 
             if (cost < best) { best = cost; *TH = th; *TW = tw; }
         }
     }
+}
+
+// pf_div_small (pf_common.h) is exact for 0 <= x < min(4096, 2^20 / d): launch sites whose kernels divide a staging index by a tile-derived
+// row length check the largest index they will produce against that domain instead of trusting the hard-coded tile
+static inline bool pf_div_small_domain_ok(int max_x_exclusive, int d) {
+    return d > 0 && max_x_exclusive <= 4096 && (long long)max_x_exclusive <= (1ll << 20) / d;
 }
 
 template <typename T, bool SPLIT>
@@ -385,6 +391,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         s.B = B; s.H = p.hdr.in_h; s.W = p.hdr.in_w; s.OH = to.H; s.OW = to.W; s.act = a.act;
                         s.TH = 8; s.TW = 32; s.tilesX = pf_div_up(to.W, s.TW);
                         s.range_slot = slot_of(oi);
+                        // the float-input staging loop divides i < IRH * IRW * 3 by IRW * 3 with pf_div_small (IRH = 2 TH + 1, IRW = 2 TW + 1)
+                        if (!pf_div_small_domain_ok((2 * s.TH + 1) * (2 * s.TW + 1) * 3, (2 * s.TW + 1) * 3)) PF_FAIL(h, "stem: tile %dx%d outside pf_div_small's exact range", s.TH, s.TW);
                         const dim3 sg(s.tilesX * pf_div_up(to.H, s.TH), B);
                         // tile 8 x 32 output pixels: image region 17 rows x 65 pixels (200 halves per LDS row)
                         if (to.C == 16) {
@@ -611,6 +619,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (to.C != 16 || a.OH != (a.SH + 1) / 2 || a.OW != (a.SW + 1) / 2) PF_FAIL(h, "detstem: inconsistent shapes");
                     a.TH = 4; a.TW = 16; a.tilesX = pf_div_up(a.OW, a.TW);
                     a.range_slot = slot_of(oi);
+                    // the float-input staging loop divides i < IRH * IRW * 3 by IRW * 3 with pf_div_small (IRH = 4 TH + 3, IRW = 4 TW + 3)
+                    if (!pf_div_small_domain_ok((4 * a.TH + 3) * (4 * a.TW + 3) * 3, (4 * a.TW + 3) * 3)) PF_FAIL(h, "detstem: tile %dx%d outside pf_div_small's exact range", a.TH, a.TW);
                     ProfScope ps(h, "stem_block");
                     if ((a.W & 3) || ((size_t)d_input & 3)) PF_FAIL(h, "detstem: the image width must be a multiple of 4 and the input 4-byte aligned");
                     // tile 4 x 16: stem_1 region 9 x 33 = 297 (304 rows), image region 19 rows x 67 pixels (208 halves per LDS row)
@@ -897,7 +907,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     if (ti.H != 16 || ti.W != 16 || (ti.C & 3) || ti.C > 32 * KS || (ti.ld & 3) || pad != dil * (K - 1) / 2 || mode < 0 || mode > 3 ||
                         (a.act != PF_ACT_RELU && a.act != PF_ACT_HSWISH) || a.T < 1 || a.CEXP > 32 * a.T || (nw != 8 && nw != 16) ||
                         (proj && (!a.out || !a.w2 || !a.b2 || (a.outLd & 3) || p.tens[f[1]].C != Cout || (a.res && (a.resLd & 3)))) ||
-                        (sq && !a.gap_out) || (mode == 2 && !a.gate) || (mode == 3 && (!a.out || (a.outLd & 1) || p.tens[f[1]].C < a.CEXP)))
+                        (sq && !a.gap_out) || (mode == 2 && (!a.gate || (a.CEXP & 31))) ||      // mode 2 DMAs whole 32-float gate tiles of the face
+                         (mode == 3 && (!a.out || (a.outLd & 1) || p.tens[f[1]].C < a.CEXP)))
                         PF_FAIL(h, "mbx: unsupported shape (%dx%dx%d, k%d pad %d dil %d, mode %d, %d waves)", ti.H, ti.W, ti.C, K, pad, dil, mode, nw);
                     char tagbuf[96];
                     tagbuf[0] = 0;

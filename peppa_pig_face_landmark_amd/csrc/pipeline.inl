@@ -111,13 +111,15 @@ int run_detector_stage(pf_handle* h, const unsigned char* d_frames, int F, int H
 }
 
 int run_nms_stage(pf_handle* h, const float* d_rows, int rows, int F, const LetterboxGeom& g,
-                  float score_thres, float iou_thres, float min_face, int top_k, bool select) {
+                  float score_thres, float iou_thres, float min_face, int top_k, bool select,
+                  float* sel_boxes_out = nullptr, int* sel_count_out = nullptr) {
     PipelineScratch& s = h->pipe;
     NmsArgs na{};
     // letterbox geometry travels by value in the kernel arguments, so a captured graph carries its own copy
     na.lb_scale = (float)g.scale; na.lb_left = (float)g.left; na.lb_top = (float)g.top;
     na.rows = d_rows; na.keep_rows = s.d_keep_rows; na.keep_count = s.d_keep_count;
-    na.sel_boxes = select ? s.d_sel_boxes : nullptr; na.sel_count = s.d_sel_count;
+    // (the front lane of a pf_batch selects into buffers the landmark lanes read: batch.inl)
+    na.sel_boxes = select ? (sel_boxes_out ? sel_boxes_out : s.d_sel_boxes) : nullptr; na.sel_count = sel_count_out ? sel_count_out : s.d_sel_count;
     na.keys = s.d_nms_keys; na.flags = s.d_nms_flags; na.cand_count = s.d_cand_count;
     na.R = rows; na.cap = next_pow2(std::max(s.cap_rows, 2)); na.max_keep = kMaxKeep; na.top_k = top_k;
     na.score_thres = score_thres; na.iou_thres = iou_thres; na.min_face = min_face;
@@ -255,25 +257,19 @@ static int landmarks_impl(pf_handle* h, const uint8_t* bgr, int mem, int height,
     return 0;
 }
 
-static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
-                              const float* det_rows, int rows, float score_thres, float iou_thres,
-                              float min_face, int top_k,
-                              int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+// The two halves of a pf_run_frames call.  FRONT: letterbox + detector network + NMS / top-k of F frames -> selected boxes and
+// counts (into the handle's own scratch, or into `sel_boxes_out` / `sel_count_out`).  TAIL: crop + landmark network + result
+// copies of F frames whose boxes / counts are `d_boxes` / `d_counts`.  enqueue_run_frames is front + tail on one handle; a
+// pf_batch (batch.inl) runs ONE front for all frames of a call on its front engine and one tail per lane.
+static int enqueue_front(pf_handle* h, const unsigned char* d_frames, int F, int height, int width,
+                         const float* det_rows, bool rows_on_device, int rows, float score_thres, float iou_thres,
+                         float min_face, int top_k, float* sel_boxes_out, int* sel_count_out) {
     Program& det = h->prog[PF_NET_DETECTOR];
-    Program& lm = h->prog[PF_NET_LANDMARK];
-    if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
     if (!det.loaded && !det_rows) PF_FAIL(h, "no detector program and no planted rows");
-    if (!frames || n_frames < 1 || height < 1 || width < 1 || top_k < 1) PF_FAIL(h, "pf_run_frames: bad arguments");
-    PF_HIP(h, hipSetDevice(h->device));
-    const int F = n_frames, faces = F * top_k;
     const int det_nrows = det.loaded ? det.bufs[det.hdr.out_buf0].elems_per_item / 16 : rows;
     if (det_rows && det.loaded && rows != det_nrows) PF_FAIL(h, "planted rows %d != detector rows %d", rows, det_nrows);
-    if (ensure_pipeline(h, F, faces, top_k, det_nrows)) return 1;
+    if (ensure_pipeline(h, F, 0, top_k, det_nrows)) return 1;
     const int row_stride = width * 3;
-    const unsigned char* d_frames = nullptr;
-    const bool rows_on_device = (mem & 0xff) == PF_MEM_DEVICE || (mem & PF_MEM_ROWS_DEVICE) != 0;
-    mem &= 0xff;
-    if (stage_frames(h, frames, mem, (size_t)F * height * row_stride, &d_frames)) return 1;
     const int in_h = det.loaded ? det.hdr.in_h : 384, in_w = det.loaded ? det.hdr.in_w : 640;
     const LetterboxGeom g = letterbox_geom(height, width, in_h, in_w);
     if (det.loaded) {
@@ -291,15 +287,96 @@ static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int 
             d_rows = h->pipe.d_rows_planted;
         }
     }
-    if (run_nms_stage(h, d_rows, det_nrows, F, g, score_thres, iou_thres, min_face, top_k, true)) return 1;
-    if (run_landmark_stage(h, d_frames, height, width, row_stride, h->pipe.d_sel_boxes, h->pipe.d_sel_count, faces, top_k)) return 1;
+    return run_nms_stage(h, d_rows, det_nrows, F, g, score_thres, iou_thres, min_face, top_k, true, sel_boxes_out, sel_count_out);
+}
+
+static int enqueue_tail(pf_handle* h, const unsigned char* d_frames, int F, int height, int width, const float* d_boxes,
+                        const int* d_counts, int top_k, int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
+    const int faces = F * top_k;
+    if (ensure_pipeline(h, 0, faces, 0, 0)) return 1;
+    if (run_landmark_stage(h, d_frames, height, width, width * 3, d_boxes, d_counts, faces, top_k)) return 1;
     const hipMemcpyKind kind = out_mem == PF_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (counts) PF_HIP(h, hipMemcpyAsync(counts, h->pipe.d_sel_count, (size_t)F * sizeof(int), kind, h->stream));
-    if (boxes) PF_HIP(h, hipMemcpyAsync(boxes, h->pipe.d_sel_boxes, (size_t)faces * 4 * sizeof(float), kind, h->stream));
+    if (counts) PF_HIP(h, hipMemcpyAsync(counts, d_counts, (size_t)F * sizeof(int), kind, h->stream));
+    if (boxes) PF_HIP(h, hipMemcpyAsync(boxes, d_boxes, (size_t)faces * 4 * sizeof(float), kind, h->stream));
     if (kps) PF_HIP(h, hipMemcpyAsync(kps, h->pipe.d_kps, (size_t)faces * kNumPoints * 2 * sizeof(float), kind, h->stream));
     if (scores) PF_HIP(h, hipMemcpyAsync(scores, lm.buf_ptr(lm.hdr.out_buf1), (size_t)faces * kNumPoints * sizeof(float), kind, h->stream));
     return 0;
 }
+
+static int enqueue_run_frames(pf_handle* h, const uint8_t* frames, int mem, int n_frames, int height, int width,
+                              const float* det_rows, int rows, float score_thres, float iou_thres,
+                              float min_face, int top_k,
+                              int* counts, float* boxes, float* kps, float* scores, int out_mem) {
+    Program& det = h->prog[PF_NET_DETECTOR];
+    Program& lm = h->prog[PF_NET_LANDMARK];
+    if (!lm.loaded) PF_FAIL(h, "landmark program not loaded");
+    if (!det.loaded && !det_rows) PF_FAIL(h, "no detector program and no planted rows");
+    if (!frames || n_frames < 1 || height < 1 || width < 1 || top_k < 1) PF_FAIL(h, "pf_run_frames: bad arguments");
+    PF_HIP(h, hipSetDevice(h->device));
+    const int F = n_frames;
+    const int det_nrows = det.loaded ? det.bufs[det.hdr.out_buf0].elems_per_item / 16 : rows;
+    if (ensure_pipeline(h, F, F * top_k, top_k, det_nrows)) return 1;      // one (re)allocation round for both halves
+    const unsigned char* d_frames = nullptr;
+    const bool rows_on_device = (mem & 0xff) == PF_MEM_DEVICE || (mem & PF_MEM_ROWS_DEVICE) != 0;
+    mem &= 0xff;
+    if (stage_frames(h, frames, mem, (size_t)F * height * width * 3, &d_frames)) return 1;
+    if (enqueue_front(h, d_frames, F, height, width, det_rows, rows_on_device, rows, score_thres, iou_thres, min_face, top_k, nullptr, nullptr)) return 1;
+    return enqueue_tail(h, d_frames, F, height, width, h->pipe.d_sel_boxes, h->pipe.d_sel_count, top_k, counts, boxes, kps, scores, out_mem);
+}
+
+// hipGraph cache of a handle (PF_OPT_HIP_GRAPH): `enqueue` is launched eagerly the first time `key` is seen (which also performs
+// every lazy allocation / constant upload), captured into a hipGraph the second time and replayed from then on.
+extern "C++" {
+template <typename Enqueue>
+static int graphed_call(pf_handle* h, GraphKey key, Enqueue&& enqueue) {
+    key.epoch = h->alloc_epoch;
+    // any (re)allocation since a graph was captured -- scratch growth for a larger call, a program reload -- may have
+    // freed memory the graph's kernel arguments point at: drop every graph captured under an older epoch
+    if (!h->graphs.empty() && h->graphs.front().key.epoch != h->alloc_epoch) {
+        for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        h->graphs.clear();
+    }
+    GraphEntry* e = nullptr;
+    for (auto& g : h->graphs)
+        if (memcmp(&g.key, &key, sizeof(key)) == 0) { e = &g; break; }
+    if (!e) {   // first sighting: run eagerly
+        if (h->graphs.size() >= 16) {
+            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+        }
+        GraphEntry ne{};
+        ne.key = key;
+        h->graphs.push_back(ne);
+        const int rc = enqueue();
+        if (h->alloc_epoch != key.epoch) {   // this eager run (re)allocated scratch: older graphs are stale, this entry is not
+            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+            h->graphs.clear();
+            ne.key.epoch = h->alloc_epoch;
+            if (!rc) h->graphs.push_back(ne);
+        } else if (rc) {
+            h->graphs.pop_back();
+        }
+        return rc;
+    }
+    if (!e->exec) {
+        PF_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true;
+        const int rc = enqueue();
+        h->capturing = false;
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
+        if (ce != hipSuccess || !graph) PF_FAIL(h, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+        const hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess) { e->exec = nullptr; PF_FAIL(h, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+    }
+    PF_HIP(h, hipGraphLaunch(e->exec, h->stream));
+    return 0;
+}
+}  // extern "C++"
 
 // With PF_OPT_HIP_GRAPH on and everything device resident, the ~170 launches of one call are captured
 // into a hipGraph the second time the same (pointers, shapes, thresholds) key is seen and replayed from
@@ -327,52 +404,10 @@ int pf_run_frames_planted(pf_handle* h, const uint8_t* frames, int mem, int n_fr
     key.p[0] = frames; key.p[1] = det_rows; key.p[2] = counts; key.p[3] = boxes; key.p[4] = kps; key.p[5] = scores;
     key.i[0] = n_frames; key.i[1] = height; key.i[2] = width; key.i[3] = rows; key.i[4] = top_k;
     key.f[0] = score_thres; key.f[1] = iou_thres; key.f[2] = min_face;
-    key.epoch = h->alloc_epoch;
-    // any (re)allocation since a graph was captured -- scratch growth for a larger call, a program reload -- may have
-    // freed memory the graph's kernel arguments point at: drop every graph captured under an older epoch
-    if (!h->graphs.empty() && h->graphs.front().key.epoch != h->alloc_epoch) {
-        for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        h->graphs.clear();
-    }
-    GraphEntry* e = nullptr;
-    for (auto& g : h->graphs)
-        if (memcmp(&g.key, &key, sizeof(key)) == 0) { e = &g; break; }
-    if (!e) {   // first sighting: run eagerly (this also performs every lazy allocation / constant upload)
-        if (h->graphs.size() >= 16) {
-            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-            h->graphs.clear();
-        }
-        GraphEntry ne{};
-        ne.key = key;
-        h->graphs.push_back(ne);
-        const int rc = enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
-                                          top_k, counts, boxes, kps, scores, out_mem);
-        if (h->alloc_epoch != key.epoch) {   // this eager run (re)allocated scratch: older graphs are stale, this entry is not
-            for (auto& g : h->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-            h->graphs.clear();
-            ne.key.epoch = h->alloc_epoch;
-            if (!rc) h->graphs.push_back(ne);
-        } else if (rc) {
-            h->graphs.pop_back();
-        }
-        return rc;
-    }
-    if (!e->exec) {
-        PF_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        h->capturing = true;
-        const int rc = enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres,
-                                          min_face, top_k, counts, boxes, kps, scores, out_mem);
-        h->capturing = false;
-        hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(h->stream, &graph);
-        if (rc) { if (graph) (void)hipGraphDestroy(graph); return 1; }
-        if (ce != hipSuccess || !graph) PF_FAIL(h, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
-        const hipError_t ie = hipGraphInstantiate(&e->exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) { e->exec = nullptr; PF_FAIL(h, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
-    }
-    PF_HIP(h, hipGraphLaunch(e->exec, h->stream));
-    return 0;
+    return graphed_call(h, key, [&]() {
+        return enqueue_run_frames(h, frames, mem, n_frames, height, width, det_rows, rows, score_thres, iou_thres, min_face,
+                                  top_k, counts, boxes, kps, scores, out_mem);
+    });
 }
 
 int pf_host_alloc(size_t bytes, void** out) {

@@ -644,6 +644,7 @@ class ProgramBuilder:
             hid = self.fc(gap, w_rd, b_rd, "relu")
             gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
             return self.conv(dwt, w_pwl, b_pwl, "none", res=res, gate_buf=gate, out_name=out_name)
+        assert mid % 32 == 0, "the recompute pass fetches the face's gates in whole 32-channel tiles (k_mbx.h dma_ct)"
         out = self.tensor(ti.H, ti.W, cout, name=out_name)
         self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1, 16], [self._tb(x)], [gap])
         hid = self.fc(gap, w_rd, b_rd, "relu")

@@ -174,8 +174,10 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 wt, b = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn2"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, out_name=f"{p}.out")
             elif fuse_mbx and kind == "ir" and pb.mbx_supported(x, k, s, pad, cur_dil, cout, se):
-                # stages 3-5 at 16 x 16: the whole block with the face's input stationary in registers (csrc/k_mbx.h); an SE block is
-                # squeeze pass -> two FCs -> recompute + gate + project, the expanded tensor never in HBM
+                # stages 3-5 at 16 x 16: the whole block with the face's input stationary in registers (csrc/k_mbx.h).  An SE block is,
+                # by default (ir.mbx se_mode "store"), a squeeze pass that also STORES the activated depthwise map -> the SE FC pair ->
+                # the layer-wise gated projection reading that map back; mbx_se="recompute" is the A/B alternative (second pass
+                # recomputes expand + depthwise, the expanded tensor never in HBM -- measured slower for every block)
                 we, be = ir.fold_bn(w[f"{p}.conv_pw.weight"], None, _bn(w, f"{p}.bn1"))
                 wd, bd = ir.fold_bn(w[f"{p}.conv_dw.weight"], None, _bn(w, f"{p}.bn2"))
                 wl, bl = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))

@@ -45,6 +45,60 @@ def test_batch_equals_single_engine_emu(emu_library, student_weights, F, lanes):
         assert np.array_equal(r, g) and np.array_equal(r, g2)
 
 
+@pytest.mark.parametrize("F,lanes,with_det", [(5, 3, False), (4, 2, True), (2, 3, False)])
+def test_batch_front_engine_equals_per_lane_path_emu(emu_library, student_weights, detector_weights, F, lanes, with_det):
+    """Round 6: with device-resident frames a call runs letterbox + detector + NMS ONCE on the front engine and the lanes run crop +
+    landmarks of their slices behind an event (PF_OPT_BATCH_FRONT, default on).  On the emulator device memory is host memory, so
+    numpy buffers stand in: every array bit-identical with the per-lane path (option 0) and with one engine, over two calls (the
+    selected boxes are double-buffered by call parity), ragged splits, with and without a detector program behind the planted rows."""
+    S, top_k = 64, 3
+    blob, _ = build_student_program(student_weights, S, "f32")
+    frames, rows = _small_inputs(F)
+    frames, rows = np.ascontiguousarray(frames), np.ascontiguousarray(rows, np.float32)
+    det_blob = None
+    if with_det:
+        # the detector's own rows are computed (and replaced by the planted ones, as in bench.py): the planted rows must have the
+        # program's row count, 3 anchors x (12 x 20 + 6 x 10 + 3 x 5) = 945 at 96 x 160.  Boxes planted past row 945 are lost: the
+        # single-engine reference below sees the same rows.
+        det_blob = build_detector_program(detector_weights, (96, 160), "f32")[0]
+        rows = np.ascontiguousarray(rows[:, :945])
+    one = _native.Engine(0, emu_library)
+    one.load_program(0, blob, F * top_k)
+    if det_blob is not None:
+        one.load_program(_native.PF_NET_DETECTOR, det_blob, F)       # (the letterbox geometry follows the detector's input size)
+    ref = one.run_frames(frames, 0.5, 0.3, 100.0, top_k, planted_rows=rows)
+    one.close()
+    per = (F + lanes - 1) // lanes
+
+    def run(front_mode):
+        be = _native.BatchEngine(0, lanes, emu_library)
+        be.set_option(_native.PF_OPT_BATCH_FRONT, front_mode)
+        be.load_program(0, blob, per * top_k)
+        if det_blob is not None:
+            be.load_program(_native.PF_NET_DETECTOR, det_blob, per)
+        outs = []
+        for rep in range(3):            # parity 0, 1, 0: the third call waits for the events of the first
+            counts = np.zeros((F,), np.int32)
+            boxes = np.zeros((F, top_k, 4), np.float32)
+            kps = np.zeros((F, top_k, 98, 2), np.float32)
+            scores = np.zeros((F, top_k, 98), np.float32)
+            be.run_frames_device(frames.ctypes.data, F, 270, 480, 0.5, 0.3, 100.0, top_k, d_planted=rows.ctypes.data, rows=rows.shape[1],
+                                 d_counts=counts.ctypes.data, d_boxes=boxes.ctypes.data, d_kps=kps.ctypes.data, d_scores=scores.ctypes.data)
+            be.sync()
+            outs.append((counts, boxes.reshape(F, top_k, 4), kps, scores))
+        be.close()
+        return outs
+
+    assert int(ref[0].sum()) > 0
+    for mode in (1, 0):
+        for got in run(mode):
+            for r, g in zip(ref, got):
+                # rows of a frame beyond its count are undefined (run_frames' contract): compare what is defined
+                for f in range(F):
+                    n = int(ref[0][f])
+                    assert np.array_equal(np.asarray(r[f])[:n] if r.ndim > 1 else r[f], np.asarray(g[f])[:n] if g.ndim > 1 else g[f]), (mode, f)
+
+
 def test_batch_errors_name_the_lane_emu(emu_library, student_weights):
     be = _native.BatchEngine(0, 2, emu_library)
     frames, rows = _small_inputs(2)

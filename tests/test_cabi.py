@@ -123,7 +123,14 @@ def test_library_has_no_mixed_precision_fma(hip_library, tmp_path):
     subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True)
     objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
     assert objs
+    n_mfma, symbols = 0, ""
     for co in objs:
         asm = subprocess.run([objdump, "-d", str(co)], check=True, capture_output=True, text=True).stdout
-        assert "v_mfma_f32_16x16x32" in asm or "s_endpgm" in asm
+        assert "s_endpgm" in asm, "%s did not disassemble as gfx950 code" % co.name
+        n_mfma += asm.count("v_mfma_f32_16x16x32")
+        symbols += asm
         assert "v_fma_mix" not in asm, "%s contains mixed-precision fma instructions" % co.name
+    # the check above is vacuous on an empty or mis-extracted disassembly: the product's matrix instruction and two kernels every
+    # build contains must have been seen
+    assert n_mfma > 100, "only %d v_mfma_f32_16x16x32 in the disassembly: extraction broken?" % n_mfma
+    assert "conv3x3_hero_kernel" in symbols and "mbx_kernel" in symbols, "known kernel symbols missing from the disassembly"
