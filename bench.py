@@ -151,6 +151,8 @@ def parse_args():
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
                     "(a sustained rate an external GPU-busy sampler can see)")
     ap.add_argument("--jpeg-threads", type=int, default=4, help="host threads per lane that strip the byte stuffing in the JPEG-file ingest probe")
+    ap.add_argument("--no-front2", action="store_true", help="A/B aid: conv_stem and blocks.0.0 as two launches (round 5) instead of the fused lm_front2_kernel")
+    ap.add_argument("--no-fc-pairs", action="store_true", help="A/B aid: the SE / cSE / ASPP-pool FC pairs as two fc launches each (round 5) instead of one fc2 launch")
     ap.add_argument("--no-front", action="store_true", help="A/B aid: every lane runs the detector + NMS of its own slice (the round-5 "
                     "flow) instead of one front-engine pass over all frames of a step (PF_OPT_BATCH_FRONT = 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -453,6 +455,10 @@ def main():
             skw["mbx_se"] = args.mbx
         if args.mbx_waves != 16:
             skw["mbx_waves"] = args.mbx_waves
+        if args.no_fc_pairs:
+            skw["fuse_fc_pairs"] = False
+        if args.no_front2:
+            skw["fuse_front2"] = False
     blobs = bs.build_programs(workload, args.dtype, args.model, **skw) if rank == 0 else None
     slots = [PF_NET_LANDMARK] + ([PF_NET_DETECTOR] if workload == "pipeline" else [])
 

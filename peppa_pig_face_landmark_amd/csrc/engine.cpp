@@ -20,6 +20,7 @@
 #include "k_chain.h"
 #include "k_det.h"
 #include "k_front.h"
+#include "k_front2.h"
 #include "k_hrb.h"
 #include "k_hero.h"
 #include "k_sepup.h"
@@ -440,10 +441,11 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     const bool patch_ok = (to.W == 16 || to.W == 32 || to.W == 64) && ((to.H * to.W) % 128) == 0 && (tl.C % 32) == 0 && a.Cpad <= 640;
                     // producer / consumer pipelined kernel (k_sepup.h): persistent workgroups, one per CU
                     const bool pipe_ok = patch_ok && (to.H * to.W) / 128 >= 2 && (tk.C % 8) == 0 && tk.C <= 64 && a.N == a.Npad && (a.Npad == 128 || a.Npad == 256) &&
-                                         f[13] > 0 && f[14] > 0 && !(host_dbg(h) & 2048);
+                                         f[13] > 0 && f[14] > 0 && f[15] > 0 && !(host_dbg(h) & 2048);
                     if (pipe_ok) {
                         SepupArgs s{};
                         s.lo = a.up_lo; s.skip = a.up_skip; s.out = (float*)a.out; s.dw_lo = (const float*)p.cptr(f[14]); s.dw_w2 = a.dw_w2;
+                        s.dw_v = (const float*)p.cptr(f[15]);
                         s.wt = (const unsigned char*)a.wt; s.bias = a.bias; s.skipx = (unsigned char*)p.buf_ptr(f[13]);
                         s.B = B; s.H = to.H; s.C1 = tl.C; s.C2 = tk.C; s.loLd = tl.ld; s.skipLd = tk.ld; s.outLd = to.ld;
                         s.N = a.N; s.Cpad = a.Cpad; s.act = a.act; s.acc_scale = a.acc_scale; s.dbg = h->dbg; s.range_slot = a.range_slot;
@@ -455,12 +457,13 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         const int per_xcd = ((B + 7) / 8) * tpf;                  // tiles of the busiest XCD
                         const int wgs = 8 * std::min(h->num_cus / 8, per_xcd);
                         const dim3 sg(B * tpf);
+// (VCOL: at W = 16 a tile is eight image rows and their eight filter sets do not fit the request stage)
 #define PF_SEPUP_CASE(WW)                                                                                          \
     if (to.W == WW) {                                                                                              \
         if (nskip > 0 && tk.C <= 32) PF_LAUNCH((sepup_skip_kernel<WW, 32>), sg, dim3(512), h->stream, s);          \
         else if (nskip > 0) PF_LAUNCH((sepup_skip_kernel<WW, 64>), sg, dim3(512), h->stream, s);                   \
-        if (a.Npad == 128) PF_LAUNCH((sepup_pipe_kernel<128, WW, 3, false, true>), dim3(wgs), dim3(1024), h->stream, s);     \
-        else PF_LAUNCH((sepup_pipe_kernel<256, WW, 2, true, false>), dim3(wgs), dim3(1024), h->stream, s);                   \
+        if (a.Npad == 128) PF_LAUNCH((sepup_pipe_kernel<128, WW, 3, false, true, false, false, (WW >= 32)>), dim3(wgs), dim3(1024), h->stream, s);     \
+        else PF_LAUNCH((sepup_pipe_kernel<256, WW, 2, true, false, false, false, (WW >= 32)>), dim3(wgs), dim3(1024), h->stream, s);                   \
     }
                         PF_SEPUP_CASE(64) PF_SEPUP_CASE(32) PF_SEPUP_CASE(16)
 #undef PF_SEPUP_CASE
@@ -627,6 +630,28 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     const dim3 sg(persistent_grid(a.tilesX * pf_div_up(a.OH, a.TH) * B, 3));     // persistent: three workgroups per CU walk the tiles
                     if (a.in_f32_nchw) PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, true, 256>), sg, dim3(256), h->stream, a);
                     else PF_LAUNCH((det_stem_kernel<64, 304, 19, 208, false, 256>), sg, dim3(256), h->stream, a);
+                }
+                break;
+            }
+            case PF_OP_FRONT2: {
+                if constexpr (!SPLIT) {
+                    PF_FAIL(h, "fused stem + first block op needs a split-precision (f32s) program");
+                } else {
+                    const PfTensorRec& to = p.tens[f[0]];
+                    Front2Args a{};
+                    a.in = d_input; a.out = (float*)p.tensor_ptr(f[0]); a.outLd = to.ld;
+                    a.w_u8 = (const pf_half*)p.cptr(f[1]); a.w_f32 = (const pf_half*)p.cptr(f[2]); a.b_stem = (const float*)p.cptr(f[3]);
+                    memcpy(&a.s_u8, &f[4], 4); memcpy(&a.s_f32, &f[5], 4);
+                    a.act_stem = f[6];
+                    a.w_dw = (const float*)p.cptr(f[7]); a.b_dw = (const float*)p.cptr(f[8]); a.w_pw = (const float*)p.cptr(f[9]); a.b_pw = (const float*)p.cptr(f[10]);
+                    a.B = B; a.H = p.hdr.in_h; a.W = p.hdr.in_w; a.OH = to.H; a.OW = to.W; a.tilesX = pf_div_up(to.W, 32);
+                    a.range_slot = slot_of(oi);
+                    if (to.C != 16 || (to.ld & 3) || to.H != (a.H + 1) / 2 || to.W != (a.W + 1) / 2 || (a.W & 3) || ((size_t)d_input & 3))
+                        PF_FAIL(h, "front2: unsupported shapes (%dx%d input, %dx%dx%d output)", a.H, a.W, to.H, to.W, to.C);
+                    ProfScope ps(h, "stem_block0");
+                    const dim3 grid(a.tilesX * pf_div_up(to.H, 8), B);
+                    if (input_kind == PF_INPUT_F32_NCHW) PF_LAUNCH((lm_front2_kernel<true>), grid, dim3(256), h->stream, a);
+                    else PF_LAUNCH((lm_front2_kernel<false>), grid, dim3(256), h->stream, a);
                 }
                 break;
             }
@@ -981,6 +1006,20 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 ProfScope ps(h, "fc");
                 if (a.K <= PF_FC_MAXK) PF_LAUNCH(fc_kernel<true>, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
                 else PF_LAUNCH(fc_kernel<false>, dim3(pf_div_up(a.N, PF_FC_BN), pf_div_up(B, PF_FC_BB)), dim3(256), h->stream, a);
+                break;
+            }
+            case PF_OP_FC2: {
+                Fc2Args a{};
+                a.x = (const float*)p.buf_ptr(f[0]); a.y = (float*)p.buf_ptr(f[1]);
+                a.w1 = (const float*)p.cptr(f[2]); a.b1 = (const float*)p.cptr(f[3]);
+                a.K = f[4]; a.R = f[5]; a.act1 = f[6];
+                a.scale2 = (const float*)p.cptr(f[7]); a.shift2 = (const float*)p.cptr(f[8]); a.act1b = f[9];
+                a.w2 = (const float*)p.cptr(f[10]); a.b2 = (const float*)p.cptr(f[11]); a.N = f[12]; a.act2 = f[13];
+                a.B = B;
+                if (a.K < 1 || a.K > 960 || a.R < 4 || a.R > 960 || (a.R & 3) || a.N < 4 || a.N > 960 || (a.N & 3) || !a.w1 || !a.w2 || (a.scale2 && !a.shift2))
+                    PF_FAIL(h, "fc2: unsupported shape %d -> %d -> %d", a.K, a.R, a.N);
+                ProfScope ps(h, "fc");
+                PF_LAUNCH(fc2_kernel, dim3(pf_div_up(B, PF_FC2_FB)), dim3(1024), h->stream, a);
                 break;
             }
             case PF_OP_SCSE: {

@@ -342,6 +342,119 @@ __global__ __launch_bounds__(256) void fc_kernel(FcArgs a) {
 }
 
 // --------------------------------------------------------------------------------------------
+// Two dependent FCs on pooled vectors in ONE launch (round 6): y = act2(W2 . h + b2), h = act1b(s2 * act1(W1 . x + b1) + t2) -- a
+// squeeze-excite gate (timm SE: reduce -> ReLU -> expand -> hard-sigmoid), the cSE gate of SCSE (model.py:117-130) or the pooled
+// branch of the ASPP (model.py:46-61, 85-93).  The Student's forward had 20 fc_kernel launches of 5-17 us each, every one a chain of
+// launch latency + dependent loads (three times the faces cost 1.25 x: profiles/r06_run1_kernel_table_1lane_f96.json); the hidden
+// vector (24 ... 240 floats per face) never needs HBM.
+// A workgroup of 1 024 threads owns PF_FC2_FB faces and streams BOTH weight matrices once (16-byte loads, [K][N] rows): thread =
+// (4 output columns, k slice); the slices' partial sums meet in LDS and are added in a fixed order (deterministic).  With 4 faces
+// per workgroup a launch of 256 faces is 64 workgroups x 16 waves -- the parallelism of the FC launches it replaces -- and reads each
+// matrix 64 times from L2 (118 MB for the 960 -> 240 -> 960 pair).
+#define PF_FC2_FB 4
+#define PF_FC2_MAXK 1088          // staged input / hidden floats per face (K, R <= 960 + chunk padding)
+struct Fc2Args {
+    const float* x;       // [B][K]
+    const float* w1;      // [K][R]
+    const float* b1;      // [R] or nullptr
+    const float* scale2;  // optional affine + activation behind act1 (ASPP: the post-concat BN of the pooled branch)
+    const float* shift2;
+    const float* w2;      // [R][N]
+    const float* b2;      // [N] or nullptr
+    float* y;             // [B][N]
+    int B, K, R, N, act1, act1b, act2;
+};
+
+// one FC phase: out[f][n] (LDS, [FB][NOUT]) = sum_k xs[f][k] * wt[k][n] for the workgroup's faces; xs rows are PF_FC2_MAXK floats, zero beyond K
+__device__ __forceinline__ void pf_fc2_phase(const float* __restrict__ wt, int K, int NOUT, const float (*xs)[PF_FC2_MAXK], float* red, float (*out)[PF_FC2_MAXK]) {
+    const int t = threadIdx.x;
+    const int n4 = (NOUT + 3) >> 2;
+    int cg = 8;
+    while (cg < n4) cg <<= 1;                             // column groups: power of two >= NOUT / 4 (8 ... 256)
+    const int ks = min(1024 / cg, 16);                    // k slices: at most 16 (the partial sums are added serially; spare threads idle)
+    const int chunk = ((K + ks - 1) / ks + 3) & ~3;       // k per slice, whole groups of four
+    const int c = t & (cg - 1), s = t / cg;
+    const int col = min(c, n4 - 1) * 4;                   // (columns past NOUT recompute the last group; dropped at the reduction)
+    float acc[PF_FC2_FB][4];
+#pragma unroll
+    for (int f = 0; f < PF_FC2_FB; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[f][e] = 0.f;
+    const int k0 = s * chunk;
+    if (s < ks && k0 < K) {
+        // eight weight rows requested at a time (the loop is a chain of L2 round trips otherwise); rows past K: a finite weight of the
+        // last row meets a staged zero
+        for (int kk = 0; kk < chunk; kk += 8) {
+            pf_f32x4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                w[j] = *reinterpret_cast<const pf_f32x4*>(wt + (size_t)min(k0 + kk + j, K - 1) * NOUT + col);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (kk + 4 * h >= chunk) break;
+#pragma unroll
+                for (int f = 0; f < PF_FC2_FB; ++f) {
+                    const pf_f32x4 xv = *reinterpret_cast<const pf_f32x4*>(&xs[f][k0 + kk + 4 * h]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[f][e] = fmaf(w[4 * h + j][e], xv[j], acc[f][e]);
+                }
+            }
+        }
+    }
+    // red[slice][column group][face][4]
+    if (s < ks) {
+#pragma unroll
+        for (int f = 0; f < PF_FC2_FB; ++f)
+            *reinterpret_cast<pf_f32x4*>(red + ((size_t)(s * cg + c) * PF_FC2_FB + f) * 4) = pf_f32x4{acc[f][0], acc[f][1], acc[f][2], acc[f][3]};
+    }
+    __syncthreads();
+    for (int o = t; o < PF_FC2_FB * NOUT; o += 1024) {
+        const int f = o / NOUT, n = o - f * NOUT;
+        float v = 0.f;
+        for (int q = 0; q < ks; ++q) v += red[((size_t)(q * cg + (n >> 2)) * PF_FC2_FB + f) * 4 + (n & 3)];
+        out[f][n] = v;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void fc2_kernel(Fc2Args a) {
+    __shared__ __attribute__((aligned(16))) float xs[PF_FC2_FB][PF_FC2_MAXK];
+    __shared__ __attribute__((aligned(16))) float hs[PF_FC2_FB][PF_FC2_MAXK];
+    __shared__ __attribute__((aligned(16))) float red[1024 * PF_FC2_FB * 4];
+    const int t = threadIdx.x;
+    const int b0 = blockIdx.x * PF_FC2_FB;
+    {
+        // the faces' input vectors: every load requested before the first is stored (clamped addresses + a select, no branch around a
+        // load); the padding of both staging arrays zeroed alongside
+        float v[PF_FC2_FB];
+#pragma unroll
+        for (int f = 0; f < PF_FC2_FB; ++f) v[f] = a.x[(size_t)min(b0 + f, a.B - 1) * a.K + min(t, a.K - 1)];
+#pragma unroll
+        for (int f = 0; f < PF_FC2_FB; ++f) {
+            xs[f][t] = (b0 + f < a.B && t < a.K) ? v[f] : 0.f;
+            hs[f][t] = 0.f;
+            if (t < PF_FC2_MAXK - 1024) { xs[f][1024 + t] = 0.f; hs[f][1024 + t] = 0.f; }
+        }
+    }
+    __syncthreads();
+    pf_fc2_phase(a.w1, a.K, a.R, xs, red, hs);
+    for (int o = t; o < PF_FC2_FB * a.R; o += 1024) {
+        const int f = o / a.R, r = o - f * a.R;
+        float v = pf_act(hs[f][r] + (a.b1 ? a.b1[r] : 0.f), a.act1);
+        if (a.scale2) v = pf_act(a.scale2[r] * v + a.shift2[r], a.act1b);
+        hs[f][r] = v;
+    }
+    __syncthreads();
+    pf_fc2_phase(a.w2, a.R, a.N, hs, red, xs);
+    for (int o = t; o < PF_FC2_FB * a.N; o += 1024) {
+        const int f = o / a.N, n = o - f * a.N;
+        if (b0 + f < a.B) a.y[(size_t)(b0 + f) * a.N + n] = pf_act(xs[f][n] + (a.b2 ? a.b2[n] : 0.f), a.act2);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 struct ScseArgs {
     const void* in;      // T [B][HW][ld]
     void* out;           // T [B][HW][outLd]

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 MAGIC = 0x47504650
-VERSION = 10
+VERSION = 11
 OP_FIELDS = 39
 
 DTYPE_F16, DTYPE_F32, DTYPE_F32_SPLIT = 0, 1, 2
@@ -26,6 +26,8 @@ ACT = {"none": 0, "relu": 1, "hswish": 2, "silu": 3, "sigmoid": 4, "hsigmoid": 5
 
 OP_STEM, OP_CONV, OP_DW, OP_UPCAT, OP_GAP, OP_FC, OP_SCSE, OP_HMDEC, OP_MAXPOOL, OP_COPY, OP_DETDEC, OP_SEPUP, OP_ADDUP, OP_MBCONV, OP_EXPDW, OP_CHAIN, OP_BLOCK, OP_DETUNIT, OP_DETC3, OP_DETSTEM, OP_LMFRONT, OP_HRB, OP_FUSEUP = range(1, 24)
 OP_MBX = 24
+OP_FC2 = 25
+OP_FRONT2 = 26
 
 # conv_gemm_kernel tile configurations (BM, BN, WARPS_M); index == cfg field
 CONV_CFGS = [(128, 128, 2), (128, 64, 2), (256, 32, 4), (256, 16, 4)]
@@ -459,6 +461,24 @@ class ProgramBuilder:
             out[:, 24 + ky] = w9[:, ky, 8]
         return out
 
+    def front2_supported(self) -> bool:
+        return self.split and self.in_h % 2 == 0 and self.in_w % 4 == 0
+
+    def front2(self, w_stem, b_stem, act_stem: str, w_dw, b_dw, w_pw, b_pw, out_name: str = "") -> int:
+        """conv_stem (3x3 s2, 3 -> 16, + act) + blocks.0.0 (depthwise 3x3 + relu -> 1x1 16 -> 16, + x) of the Student encoder on the
+        program input in ONE launch (csrc/k_front2.h): the 16-channel stem map never reaches HBM.  BN-folded weights."""
+        assert self.front2_supported()
+        assert w_stem.shape == (16, 3, 3, 3) and w_dw.shape == (16, 1, 3, 3) and w_pw.shape[:2] == (16, 16)
+        out = self.tensor(self.in_h // 2, self.in_w // 2, 16, name=out_name)
+        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
+        ws = self._stem_k_order(w_stem)
+        wu, su = self._split_rows(ws / 255.0)
+        wf, sf = self._split_rows(ws)
+        self._op(OP_FRONT2, [out, self.const(wu), self.const(wf), self.const_f32(b_stem), fbits(su), fbits(sf), ACT[act_stem],
+                             self.const_f32(w_dw.reshape(16, 9).T), self.const_f32(b_dw), self.const_f32(w_pw.reshape(16, 16)), self.const_f32(b_pw)],
+                 [], [self._tb(out)])
+        return out
+
     def lm_front_supported(self) -> bool:
         return self.split and self.in_h % 4 == 0 and self.in_w % 4 == 0
 
@@ -641,14 +661,12 @@ class ProgramBuilder:
             assert mid % 32 == 0, "the stored map is written in whole 32-channel tiles"
             dwt = self.tensor(ti.H, ti.W, mid, name=dw_name)
             self._op(OP_MBX, [x, dwt, -1, gap, -1] + common + [3, 16], [self._tb(x)], [self._tb(dwt), gap])
-            hid = self.fc(gap, w_rd, b_rd, "relu")
-            gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
+            gate = self.fc_pair(gap, w_rd, b_rd, "relu", w_ex, b_ex, "hsigmoid")
             return self.conv(dwt, w_pwl, b_pwl, "none", res=res, gate_buf=gate, out_name=out_name)
         assert mid % 32 == 0, "the recompute pass fetches the face's gates in whole 32-channel tiles (k_mbx.h dma_ct)"
         out = self.tensor(ti.H, ti.W, cout, name=out_name)
         self._op(OP_MBX, [x, -1, -1, gap, -1] + common + [1, 16], [self._tb(x)], [gap])
-        hid = self.fc(gap, w_rd, b_rd, "relu")
-        gate = self.fc(hid, w_ex, b_ex, "hsigmoid")
+        gate = self.fc_pair(gap, w_rd, b_rd, "relu", w_ex, b_ex, "hsigmoid")
         nw2 = waves if (ks, cout // 16, k, dil) in self.MBX_RECOMPUTE_16 else 8
         self._op(OP_MBX, [x, out, res, -1, gate] + common + [2, nw2], [self._tb(x), self._tb(res), gate], [self._tb(out)])
         return out
@@ -767,9 +785,14 @@ class ProgramBuilder:
         # stage per (128-pixel tile, 32-channel chunk); lives for this op only
         n_skip_chunks = cpad // 32 - c1 // 32
         skipx = self.buffer((ts.H * ts.W + 127) // 128 * n_skip_chunks * 4096, ELEM_F32, "sepup.skipx")
-        dwl = self.const_f32(np.transpose(wdw[:c1].reshape(c1, 9), (1, 0)))       # [9][C1]: the pipelined kernel upsamples, then filters
+        dwl = self.const_f32(np.transpose(wdw[:c1].reshape(c1, 9), (1, 0)))       # [9][C1]: plain filters (upsample, then filter)
+        # round 6: the pipelined kernel interpolates HORIZONTALLY only; the vertical half of the upsample and the zero rows above /
+        # below the image are folded into the filter, one 3 x 3 set per row class (first / last / even / odd):
+        # V[cy][j][kx][c] = sum_ky A_cy[ky][j] * W[c][ky][kx]  (csrc/k_sepup.h, VCOL)
+        V = np.stack([np.einsum("kj,ckl->jlc", ay[cy], wdw[:c1]) for cy in range(4)])
+        dwv = self.const_f32(V.reshape(4 * 9, c1))
         self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
-                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, skipx, dwl],
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, skipx, dwl, dwv],
                  [self._tb(lo), self._tb(skip)], [self._tb(out), skipx])
         return out
 
@@ -835,6 +858,27 @@ class ProgramBuilder:
         s2 = self.const_f32(scale2) if scale2 is not None else -1
         t2 = self.const_f32(shift2) if shift2 is not None else -1
         self._op(OP_FC, [xbuf, out, woff, boff, k, n, ACT[act], s2, t2, ACT[act2]], [xbuf], [out])
+        return out
+
+    def fc_pair(self, xbuf: int, w1: np.ndarray, b1: Optional[np.ndarray], act1: str, w2: np.ndarray, b2: Optional[np.ndarray], act2: str,
+                scale2: Optional[np.ndarray] = None, shift2: Optional[np.ndarray] = None, act1b: str = "none") -> int:
+        """y = act2(W2 h + b2), h = act1b(scale2 * act1(W1 x + b1) + shift2): two dependent FCs on pooled vectors -- an SE gate, the
+        cSE gate, the ASPP's pooled branch.  ONE launch (csrc/k_layers.h fc2_kernel) when ``self.fuse_fc_pairs`` and the shapes allow
+        it (R, N multiples of 4, everything <= 960), two ``fc`` ops otherwise."""
+        r, k = w1.shape
+        n, r2 = w2.shape
+        assert r2 == r and self.bufs[xbuf].elems == k
+        # one launch streams BOTH matrices through every workgroup (4 faces each): a win while they are small -- 5.4 against 9.0 us for
+        # 72 -> 24 -> 72, 11.1 against 12.9 us for 480 -> 120 -> 480 -- and a loss once a compute unit's 64 B / clock from the L2 is the
+        # bound (960 -> 240 -> 960, 1.8 MB per workgroup: 23.7 against 20.6 us; profiles/r06_run10_ub_fc2.txt)
+        if not (getattr(self, "fuse_fc_pairs", True) and r % 4 == 0 and n % 4 == 0 and max(k, r, n) <= 960 and k * r + r * n <= 131072):
+            hid = self.fc(xbuf, w1, b1, act1, scale2=scale2, shift2=shift2, act2=act1b)
+            return self.fc(hid, w2, b2, act2)
+        out = self.buffer(n, ELEM_F32, "fc2")
+        cf = lambda v: self.const_f32(v) if v is not None else -1
+        self._op(OP_FC2, [xbuf, out, self.const_f32(np.transpose(w1.astype(np.float64), (1, 0))), cf(b1), k, r, ACT[act1],
+                          cf(scale2), cf(shift2), ACT[act1b], self.const_f32(np.transpose(w2.astype(np.float64), (1, 0))), cf(b2), n, ACT[act2]],
+                 [xbuf], [out])
         return out
 
     def scse(self, x: int, cse_buf: int, sse_w: np.ndarray, sse_b: float, out_name: str = "") -> int:

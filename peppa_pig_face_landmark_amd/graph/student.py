@@ -65,9 +65,9 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
     cat = pb.view(cat_buf, h16, h16, 192, 0, 192, name=f"{a}.cat192")
     pooled = pb.gap(encx16)
     wp, bp = ir.fold_bn(w[f"{a}.fm_pool.pool.1.weight"], None, _bn(w, f"{a}.fm_pool.pool.2"))
-    v = pb.fc(pooled, wp.reshape(64, -1), bp, "relu", scale2=s_cat[192:256], shift2=t_cat[192:256], act2="relu")
     wproj, bproj = ir.fold_bn(w[f"{a}.project.0.weight"], None, _bn(w, f"{a}.project.1"))
-    fbias = pb.fc(v, wproj[:, 192:256, 0, 0], None, "none")
+    fbias = pb.fc_pair(pooled, wp.reshape(64, -1), bp, "relu", wproj[:, 192:256, 0, 0], None, "none",
+                       scale2=s_cat[192:256], shift2=t_cat[192:256], act1b="relu")
     x16 = pb.conv(cat, wproj[:, :192], bproj, "relu", fbias_buf=fbias, out_name=f"{a}.out")
 
     # ---- decoder blocks (model.py:133-196) -------------------------------------------------------
@@ -88,8 +88,8 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
         if att:
             pooled = pb.gap(x)
             w1, w2 = w[f"{name}.attention2.cSE.1.weight"], w[f"{name}.attention2.cSE.3.weight"]
-            hid = pb.fc(pooled, w1.reshape(w1.shape[0], -1), w[f"{name}.attention2.cSE.1.bias"], "relu")
-            cse = pb.fc(hid, w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid")
+            cse = pb.fc_pair(pooled, w1.reshape(w1.shape[0], -1), w[f"{name}.attention2.cSE.1.bias"], "relu",
+                             w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid")
             x = pb.scse(x, cse, w[f"{name}.attention2.sSE.0.weight"], float(w[f"{name}.attention2.sSE.0.bias"][0]),
                         out_name=f"{name}.scse")
         return x
@@ -121,7 +121,8 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
                           keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True, fuse_front: bool = False,
-                          fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16):
+                          fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16, fuse_fc_pairs: bool = True,
+                          fuse_front2: bool = True):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
@@ -129,6 +130,7 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
         fuse_mbx = fuse_mbconv     # mbx_se: None = ir.mbx's choice ("store"), or "recompute" / "store" for every SE block (A/B aid)
     w = weights
     pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
+    pb.fuse_fc_pairs = bool(fuse_fc_pairs)      # SE / cSE / ASPP-pool FC pairs as ONE launch each (ir.fc_pair); False: the round-5 two-launch form (A/B aid)
 
     # ---- encoder (timm MobileNetV3Features; output_stride 16 => stage 5 runs dilated) ---------
     wt, b = ir.fold_bn(w["encoder.conv_stem.weight"], None, _bn(w, "encoder.bn1"))
@@ -141,12 +143,20 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
         f = lambda cw, bn: ir.fold_bn(w[f"encoder.blocks.{cw}.weight"], None, _bn(w, f"encoder.blocks.{bn}"))
         x = pb.lm_front(wt, b, "hswish", *f("0.0.conv_dw", "0.0.bn1"), *f("0.0.conv_pw", "0.0.bn2"), *f("1.0.conv_pw", "1.0.bn1"),
                         *f("1.0.conv_dw", "1.0.bn2"), *f("1.0.conv_pwl", "1.0.bn3"), out_name="encoder.blocks.1.0.out")
-    else:
+    # fuse_front2 (f32s programs, default): conv_stem + blocks.0.0 in ONE shallow launch (csrc/k_front2.h, two barriers): 0.174 against
+    # 0.094 + 0.160 ms per 256 crops (profiles/r06_run11_ub_front2.txt)
+    fuse_front2 = fuse_mbconv and fuse_front2 and not fuse_front and not keep_all and pb.front2_supported()
+    if fuse_front2:
+        f = lambda cw, bn: ir.fold_bn(w[f"encoder.blocks.{cw}.weight"], None, _bn(w, f"encoder.blocks.{bn}"))
+        x = pb.front2(wt, b, "hswish", *f("0.0.conv_dw", "0.0.bn1"), *f("0.0.conv_pw", "0.0.bn2"), out_name="encoder.blocks.0.0.out")
+    elif not fuse_front:
         x = pb.stem(wt, b, "hswish", out_name="encoder.stem")
     cin, cur_stride, cur_dil = 16, 2, 1
     feats = {}
     for si, stack in enumerate(_STAGES):
         for bi, (kind, k, s, e, cout, se, act) in enumerate(stack):
+            if fuse_front2 and (si, bi) == (0, 0):                # inside front2
+                continue
             if fuse_front and (si, bi) in ((0, 0), (1, 0)):       # inside lm_front: only the bookkeeping of the loop below
                 if s > 1:
                     cur_stride *= s
@@ -213,8 +223,8 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                         pooled = pb.gap(x)
                     rd = w[f"{p}.se.conv_reduce.weight"]
                     ex = w[f"{p}.se.conv_expand.weight"]
-                    hid = pb.fc(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu")
-                    gate = pb.fc(hid, ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
+                    gate = pb.fc_pair(pooled, rd.reshape(rd.shape[0], rd.shape[1]), w[f"{p}.se.conv_reduce.bias"], "relu",
+                                      ex.reshape(ex.shape[0], ex.shape[1]), w[f"{p}.se.conv_expand.bias"], "hsigmoid")
                 wt, b = ir.fold_bn(w[f"{p}.conv_pwl.weight"], None, _bn(w, f"{p}.bn3"))
                 x = pb.conv(x, wt, b, "none", res=inp if skip else -1, gate_buf=gate, out_name=f"{p}.out")
             cur_dil = next_dil

@@ -125,3 +125,36 @@ def test_pipelined_decoder_front_end_ragged_batches(emu_library, student_weights
         assert np.abs(score - oscore)[safe].max() < 4e-3          # raw heat-map maxima of O(30): 1e-4 of their range
     finally:
         eng.close()
+
+
+def test_fc_pair_launch_equals_two_fc_launches(emu_engine, student_weights):
+    """Round 6: the SE / cSE / ASPP-pool FC pairs run as ONE fc2_kernel launch each (ir.fc_pair, csrc/k_layers.h): same outputs as the
+    two-launch form up to the order of the partial sums (different k slicing)."""
+    from peppa_pig_face_landmark_amd.graph.student import build_student_program
+    crops = sw.smooth_blob_images(3, 128, seed=31)          # 3 faces: a ragged last workgroup (4 faces per workgroup)
+    outs, nops = [], []
+    for fuse in (True, False):
+        blob, info = build_student_program(student_weights, 128, "f32", fuse_fc_pairs=fuse)
+        emu_engine.load_program(0, blob, 3)
+        outs.append(emu_engine.landmark_forward(crops))
+        nops.append(info["n_ops"])
+    assert nops[1] - nops[0] == 6                            # the pairs with small matrices (ir.fc_pair): three stage-2 SE blocks, blocks.4.0's, cSE, ASPP pool
+    assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-6 and np.abs(outs[0][1] - outs[1][1]).max() < 2e-4      # (scores are logits of range ~ 20)
+
+
+@pytest.mark.parametrize("size", [64, 128])
+def test_front2_launch_equals_stem_plus_block0(emu_engine, student_weights, size):
+    """Round 6: conv_stem + blocks.0.0 as ONE launch (csrc/k_front2.h; the 16-channel stem map stays in LDS) against the two launches it
+    replaces, on uint8 crops and through the float NCHW seam of pf_landmark_forward, ragged tiles included (a 64 x 64 crop has a 32 x 32
+    stem map: one 32-wide tile column, four 8-row tile rows)."""
+    from peppa_pig_face_landmark_amd.graph.student import build_student_program
+    crops = sw.smooth_blob_images(2, size, seed=41)
+    xf = np.ascontiguousarray((crops.astype(np.float32) / np.float32(255.0)).transpose(0, 3, 1, 2))
+    outs = []
+    for fuse in (True, False):
+        blob, info = build_student_program(student_weights, size, "f32s", fuse_front2=fuse)
+        emu_engine.load_program(0, blob, 2)
+        outs.append((emu_engine.landmark_forward(crops), emu_engine.landmark_forward(xf)))
+    for k in range(2):          # uint8 input, float input
+        assert np.abs(outs[0][k][0] - outs[1][k][0]).max() < 1e-5, k
+        assert np.abs(outs[0][k][1] - outs[1][k][1]).max() < 1e-3, k
