@@ -128,7 +128,8 @@ def parse_args():
     ap.add_argument("--workload", default="auto", choices=["auto", "landmark", "pipeline"])
     ap.add_argument("--batch", type=int, default=256, help="faces per step per GPU (landmark workload)")
     ap.add_argument("--frames", type=int, default=96, help="1080p frames per step per GPU (pipeline workload)")
-    ap.add_argument("--lanes", type=int, default=3, help="concurrent HIP streams (engines) per GPU sharing a step's frames")
+    ap.add_argument("--lanes", type=int, default=2, help="concurrent HIP streams (engines) per GPU sharing a step's frames (round 6: two lanes of 48 frames "
+                    "behind the front engine measure 2.6 %% above three of 32: profiles/r06_run14_lanes_ab.txt)")
     ap.add_argument("--faces-per-frame", type=int, default=8)
     ap.add_argument("--frame-hw", type=int, nargs=2, default=[1080, 1920], metavar=("H", "W"),
                     help="frame size; --frame-hw 2160 3840 --faces-per-frame 32 --model teacher = BASELINE config 5")
@@ -140,8 +141,6 @@ def parse_args():
                     help="landmark regressor: Student (headline) or Teacher/HRNet-W18 (BASELINE config 5 model)")
     ap.add_argument("--no-probes", action="store_true", help="skip the call-latency, sustained-loop and PCIe-inclusive probes (keeps a "
                     "rocprofv3 --stats run of this command to launches of ONE batch size, so its per-kernel averages are comparable)")
-    ap.add_argument("--fuse-front", type=int, default=-1, help="A/B aid: 1 / 0 = Student program with / without the fused encoder front end "
-                    "(csrc/k_front.h); default: the program builder's own default")
     ap.add_argument("--mbx", default="default", choices=["default", "off", "recompute", "store"],
                     help="A/B aid for the Student's 16 x 16 inverted-residual blocks (csrc/k_mbx.h): off = the layer-wise expand + depthwise / "
                          "projection launches, recompute / store = force one SE strategy for every SE block; default: the builder's choice")
@@ -151,6 +150,7 @@ def parse_args():
     ap.add_argument("--sustain-s", type=float, default=3.0, help="after the timed steps, keep stepping for this many seconds "
                     "(a sustained rate an external GPU-busy sampler can see)")
     ap.add_argument("--jpeg-threads", type=int, default=4, help="host threads per lane that strip the byte stuffing in the JPEG-file ingest probe")
+    ap.add_argument("--batch-engine", action="store_true", help="use the multi-lane runner (pf_batch_*, front engine) even with --lanes 1")
     ap.add_argument("--no-front2", action="store_true", help="A/B aid: conv_stem and blocks.0.0 as two launches (round 5) instead of the fused lm_front2_kernel")
     ap.add_argument("--no-fc-pairs", action="store_true", help="A/B aid: the SE / cSE / ASPP-pool FC pairs as two fc launches each (round 5) instead of one fc2 launch")
     ap.add_argument("--no-front", action="store_true", help="A/B aid: every lane runs the detector + NMS of its own slice (the round-5 "
@@ -447,7 +447,7 @@ def main():
 
     # ---- weights: packed on rank 0, broadcast once by the ENGINE over RCCL / xGMI (pf_broadcast_weights) -----------
     t0 = time.time()
-    skw = {} if args.fuse_front < 0 or args.model != "student" else {"fuse_front": bool(args.fuse_front)}
+    skw = {}
     if args.model == "student":
         if args.mbx == "off":
             skw["fuse_mbx"] = False
@@ -504,14 +504,15 @@ def main():
         blobs = blobs_out
     faces_per_step = args.batch if workload == "landmark" else args.frames * args.faces_per_frame
     lanes = args.lanes if workload == "pipeline" else 1
-    if lanes == 1:
+    single = lanes == 1 and not (args.batch_engine and workload == "pipeline")
+    if single:
         bs.load_programs(eng, blobs, workload, faces_per_step, args.frames)
     setup_s = time.time() - t0
 
     # ---- synthetic inputs, resident in HBM ----------------------------------------------------------
     if workload == "landmark":
         state = bs.LandmarkWorkload(eng, dev, args.batch, seed=1234 + rank)
-    elif lanes == 1:
+    elif single:
         state = bs.PipelineWorkload(eng, dev, args.frames, args.faces_per_frame, seed=7 + rank, graph=not args.no_graph,
                                     frame_hw=tuple(args.frame_hw))
     else:

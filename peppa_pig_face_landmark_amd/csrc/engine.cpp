@@ -701,40 +701,6 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 }
                 break;
             }
-            case PF_OP_LMFRONT: {
-                if constexpr (!SPLIT) {
-                    PF_FAIL(h, "fused encoder front end needs a split-precision (f32s) program");
-                } else {
-                    const PfTensorRec& to = p.tens[f[0]];
-                    LmFrontArgs a{};
-                    a.in = d_input; const bool f32in = input_kind == PF_INPUT_F32_NCHW;
-                    a.out = (float*)p.tensor_ptr(f[0]); a.outLd = to.ld;
-                    a.w_stem_u8 = (const pf_half*)p.cptr(f[1]); a.w_stem_f32 = (const pf_half*)p.cptr(f[2]); a.b_stem = (const float*)p.cptr(f[3]);
-                    a.w_dw0 = (const float*)p.cptr(f[4]); a.b_dw0 = (const float*)p.cptr(f[5]);
-                    a.w_pw0 = (const pf_half*)p.cptr(f[6]); a.b_pw0 = (const float*)p.cptr(f[7]);
-                    a.w_exp = (const pf_half*)p.cptr(f[8]); a.b_exp = (const float*)p.cptr(f[9]);
-                    a.w_dw1 = (const float*)p.cptr(f[10]); a.b_dw1 = (const float*)p.cptr(f[11]);
-                    a.w_prj = (const pf_half*)p.cptr(f[12]); a.b_prj = (const float*)p.cptr(f[13]);
-                    memcpy(&a.s_stem_u8, &f[14], 4); memcpy(&a.s_stem_f32, &f[15], 4); memcpy(&a.s_pw0, &f[16], 4); memcpy(&a.s_exp, &f[17], 4); memcpy(&a.s_prj, &f[18], 4);
-                    a.act_stem = f[19];
-                    a.B = B; a.H = p.hdr.in_h; a.W = p.hdr.in_w; a.SH = a.H / 2; a.SW = a.W / 2; a.OH = to.H; a.OW = to.W;
-                    if (to.C != 24 || (a.H & 3) || (a.W & 3) || a.OH != a.H / 4 || a.OW != a.W / 4) PF_FAIL(h, "lmfront: inconsistent shapes");
-                    if ((size_t)d_input & 3) PF_FAIL(h, "lmfront: the input must be 4-byte aligned");
-                    a.TH = 4; a.TW = 16; a.tilesX = pf_div_up(a.OW, a.TW);
-                    a.range_slot = slot_of(oi);
-                    if (host_dbg(h) & 4096) {      // per-phase cycle accounting (ablation build; printed at pf_destroy)
-                        if (!h->d_dbg) { PF_HIP(h, hipMalloc((void**)&h->d_dbg, 64 * 16 * sizeof(unsigned long long))); PF_HIP(h, hipMemset(h->d_dbg, 0, 64 * 16 * sizeof(unsigned long long))); }
-                        a.prof = h->d_dbg + 128;
-                    }
-                    ProfScope ps(h, "lm_front");
-                    // tile 4 x 16 of the /4 map: y0 region 9 x 33 = 297 (304 rows), stem region 11 x 35 = 385 (400), image region 23 rows x 71 pixels
-                    const int tiles = a.tilesX * pf_div_up(a.OH, a.TH) * B;
-                    if (f32in) PF_LAUNCH((lm_front_kernel<64, 400, 304, 23, 220, true, 512, 2>), dim3(persistent_grid(tiles, 1)), dim3(512), h->stream, a);
-                    else if (host_dbg(h) & 8192) PF_LAUNCH((lm_front_kernel<64, 400, 304, 23, 220, false, 512, 2>), dim3(persistent_grid(tiles, 1)), dim3(512), h->stream, a);
-                    else PF_LAUNCH((lm_front_kernel<64, 400, 304, 23, 220, false, 512, 4>), dim3(persistent_grid(tiles, 2)), dim3(512), h->stream, a);
-                }
-                break;
-            }
             case PF_OP_DETC3: {
                 if constexpr (!SPLIT) {
                     PF_FAIL(h, "fused C3 op needs a split-precision (f32s) program");
@@ -1281,12 +1247,6 @@ void pf_destroy(pf_handle* h) {
                 fprintf(stderr, "[det_mbx %s mode %d] per wave and launch-face (cycles): prologue+expand0 %.0f | project %.0f | wait a %.0f | depthwise %.0f | expand %.0f | wait b %.0f | epilogue %.0f  (%.0f waves)\n",
                         shp[k / 4], k % 4, q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n, q[5] / n, q[6] / n, n);
             }
-        unsigned long long w9[9];
-        if (hipMemcpy(w9, h->d_dbg + 128, sizeof(w9), hipMemcpyDeviceToHost) == hipSuccess && w9[8]) {
-            const double n = (double)w9[8];
-            fprintf(stderr, "[det_lm_front] per tile (cycles): image+flags %.0f | stem %.0f | depthwise0 %.0f | pointwise0 %.0f | expand x4 %.0f | depthwise1 x4 %.0f | project+store %.0f  (%.0f tiles)\n",
-                    w9[0] / n, w9[1] / n, w9[2] / n, w9[3] / n, w9[4] / n, w9[5] / n, w9[6] / n, n);
-        }
         unsigned long long v[32];
         if (hipMemcpy(v, h->d_dbg, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) {
             for (int k = 0; k < 2; ++k) {

@@ -20,6 +20,9 @@
 #pragma once
 #include "pf_common.h"
 #include "k_det.h"
+#ifndef FRONT2_ABL
+#define FRONT2_ABL 0      // tools/ub_front2.hip timing ablations (1 no image loads, 2 no stem phase, 4 no block arithmetic, 8 no stores); 0 in the library
+#endif
 
 struct Front2Args {
     const void* in;            // u8 [B][H][W][3] (1/255 folded into w_u8) or f32 [B][3][H][W]
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void lm_front2_kernel(Front2Args a) {
             const int ry = i / nwd, w = i - ry * nwd;
             const int iy = iy0 + ry, bw = wb + 4 * w;
             wv[it] = 0u;
-            if (ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
+            if (!(FRONT2_ABL & 1) && ry < IRH && (unsigned)iy < (unsigned)a.H && bw >= 0 && bw < rowb) wv[it] = *reinterpret_cast<const unsigned*>(in8 + (size_t)iy * rowb + bw);
         }
 #pragma unroll
         for (int it = 0; it < ITW; ++it) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void lm_front2_kernel(Front2Args a) {
     __syncthreads();
 
     // ---- stem conv on the (TH + 2) x (TW + 2) positions ---------------------------------------------------------------------------
-    for (int mt = wave; mt < (SP + 15) / 16; mt += NW) {
+    for (int mt = wave; mt < ((FRONT2_ABL & 2) ? 0 : (SP + 15) / 16); mt += NW) {
         const int p = mt * 16 + frow;
         const int pc = p < SP ? p : 0;
         const int sy = pc / SW, sx = pc - sy * SW;
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(256) void lm_front2_kernel(Front2Args a) {
         const int py = mt >> 1, px = (mt & 1) * 16 + frow;
         const float* sp = s_st + (py * SW + px) * 16 + g4;
         pf_f32x4 d = bdw;
+        if (!(FRONT2_ABL & 4))
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void lm_front2_kernel(Front2Args a) {
         pf_f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (acc[e] + bpw[e]) + res[e];
-        if (oy < a.OH && ox < a.OW) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.OW + ox) * a.outLd + g4) = v;
+        if (!(FRONT2_ABL & 8) && oy < a.OH && ox < a.OW) *reinterpret_cast<pf_f32x4*>(out + ((size_t)oy * a.OW + ox) * a.outLd + g4) = v;
     }
     pf_amax_commit(a.range_slot, amax, amax_seen);
 }

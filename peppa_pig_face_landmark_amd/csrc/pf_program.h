@@ -63,9 +63,7 @@ enum PfOpCode : int32_t {
                         //    Detect conv (raw output into out2 if given) and its decode into rows_buf; split programs only
     PF_OP_DETSTEM = 20, // f: out_t w1_u8 w1_f32 b1 w2a b2a w2b b2b w3 b3 s1_u8 s1_f32 s2a s2b s3 (float bits): the detector's StemBlock (stem_1 3x3 s2,
                         //    stem_2a 1x1, stem_2b 3x3 s2, max-pool, stem_3 1x1) in one launch on the program input (k_det.h det_stem_kernel)
-    PF_OP_LMFRONT = 21, // f: out_t w_stem_u8 w_stem_f32 b_stem w_dw0 b_dw0 w_pw0 b_pw0 w_exp b_exp w_dw1 b_dw1 w_prj b_prj s_stem_u8 s_stem_f32 s_pw0 s_exp s_prj
-                        //    (float bits) act_stem: conv_stem + blocks.0.0 + blocks.1.0 of the Student encoder in one launch on the program input
-                        //    (k_front.h lm_front_kernel); split programs only
+    // 21: PF_OP_LMFRONT (round 4: conv_stem + blocks.0.0 + blocks.1.0 in one launch) -- removed in round 6, see PF_OP_FRONT2
     PF_OP_HRB = 22,     // f: in_t out_t w1 b1 w2 b2 w3 b3 wd(-1) bd(-1) s1 s2 s3 sd (float bits) CIN: an HRNet Bottleneck (1x1 -> 3x3 -> 1x1 + shortcut, mid 64,
                         //    out 256; wd / bd = the first block's shortcut conv) in one launch (k_hrb.h hr_bottleneck_kernel); split programs only
     PF_OP_FUSEUP = 23,  // f: y_t out_t act nsrc then per source (<= 3): src_t wt bias shift: an HRNet fuse sum towards a higher-resolution branch,

@@ -479,36 +479,6 @@ class ProgramBuilder:
                  [], [self._tb(out)])
         return out
 
-    def lm_front_supported(self) -> bool:
-        return self.split and self.in_h % 4 == 0 and self.in_w % 4 == 0
-
-    def lm_front(self, w_stem, b_stem, act_stem, w_dw0, b_dw0, w_pw0, b_pw0, w_exp, b_exp, w_dw1, b_dw1, w_prj, b_prj, out_name: str = "") -> int:
-        """conv_stem (3x3 s2, 3 -> 16) + blocks.0.0 (depthwise 3x3 + relu -> 1x1 16 -> 16, + x) + blocks.1.0 (1x1 16 -> 64 + relu ->
-        depthwise 3x3 s2 + relu -> 1x1 64 -> 24) of the Student encoder on the program input in ONE launch (csrc/k_front.h);
-        BN-folded weights."""
-        assert self.lm_front_supported()
-        assert w_stem.shape == (16, 3, 3, 3) and w_dw0.shape == (16, 1, 3, 3) and w_pw0.shape[:2] == (16, 16)
-        assert w_exp.shape[:2] == (64, 16) and w_dw1.shape == (64, 1, 3, 3) and w_prj.shape[:2] == (24, 64)
-        out = self.tensor(self.in_h // 4, self.in_w // 4, 24, name=out_name)
-        fbits = lambda v: struct.unpack("<i", struct.pack("<f", v))[0]
-
-        def rows(w, n, k):
-            m = np.zeros((n, k), np.float64)
-            m[:w.shape[0], :w.shape[1]] = w
-            return self._split_rows(m)
-        ws = self._stem_k_order(w_stem)
-        wsu, ssu = self._split_rows(ws / 255.0)
-        wsf, ssf = self._split_rows(ws)
-        wp, sp = rows(w_pw0.reshape(16, 16).astype(np.float64), 16, 32)
-        we, se = rows(w_exp.reshape(64, 16).astype(np.float64), 64, 32)
-        wj, sj = rows(w_prj.reshape(24, 64).astype(np.float64), 32, 64)
-        bj = np.zeros(32); bj[:24] = b_prj
-        self._op(OP_LMFRONT, [out, self.const(wsu), self.const(wsf), self.const_f32(b_stem), self.const_f32(w_dw0.reshape(16, 9).T), self.const_f32(b_dw0),
-                              self.const(wp), self.const_f32(b_pw0), self.const(we), self.const_f32(b_exp), self.const_f32(w_dw1.reshape(64, 9).T),
-                              self.const_f32(b_dw1), self.const(wj), self.const_f32(bj), fbits(ssu), fbits(ssf), fbits(sp), fbits(se), fbits(sj), ACT[act_stem]],
-                 [], [self._tb(out)])
-        return out
-
     def det_c3_supported(self, cin: int, tail: str) -> bool:
         return self.split and (cin, tail) in ((192, "conv"), (128, "detect"))
 
@@ -871,7 +841,9 @@ class ProgramBuilder:
         # one launch streams BOTH matrices through every workgroup (4 faces each): a win while they are small -- 5.4 against 9.0 us for
         # 72 -> 24 -> 72, 11.1 against 12.9 us for 480 -> 120 -> 480 -- and a loss once a compute unit's 64 B / clock from the L2 is the
         # bound (960 -> 240 -> 960, 1.8 MB per workgroup: 23.7 against 20.6 us; profiles/r06_run10_ub_fc2.txt)
-        if not (getattr(self, "fuse_fc_pairs", True) and r % 4 == 0 and n % 4 == 0 and max(k, r, n) <= 960 and k * r + r * n <= 131072):
+        # f32s programs only: the exact-f32 programs keep the two-launch form and with it their bit pattern (the golden of
+        # tests/test_tracking_parity.py was produced by the f32 engine as the reference FaceAna's landmark session)
+        if not (self.split and getattr(self, "fuse_fc_pairs", True) and r % 4 == 0 and n % 4 == 0 and max(k, r, n) <= 960 and k * r + r * n <= 131072):
             hid = self.fc(xbuf, w1, b1, act1, scale2=scale2, shift2=shift2, act2=act1b)
             return self.fc(hid, w2, b2, act2)
         out = self.buffer(n, ELEM_F32, "fc2")

@@ -120,7 +120,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 
 
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
-                          keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True, fuse_front: bool = False,
+                          keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True,
                           fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16, fuse_fc_pairs: bool = True,
                           fuse_front2: bool = True):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
@@ -134,33 +134,19 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
 
     # ---- encoder (timm MobileNetV3Features; output_stride 16 => stage 5 runs dilated) ---------
     wt, b = ir.fold_bn(w["encoder.conv_stem.weight"], None, _bn(w, "encoder.bn1"))
-    # fuse_front (f32s programs, opt-in): conv_stem + blocks.0.0 + blocks.1.0 in ONE launch (csrc/k_front.h) -- the 128 x 128 x 16 maps
-    # between them never reach HBM.  Correct (tests/test_emu_landmark.py, GPU parity green) but SLOWER on MI355X than the three
-    # launches it replaces (0.76 vs 0.51 ms per 256 faces, profiles/r04_run8_phase_cycles.txt: 13 barrier-separated phases on a
-    # 64-pixel tile never fill the CU), so it stays off by default.
-    fuse_front = fuse_mbconv and fuse_front and not keep_all and pb.lm_front_supported()
-    if fuse_front:
-        f = lambda cw, bn: ir.fold_bn(w[f"encoder.blocks.{cw}.weight"], None, _bn(w, f"encoder.blocks.{bn}"))
-        x = pb.lm_front(wt, b, "hswish", *f("0.0.conv_dw", "0.0.bn1"), *f("0.0.conv_pw", "0.0.bn2"), *f("1.0.conv_pw", "1.0.bn1"),
-                        *f("1.0.conv_dw", "1.0.bn2"), *f("1.0.conv_pwl", "1.0.bn3"), out_name="encoder.blocks.1.0.out")
     # fuse_front2 (f32s programs, default): conv_stem + blocks.0.0 in ONE shallow launch (csrc/k_front2.h, two barriers): 0.174 against
     # 0.094 + 0.160 ms per 256 crops (profiles/r06_run11_ub_front2.txt)
-    fuse_front2 = fuse_mbconv and fuse_front2 and not fuse_front and not keep_all and pb.front2_supported()
+    fuse_front2 = fuse_mbconv and fuse_front2 and not keep_all and pb.front2_supported()
     if fuse_front2:
         f = lambda cw, bn: ir.fold_bn(w[f"encoder.blocks.{cw}.weight"], None, _bn(w, f"encoder.blocks.{bn}"))
         x = pb.front2(wt, b, "hswish", *f("0.0.conv_dw", "0.0.bn1"), *f("0.0.conv_pw", "0.0.bn2"), out_name="encoder.blocks.0.0.out")
-    elif not fuse_front:
+    else:
         x = pb.stem(wt, b, "hswish", out_name="encoder.stem")
     cin, cur_stride, cur_dil = 16, 2, 1
     feats = {}
     for si, stack in enumerate(_STAGES):
         for bi, (kind, k, s, e, cout, se, act) in enumerate(stack):
             if fuse_front2 and (si, bi) == (0, 0):                # inside front2
-                continue
-            if fuse_front and (si, bi) in ((0, 0), (1, 0)):       # inside lm_front: only the bookkeeping of the loop below
-                if s > 1:
-                    cur_stride *= s
-                cin = cout
                 continue
             if bi >= 1:
                 s = 1

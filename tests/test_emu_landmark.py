@@ -134,7 +134,7 @@ def test_fc_pair_launch_equals_two_fc_launches(emu_engine, student_weights):
     crops = sw.smooth_blob_images(3, 128, seed=31)          # 3 faces: a ragged last workgroup (4 faces per workgroup)
     outs, nops = [], []
     for fuse in (True, False):
-        blob, info = build_student_program(student_weights, 128, "f32", fuse_fc_pairs=fuse)
+        blob, info = build_student_program(student_weights, 128, "f32s", fuse_fc_pairs=fuse)
         emu_engine.load_program(0, blob, 3)
         outs.append(emu_engine.landmark_forward(crops))
         nops.append(info["n_ops"])

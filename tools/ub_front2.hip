@@ -5,6 +5,9 @@
 #include <cstdlib>
 #include <vector>
 #include <algorithm>
+#ifndef FRONT2_ABL
+#define FRONT2_ABL 0
+#endif
 #include "k_front2.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 int main(int argc, char** argv) {
