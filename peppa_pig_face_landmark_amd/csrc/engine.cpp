@@ -311,6 +311,13 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
                 const int fill = h->num_cus;
 #endif
                 while (segs < tpf && (tpf % (2 * segs)) == 0 && B * segs < fill) segs *= 2;
+                if (B * segs > fill) {              // more items than CUs: pick the split whose LAST round of the persistent grid is full (384 faces on
+                    double best = 1e30;             // 256 CUs: two rounds of faces, the second half empty, or three rounds of half faces)
+                    for (int sg = 1; sg <= 8 && sg <= tpf && (tpf % sg) == 0; sg *= 2) {
+                        const double face_times = (double)pf_div_up(B * sg, fill) / sg + 0.02 * (sg - 1);
+                        if (face_times < best - 1e-9) { best = face_times; segs = sg; }
+                    }
+                }
                 a.head_segs = segs;
                 PF_LAUNCH((pw_head_kernel<4>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);
             }
@@ -905,7 +912,19 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                     tagbuf[0] = 0;
                     if (h->profiling) snprintf(tagbuf, sizeof(tagbuf), "mbx%s%dx%dd%d_c%d_m%d_n%d_16x16", mode == 0 ? "" : (mode == 1 ? "A" : (mode == 2 ? "B" : "S")), K, K, dil, ti.C, a.CEXP, proj ? Cout : 0);
                     ProfScope ps(h, tagbuf);
-                    const dim3 grid(persistent_grid(B, 1));      // one workgroup per CU, faces strided over the grid
+                    // One workgroup per CU, work units strided over the grid.  A unit is a face -- or, in the squeeze modes (whose channel
+                    // tiles are independent), one of `nsplit` tile ranges of a face, chosen so that the last round of the persistent grid is
+                    // full: 384 faces on 256 CUs are two rounds of faces (the second half empty) but three rounds of half faces.
+                    a.nsplit = 1;
+                    if (sq) {
+                        const int cus = std::max(1, persistent_grid(1 << 20, 1));
+                        double best = 1e30;
+                        for (int ns = 1; ns <= 4 && ns <= a.T; ++ns) {
+                            const double face_times = (double)pf_div_up(B * ns, cus) / ns + 0.02 * (ns - 1);      // (+ the input fetched ns times)
+                            if (face_times < best - 1e-9) { best = face_times; a.nsplit = ns; }
+                        }
+                    }
+                    const dim3 grid(persistent_grid(B * a.nsplit, 1));
                     const int lrc = pf_mbx_launch(a, nw, KS, Cout, K, dil, mode, (int)grid.x, h->stream);      // mbx_launch.cpp (own translation unit)
                     if (lrc > 0) PF_FAIL(h, "launch of mbx_kernel failed: %s", hipGetErrorString((hipError_t)lrc));
                     const bool launched = lrc == 0;

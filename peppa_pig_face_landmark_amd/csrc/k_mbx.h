@@ -99,7 +99,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     if (threadIdx.x < Z_BYTES / 4) reinterpret_cast<float*>(zeros)[threadIdx.x] = 0.f;      // (the first barrier of the first face orders it)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int T = a.T;
     unsigned amax = 0;                                      // range guard (pf_common.h): everything this launch splits
     const unsigned amax_seen = pf_amax_seen(a.range_slot);
 
@@ -109,9 +108,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     // as 64-bit pointers) are hoisted out of the tile loop, and next to the resident fragment / accumulator registers they spill
     // (first build: 616 bytes of scratch per lane).  Recomputing them costs a few dozen VALU instructions per phase.
     auto glds = [&](const void* sb, unsigned voff, void* dst) { pf_glds16_raw_soff<0>(sb, voff, dst); };
+    // Tile indices below are RELATIVE to the work unit's first tile `tb` (round 6: in the squeeze modes a face is split into a.nsplit
+    // tile ranges): LDS stages, parities and the loop structure see every unit as a run from tile 0, only global addresses add tb.
+    int tb = 0;
     auto dma_w1 = [&](int tile) {                           // slot -> [k-step][plane][row][position], chunk rotation on the SOURCE
         const int tt = pf_opaque(t);
-        const unsigned char* sb = a.w1 + (size_t)tile * (32 * KS * 128);
+        const unsigned char* sb = a.w1 + (size_t)(tb + tile) * (32 * KS * 128);
         unsigned char* dst = w1s + (tile % NW1) * W1_BYTES;
 #pragma unroll
         for (int r = 0; r < (KS * 256 + NTHR - 1) / NTHR; ++r) {
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
     auto dma_w2 = [&](int tile) {                           // slot -> [plane][row][position]
         if constexpr (PROJECT) {
             const int tt = pf_opaque(t);
-            const unsigned char* sb = a.w2 + (size_t)tile * 128;
+            const unsigned char* sb = a.w2 + (size_t)(tb + tile) * 128;
 #pragma unroll
             for (int r = 0; r < (COUT * 8 + NTHR - 1) / NTHR; ++r) {
                 const int sl = r * NTHR + tt;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                     const int plane = sl >= COUT * 4 ? 1 : 0;
                     const int row = (sl - plane * COUT * 4) >> 2;
                     const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-                    glds(sb, (unsigned)(row * T * 128 + plane * 64 + chunk * 16), w2s + (size_t)sl * 16);
+                    glds(sb, (unsigned)(row * a.T * 128 + plane * 64 + chunk * 16), w2s + (size_t)sl * 16);
                 }
             }
         }
@@ -144,15 +146,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
         unsigned char* dst = cts + (tile % NCT) * CT_BYTES;
         if (tt < CT_SLOTS) {
             const int sl = tt < CT_FLOATS / 4 ? tt : 0;     // padding slots of the last wave re-read slot 0
-            glds(a.ctile + (size_t)tile * CT_FLOATS, (unsigned)(sl * 16), dst + (size_t)tt * 16);
+            glds(a.ctile + (size_t)(tb + tile) * CT_FLOATS, (unsigned)(sl * 16), dst + (size_t)tt * 16);
         } else if (MODE == 2 && tt < CT_SLOTS + 64) {       // the next wave: the gate values, slots GATE_OFF / 16 ... (8 distinct ones)
-            glds(a.gate + (size_t)face * a.CEXP + tile * 32, (unsigned)((tt & 7) * 16), dst + (size_t)tt * 16);
+            glds(a.gate + (size_t)face * a.CEXP + (tb + tile) * 32, (unsigned)((tt & 7) * 16), dst + (size_t)tt * 16);
         }
     };
 
     const bool prof = (pf_dbg(a) & 64) != 0;
     unsigned long long c_pro = 0, c_mma = 0, c_wa = 0, c_dw = 0, c_exp = 0, c_wb = 0, c_epi = 0;
-    for (int face = blockIdx.x; face < a.B; face += gridDim.x) {
+    const int NS = SQUEEZE ? a.nsplit : 1;
+    for (int unit = blockIdx.x; unit < a.B * NS; unit += gridDim.x) {
+        const int face = unit / NS, upart = unit - face * NS;
+        tb = a.T * upart / NS;
+        const int T = a.T * (upart + 1) / NS - tb;          // this unit's tiles: [tb, tb + T)
         const unsigned long long q0 = prof ? pf_clock() : 0;
         dma_w1(0);
         dma_ct(0, face);
@@ -345,8 +351,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                 for (int x = 0; x < XP; ++x) { rs[0] += of[2 * x]; rs[1] += of[2 * x + 1]; }
                 *reinterpret_cast<pf_f32x2*>(psum + (tile & 1) * (NPART * 32) + (yrow * NP + part) * 32 + c2) = rs;
                 if constexpr (STORE_D) {                    // a pixel's 32 channels of the tile are one 128-byte line: 16 lanes x 8 bytes
-                    float* drow = a.out + ((size_t)face * 256 + yrow * 16 + XP * part) * a.outLd + tile * 32 + c2;
-                    if (tile * 32 + c2 < a.CEXP && !(pf_dbg(a) & 16))
+                    float* drow = a.out + ((size_t)face * 256 + yrow * 16 + XP * part) * a.outLd + (tb + tile) * 32 + c2;
+                    if ((tb + tile) * 32 + c2 < a.CEXP && !(pf_dbg(a) & 16))
 #pragma unroll
                         for (int x = 0; x < XP; ++x) *reinterpret_cast<pf_f32x2*>(drow + (size_t)x * a.outLd) = pf_f32x2{of[2 * x], of[2 * x + 1]};
                 }
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mbx_kernel(MbxArgs a) {
                     float tot = 0.f;
 #pragma unroll
                     for (int q = 0; q < NPART; ++q) tot += ps[q * 32];
-                    const int c = tile * 32 + t;
+                    const int c = (tb + tile) * 32 + t;
                     if (c < a.CEXP) a.gap_out[(size_t)face * a.CEXP + c] = tot / 256.f;
                 }
             }

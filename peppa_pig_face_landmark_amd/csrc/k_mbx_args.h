@@ -14,6 +14,8 @@ struct MbxArgs {
     const unsigned char* w2;   // [COUT][T][hi 32 | lo 32] f16
     const float* b2;           // [COUT]
     int B, inC, inLd, outLd, resLd, T, CEXP, act;
+    int nsplit;                // MODE 1 / 3: a face's T channel tiles are independent there, so a face is `nsplit` work units (tile ranges) -- 384
+                               // faces on 256 CUs are two rounds of whole faces but three of half faces (1.5 instead of 2 face times); 1 otherwise
     float scale1, scale2;      // 1 / (power-of-two weight scales)
     unsigned* range_slot;
     unsigned long long* prof;  // ablation build, dbg & 64: per-wave cycle totals {prologue + expand(0), project, wait a, depthwise, expand, wait b, epilogue, waves}
