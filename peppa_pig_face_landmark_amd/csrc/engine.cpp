@@ -453,6 +453,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                         SepupArgs s{};
                         s.lo = a.up_lo; s.skip = a.up_skip; s.out = (float*)a.out; s.dw_lo = (const float*)p.cptr(f[14]); s.dw_w2 = a.dw_w2;
                         s.dw_v = (const float*)p.cptr(f[15]);
+                        s.gap_part = f[16] > 0 ? (float*)p.buf_ptr(f[16] - 1) : nullptr;
+                        if (s.gap_part && !(a.Npad == 256)) PF_FAIL(h, "sepup: per-tile channel sums need the 256-output instance");
                         s.wt = (const unsigned char*)a.wt; s.bias = a.bias; s.skipx = (unsigned char*)p.buf_ptr(f[13]);
                         s.B = B; s.H = to.H; s.C1 = tl.C; s.C2 = tk.C; s.loLd = tl.ld; s.skipLd = tk.ld; s.outLd = to.ld;
                         s.N = a.N; s.Cpad = a.Cpad; s.act = a.act; s.acc_scale = a.acc_scale; s.dbg = h->dbg; s.range_slot = a.range_slot;
@@ -474,6 +476,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
     }
                         PF_SEPUP_CASE(64) PF_SEPUP_CASE(32) PF_SEPUP_CASE(16)
 #undef PF_SEPUP_CASE
+                    } else if (f[16] > 0) {
+                        PF_FAIL(h, "sepup: the program asks for per-tile channel sums, which only the pipelined kernel produces");
                     } else
                     if (patch_ok && a.Npad == 256) {
                         grid.y = 1;
@@ -1001,6 +1005,8 @@ static int run_program_t(pf_handle* h, int slot, const void* d_input, int input_
                 a.scale2 = (const float*)p.cptr(f[7]); a.shift2 = (const float*)p.cptr(f[8]); a.act1b = f[9];
                 a.w2 = (const float*)p.cptr(f[10]); a.b2 = (const float*)p.cptr(f[11]); a.N = f[12]; a.act2 = f[13];
                 a.B = B;
+                a.nparts = f[14] > 0 ? f[14] : 1; memcpy(&a.xscale, &f[15], 4);
+                if (a.nparts == 1) a.xscale = 1.f;
                 if (a.K < 1 || a.K > 960 || a.R < 4 || a.R > 960 || (a.R & 3) || a.N < 4 || a.N > 960 || (a.N & 3) || !a.w1 || !a.w2 || (a.scale2 && !a.shift2))
                     PF_FAIL(h, "fc2: unsupported shape %d -> %d -> %d", a.K, a.R, a.N);
                 ProfScope ps(h, "fc");

@@ -363,6 +363,8 @@ struct Fc2Args {
     const float* b2;      // [N] or nullptr
     float* y;             // [B][N]
     int B, K, R, N, act1, act1b, act2;
+    int nparts;           // x is [B][nparts][K]: partial sums to be added (in order) and scaled by xscale -- the per-tile channel sums the decoder
+    float xscale;         // front end leaves behind (k_sepup.h gap_part) instead of a pooled vector; 1, 1.0 otherwise
 };
 
 // one FC phase: out[f][n] (LDS, [FB][NOUT]) = sum_k xs[f][k] * wt[k][n] for the workgroup's faces; xs rows are PF_FC2_MAXK floats, zero beyond K
@@ -430,7 +432,14 @@ __global__ __launch_bounds__(1024) void fc2_kernel(Fc2Args a) {
         // load); the padding of both staging arrays zeroed alongside
         float v[PF_FC2_FB];
 #pragma unroll
-        for (int f = 0; f < PF_FC2_FB; ++f) v[f] = a.x[(size_t)min(b0 + f, a.B - 1) * a.K + min(t, a.K - 1)];
+        for (int f = 0; f < PF_FC2_FB; ++f) v[f] = a.x[(size_t)min(b0 + f, a.B - 1) * a.nparts * a.K + min(t, a.K - 1)];
+        if (a.nparts > 1) {
+            for (int p = 1; p < a.nparts; ++p)
+#pragma unroll
+                for (int f = 0; f < PF_FC2_FB; ++f) v[f] += a.x[((size_t)min(b0 + f, a.B - 1) * a.nparts + p) * a.K + min(t, a.K - 1)];
+#pragma unroll
+            for (int f = 0; f < PF_FC2_FB; ++f) v[f] *= a.xscale;
+        }
 #pragma unroll
         for (int f = 0; f < PF_FC2_FB; ++f) {
             xs[f][t] = (b0 + f < a.B && t < a.K) ? v[f] : 0.f;

@@ -47,6 +47,8 @@ struct SepupArgs {
     int B, H, C1, C2, loLd, skipLd, outLd;
     int N, Cpad, act;
     float acc_scale;
+    float* gap_part;            // [B * tiles per face][N] or nullptr: per-tile channel sums of the ACTIVATED output (the squeeze of the SCSE block
+                                //                        that follows, model.py:117-130): the consumers have every output of a tile in registers
     unsigned* range_slot;       // f32s range guard: max |v| (raw bits) over the depthwise outputs both kernels split, or nullptr
     unsigned long long* prof;   // dbg & 64: per-role cycle totals {producer: work, barrier wait | consumer: dma issue, mfma, epilogue, barrier wait} + wave counts
     int dbg;                    // timing ablations (1 no weight refresh, 2 no patch/filter refresh, 4 no producer taps, 8 no MFMAs, 16 no stores)
@@ -159,14 +161,17 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
     constexpr int EXP_P = (P_BY_CONS ? 0 : PI) + (W_BY_PROD ? WI : 0);      // requests per iteration of a producer / consumer wave in steady state
     constexpr int EXP_C = (P_BY_CONS ? PI : 0) + (W_BY_PROD ? 0 : WI);
     constexpr int BIAS_BYTES = BIAS_REG ? 0 : BN * 4;
+    constexpr bool GAP_OK = !DEFER && W_BY_PROD;         // channel sums of the output (a.gap_part): the instance whose consumers count no vmcnt
+    constexpr int GAP_BYTES = GAP_OK ? 4 * BN * 4 : 0;   // [pixel quarter wm][channel]
     static_assert(PATCH_SLOTS + FILT_SLOTS <= P_INSTR * 64 && 1024 <= P_INSTR * 64, "patch/filter stage");
     static_assert(D >= 2 && (D - 2) * (PI + WI) + 1 < 63, "ring depth");
-    static_assert(2 * X_BYTES + D * W_BYTES + D * P_BYTES + BIAS_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + D * W_BYTES + D * P_BYTES + BIAS_BYTES];
+    static_assert(2 * X_BYTES + D * W_BYTES + D * P_BYTES + BN * 4 + GAP_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + D * W_BYTES + D * P_BYTES + (BIAS_BYTES ? BIAS_BYTES : 16) + GAP_BYTES];
     unsigned char* const xbase = smem;
     unsigned char* const wbase = smem + 2 * X_BYTES;
     unsigned char* const pbase = wbase + D * W_BYTES;
     float* const sbias = reinterpret_cast<float*>(pbase + D * P_BYTES);
+    float* const gsum = reinterpret_cast<float*>(pbase + D * P_BYTES + (BIAS_BYTES ? BIAS_BYTES : 16));
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -446,6 +451,7 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             if (n < a.N && !(pf_dbg(a) & 16)) *reinterpret_cast<pf_f32x4*>(orow + (size_t)m * a.outLd + n) = v;
         };
         int cj = 0, ccb = 0;                                        // consume position
+        int gap_gt = -1;                                            // GAP_OK: global tile whose partial sums wait in LDS
         const int xoff0 = pf_lds_chunk_off(wm * 32 + frow, fchunk), xoff1 = pf_lds_chunk_off(wm * 32 + 16 + frow, fchunk);
         unsigned long long t_dma = 0, t_mma = 0, t_epi = 0, t_wait = 0;
         for (int g = 0; g <= S; ++g) {
@@ -453,6 +459,14 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             unsigned long long c1 = c0, c2 = c0;
             int nreq = 0;
             bool stored = false;                                    // did this step issue a pending-vector store behind its weight requests?
+            if constexpr (GAP_OK) {
+                // the channel sums of the tile finished in the previous iteration: its four pixel quarters were parked in LDS before that
+                // iteration's barrier; added here in a fixed order, one channel per consumer thread
+                if (gap_gt >= 0) {
+                    if (rt < BN) a.gap_part[(size_t)gap_gt * a.N + rt] = (gsum[rt] + gsum[BN + rt]) + (gsum[2 * BN + rt] + gsum[3 * BN + rt]);
+                    gap_gt = -1;
+                }
+            }
             if (P_BY_CONS && issued_p < S && !(pf_dbg(a) & 2)) { dma_issue(issued_p % D); ++issued_p; nreq += PI; }
             if (g >= 1) {
                 const int c = g - 1;
@@ -497,9 +511,11 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
                             if (k >= NV - pend_left) store_vec(pend_row, k, pend[DEFER ? k : 0]);
                         pend_left = 0;
                     }
+                    const bool want_gap = GAP_OK && a.gap_part != nullptr;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const pf_f32x4 bv = BIAS_REG ? breg[BIAS_REG ? j : 0] : *reinterpret_cast<const pf_f32x4*>(sbias + wn * WN + j * 16 + crow);
+                        pf_f32x4 gs = pf_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             float v[4];
@@ -509,9 +525,22 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
                             const pf_f32x4 ov = pf_f32x4{v[0], v[1], v[2], v[3]};
                             if (DEFER) pend[DEFER ? j * 2 + i : 0] = ov;
                             else store_vec(orow, j * 2 + i, ov);
+                            gs += ov;
                             acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
                         }
+                        if constexpr (GAP_OK) {
+                            if (want_gap) {         // this wave's 32 pixels of channels n .. n + 3: the 16 lanes of a row hold 16 pixel pairs
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    float q = gs[r];
+                                    q += pf_row_xchg_f32<0>(q); q += pf_row_xchg_f32<1>(q); q += pf_row_xchg_f32<2>(q); q += pf_row_xchg_f32<3>(q);
+                                    gs[r] = q;
+                                }
+                                if (frow == 0) *reinterpret_cast<pf_f32x4*>(gsum + wm * BN + wn * WN + j * 16 + crow) = gs;
+                            }
+                        }
                     }
+                    if constexpr (GAP_OK) { if (want_gap) gap_gt = gt; }
                     if (DEFER) { pend_row = orow; pend_left = NV; }
                     ccb = 0;
                     ++cj;
@@ -533,280 +562,10 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
             for (int k = 0; k < NV; ++k)
                 if (k >= NV - pend_left) store_vec(pend_row, k, pend[DEFER ? k : 0]);
         }
+        if constexpr (GAP_OK) {                                     // the last tile's channel sums (parked before the loop's final barrier)
+            if (gap_gt >= 0 && rt < BN) a.gap_part[(size_t)gap_gt * a.N + rt] = (gsum[rt] + gsum[BN + rt]) + (gsum[2 * BN + rt] + gsum[3 * BN + rt]);
+        }
         if (prof && lane == 0) { atomicAdd(a.prof + 4, t_dma); atomicAdd(a.prof + 5, t_mma); atomicAdd(a.prof + 6, t_epi); atomicAdd(a.prof + 7, t_wait); atomicAdd(a.prof + 8, 1ull); }
     }
 }
 
-// ---- round 6: the same operator WITHOUT role specialisation ------------------------------------------------------------------------
-// sepup_pipe_kernel's K step is paced by ONE producer wave's serial instruction stream -- ~330 instructions (85 of them packed, which
-// cost two) + two request issues = 2 374 cycles, while the SIMD's VALU is 47 % busy and its matrix pipe 21 % (r05_run51_sepup_roles,
-// r05_run64_pmc_all): a wave issues one instruction per ~4 cycles whatever the unit, so the eight producers are the critical path and
-// the eight consumers wait for them.  Here all sixteen waves do both halves of a step on half the work each:
-//   produce   thread = (2 x 2 output block, ONE channel): 1 024 threads cover the tile's 32 blocks x 32 channels of the chunk; scalar f32
-//             (no packed operations), VCOL filters (the vertical interpolation folded into the filter, see sepup_pipe_kernel);
-//   consume   waves 4 (pixels) x 4 (channels): 32 x BN / 4 per wave, 3 x NT x 2 MFMAs per step;
-//   requests  one patch / filter instruction and BN / 128 weight instructions per wave and step; one barrier per step as before, the
-//             same rings and the same partial vmcnt accounting as the consumer role had.
-// Same arithmetic per output as sepup_pipe_kernel<.., VCOL = true> (filter products in the same order), same operand layout.
-template <int BN, int W, int D, bool DEFER>
-__global__ __launch_bounds__(1024, 4) void sepup_uni_kernel(SepupArgs a) {
-    constexpr int TR = 128 / W;
-    constexpr int PC = W / 2 + 2;
-    constexpr int PP = (TR / 2 + 2) * PC;
-    constexpr int BCOLS = W / 2;
-    constexpr int PATCH_SLOTS = PP * 8;
-    constexpr int FILT_SLOTS = TR * 9 * 8;
-    constexpr int P_BYTES = 16384;                       // 1 024 slots: one request per thread; also exactly one ready-made skip-chunk operand
-    constexpr int X_BYTES = 16384;
-    constexpr int W_BYTES = BN * 128;
-    constexpr int WI = BN * 8 / 1024;                    // weight requests per wave and stage: 1 (BN = 128) or 2
-    constexpr int WN = BN / 4, NT = WN / 16;             // 4 (pixels) x 4 (channels) waves, 32 x WN per wave
-    constexpr int NV = NT * 2;
-    constexpr int EXP = 1 + WI;                          // requests per wave and iteration in steady state
-    static_assert(PATCH_SLOTS + FILT_SLOTS <= 1024, "patch/filter stage");
-    static_assert(D >= 2 && (D - 2) * EXP + 1 < 63, "ring depth");
-    static_assert(2 * X_BYTES + D * W_BYTES + D * P_BYTES + BN * 4 <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + D * W_BYTES + D * P_BYTES + BN * 4];
-    unsigned char* const xbase = smem;
-    unsigned char* const wbase = smem + 2 * X_BYTES;
-    unsigned char* const pbase = wbase + D * W_BYTES;
-    float* const sbias = reinterpret_cast<float*>(pbase + D * P_BYTES);
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int H = a.H, loH = H >> 1;
-    constexpr int loW = W / 2;
-    const int TPF = H * W / 128;
-    const int xcd = blockIdx.x & 7, wl = blockIdx.x >> 3, L = gridDim.x >> 3;
-    const int nfaces = (a.B - xcd + 7) >> 3;
-    const int ntile_x = nfaces * TPF;
-    if (wl >= ntile_x) return;
-    const int nt = (ntile_x - wl + L - 1) / L;
-    const int NK = a.Cpad >> 5, lo_chunks = a.C1 >> 5, nskip = NK - lo_chunks;
-    const int S = nt * NK;
-    const size_t wrow_bytes = (size_t)NK * 128;
-
-    for (int i = t; i < BN; i += 1024) sbias[i] = a.bias[i];
-
-    auto tile_of = [&](int j, int& face, int& y0, int& gt) {
-        const int q = wl + j * L;
-        const int k = q / TPF, s = q - k * TPF;
-        face = xcd + 8 * k;
-        y0 = s * TR;
-        gt = face * TPF + s;
-    };
-    // ---- request streams ------------------------------------------------------------------------------------------------------
-    const float* dsrc;
-    int dadv;
-    int dj = 0, dcb = 0, dgt = 0;
-    auto dma_tile = [&](int j) {
-        int face, y0, gt;
-        tile_of(j, face, y0, gt);
-        dgt = gt;
-        const int rmin = (y0 >> 1) - 1;
-        const float* lo_face = a.lo + (size_t)face * loH * loW * a.loLd;
-        const int s = t;
-        if (s < PATCH_SLOTS) {
-            const int pp = s >> 3, sl = s & 7;
-            const int pr = pp / PC, pc = pp - pr * PC;
-            const int ry = min(max(rmin + pr, 0), loH - 1), rx = min(max(pc - 1, 0), loW - 1);
-            dsrc = lo_face + (size_t)(ry * loW + rx) * a.loLd + (sl << 2);
-            dadv = 32;
-        } else if (s < PATCH_SLOTS + FILT_SLOTS) {
-            const int fs = s - PATCH_SLOTS;
-            const int idx = fs >> 3, r = idx / 9, jk = idx - r * 9;
-            dsrc = a.dw_v + (size_t)(pf_pos_class(y0 + r, H) * 9 + jk) * a.C1 + ((fs & 7) << 2);
-            dadv = 32;
-        } else {
-            dsrc = a.dw_v;
-            dadv = 0;
-        }
-    };
-    auto dma_issue = [&](int stage) {
-        unsigned char* dst = pbase + stage * P_BYTES;
-        const bool lo_step = dcb < lo_chunks;
-        const unsigned char* skp = a.skipx + ((size_t)dgt * nskip + (dcb - lo_chunks)) * 16384;
-        const void* src = lo_step ? (const void*)(dsrc + dcb * dadv) : (const void*)(skp + (size_t)t * 16);
-        pf_glds16_raw(src, dst + (size_t)t * 16);
-        if (++dcb == NK) { dcb = 0; ++dj; if (dj < nt) dma_tile(dj); }
-    };
-    auto w_issue = [&](int step) {
-        const int cb = step % NK;
-        unsigned char* dst = wbase + (step % D) * W_BYTES;
-#pragma unroll
-        for (int c = 0; c < WI; ++c) {
-            const int sl = t + 1024 * c;
-            const int plane = sl >= BN * 4 ? 1 : 0;
-            const int row = (sl - plane * BN * 4) >> 2;
-            const int chunk = ((sl & 3) - 2 * (row >> 2)) & 3;
-            pf_glds16_raw(a.wt + (size_t)row * wrow_bytes + (size_t)cb * 128 + plane * 64 + chunk * 16, dst + (size_t)sl * 16);
-        }
-    };
-    int issued_p = 0, issued_w = 0;
-
-    // ---- producer half: thread = (2 x 2 block, one channel) ---------------------------------------------------------------------
-    const int blk = t >> 5, ch = t & 31;
-    const int brow = blk / BCOLS, bn = blk - brow * BCOLS;
-    const int pp0 = brow * PC + bn;
-    int xoff[2][2];
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 2; ++dx)
-            xoff[dy][dx] = pf_lds_chunk_off((2 * brow + dy) * W + 2 * bn + dx, ch >> 3) + (ch & 7) * 2;
-    const float ml = bn == 0 ? 0.f : 1.f, mr = bn == BCOLS - 1 ? 0.f : 1.f;
-    const float l0 = 0.75f * ml, l1 = 0.25f * ml, r0 = 0.25f * mr, r1 = 0.75f * mr;
-    // ---- consumer half ------------------------------------------------------------------------------------------------------------
-    const int wm = wave & 3, wn = wave >> 2;
-    const int frow = lane & 15, fchunk = lane >> 4;
-    const int crow = fchunk * 4;
-    const int xoff0 = pf_lds_chunk_off(wm * 32 + frow, fchunk), xoff1 = pf_lds_chunk_off(wm * 32 + 16 + frow, fchunk);
-
-    dma_tile(0);
-#pragma unroll
-    for (int k = 0; k < D - 1; ++k) {
-        if (issued_p < S) { dma_issue(issued_p % D); ++issued_p; }
-        if (issued_w < S) { w_issue(issued_w); ++issued_w; }
-    }
-    pf_wait_vm_barrier<(D - 2) * EXP>();                 // patch stage 0 and weight stage 0 have landed
-
-    pf_f32x4 acc[NT][2];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { acc[j][0] = pf_f32x4{0.f, 0.f, 0.f, 0.f}; acc[j][1] = pf_f32x4{0.f, 0.f, 0.f, 0.f}; }
-    pf_f32x4 pend[DEFER ? NV : 1];
-    float* pend_row = nullptr;
-    int pend_left = 0;
-    auto store_vec = [&](float* orow, int k, pf_f32x4 v) {
-        const int n = wn * WN + (k >> 1) * 16 + crow;
-        const int m = wm * 32 + (k & 1) * 16 + frow;
-        if (n < a.N) *reinterpret_cast<pf_f32x4*>(orow + (size_t)m * a.outLd + n) = v;
-    };
-    int pcb = 0, cj = 0, ccb = 0;
-    unsigned amax = 0;
-    const unsigned amax_seen = pf_amax_seen(a.range_slot);
-    for (int g = 0; g <= S; ++g) {
-        int nreq = 0;
-        bool stored = false;
-        if (issued_p < S) { dma_issue(issued_p % D); ++issued_p; nreq += 1; }
-        if (g >= 1 && issued_w < S) { w_issue(issued_w); ++issued_w; nreq += WI; }
-        // ---- produce the pixel operand of step g -----------------------------------------------------------------------------
-        if (g < S) {
-            const unsigned char* pst = pbase + (g % D) * P_BYTES;
-            unsigned char* xdst = xbase + (g & 1) * X_BYTES;
-            if (pcb < lo_chunks) {
-                const unsigned char* pa = pst + pp0 * 128 + ch * 4;
-                const unsigned char* wa = pst + PATCH_SLOTS * 16 + ch * 4;
-                float hrow[3][4];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    const float p0 = *reinterpret_cast<const float*>(pa + (r * PC + 0) * 128);
-                    const float p1 = *reinterpret_cast<const float*>(pa + (r * PC + 1) * 128);
-                    const float p2 = *reinterpret_cast<const float*>(pa + (r * PC + 2) * 128);
-                    hrow[r][0] = fmaf(p1, l1, p0 * l0);
-                    hrow[r][1] = fmaf(p1, 0.75f, p0 * 0.25f);
-                    hrow[r][2] = fmaf(p2, 0.25f, p1 * 0.75f);
-                    hrow[r][3] = fmaf(p2, r1, p1 * r0);
-                }
-                float o[2][2];
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    o[dy][0] = 0.f; o[dy][1] = 0.f;
-                    const unsigned char* wr = wa + (2 * brow + dy) * (9 * 128);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const float wv = *reinterpret_cast<const float*>(wr + (j * 3 + kx) * 128);
-#pragma unroll
-                            for (int dx = 0; dx < 2; ++dx) o[dy][dx] = fmaf(wv, hrow[j][dx + kx], o[dy][dx]);
-                        }
-                }
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const pf_half hv = (pf_half)o[dy][dx];
-                        amax = pf_amax(amax, o[dy][dx]);
-                        *reinterpret_cast<pf_half*>(xdst + xoff[dy][dx]) = hv;
-                        *reinterpret_cast<pf_half*>(xdst + 8192 + xoff[dy][dx]) = pf_split_lo(o[dy][dx], hv);
-                    }
-            } else {                                     // skip-connection chunk: the stage IS the pixel operand
-                *reinterpret_cast<pf_f32x4*>(xdst + t * 16) = *reinterpret_cast<const pf_f32x4*>(pst + t * 16);
-            }
-            if (++pcb == NK) pcb = 0;
-        }
-        // ---- consume step g - 1 ------------------------------------------------------------------------------------------------
-        if (g >= 1) {
-            const int c = g - 1;
-            const unsigned char* xs = xbase + (c & 1) * X_BYTES;
-            const unsigned char* wh = wbase + (c % D) * W_BYTES;
-            const unsigned char* wlp = wh + BN * 64;
-            pf_half8 xhf[2], xlf[2];
-            xhf[0] = *reinterpret_cast<const pf_half8*>(xs + xoff0);
-            xlf[0] = *reinterpret_cast<const pf_half8*>(xs + 8192 + xoff0);
-            xhf[1] = *reinterpret_cast<const pf_half8*>(xs + xoff1);
-            xlf[1] = *reinterpret_cast<const pf_half8*>(xs + 8192 + xoff1);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const int off = pf_lds_chunk_off(wn * WN + j * 16 + frow, fchunk);
-                const pf_half8 whf = *reinterpret_cast<const pf_half8*>(wh + off);
-                const pf_half8 wlf = *reinterpret_cast<const pf_half8*>(wlp + off);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);     // small terms first
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
-            }
-            if (DEFER && pend_left > 0) {
-#pragma unroll
-                for (int k = 0; k < NV; ++k)
-                    if (pend_left == NV - k) store_vec(pend_row, k, pend[DEFER ? k : 0]);
-                --pend_left;
-                stored = true;
-            }
-            if (++ccb == NK) {
-                int face, y0, gt;
-                tile_of(cj, face, y0, gt);
-                float* orow = a.out + (size_t)gt * 128 * a.outLd;
-                if (DEFER && pend_left > 0) {
-#pragma unroll
-                    for (int k = 0; k < NV; ++k)
-                        if (k >= NV - pend_left) store_vec(pend_row, k, pend[DEFER ? k : 0]);
-                    pend_left = 0;
-                    stored = false;                      // (several stores behind the requests: take the full drain below)
-                    nreq = -1;
-                }
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const pf_f32x4 bv = *reinterpret_cast<const pf_f32x4*>(sbias + wn * WN + j * 16 + crow);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float v[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[j][i][r], a.acc_scale, bv[r]);
-                        pf_act_n<4>(v, a.act);
-                        const pf_f32x4 ov = pf_f32x4{v[0], v[1], v[2], v[3]};
-                        if (DEFER) pend[DEFER ? j * 2 + i : 0] = ov;
-                        else store_vec(orow, j * 2 + i, ov);
-                        acc[j][i] = pf_f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-                if (DEFER) { pend_row = orow; pend_left = NV; }
-                else nreq = -1;                          // stores behind this step's requests: full drain
-                ccb = 0;
-                ++cj;
-            }
-        }
-        // everything OLDER than the (D - 2) youngest steps of requests must have landed (see sepup_pipe_kernel's consumer loop for the
-        // store that may ride behind a step's requests)
-        if (nreq == EXP && stored) pf_wait_vm_barrier<(D - 2) * EXP + 1>();
-        else if (nreq == EXP) pf_wait_vm_barrier<(D - 2) * EXP>();
-        else pf_wait_vm_barrier<0>();
-    }
-    if (DEFER && pend_left > 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-            if (k >= NV - pend_left) store_vec(pend_row, k, pend[DEFER ? k : 0]);
-    }
-    pf_amax_commit(a.range_slot, amax, amax_seen);
-}

@@ -74,11 +74,11 @@ enum PfOpCode : int32_t {
                         //    the expanded tile in LDS (k_mbx.h mbx_kernel); mode 0 = block without squeeze-excite, 1 = expand + depthwise -> per-face
                         //    channel means into gap_buf (the SE squeeze), 2 = expand + depthwise recomputed, x gate_buf, projected (+ res), 3 = mode 1
                         //    + the activated depthwise map stored in out_t (for the layer-wise gated projection); split programs only
-    PF_OP_FC2 = 25,     // f: x_buf y_buf w1 b1(-1) K R act1 scale2(-1) shift2(-1) act1b w2 b2(-1) N act2: two dependent FCs on pooled vectors in one launch
+    PF_OP_FC2 = 25,     // f: x_buf y_buf w1 b1(-1) K R act1 scale2(-1) shift2(-1) act1b w2 b2(-1) N act2 nparts(0 = 1) xscale(float bits): two dependent FCs on pooled vectors in one launch; x = xscale * sum of nparts partial vectors
                         //    (k_layers.h fc2_kernel: SE gate, cSE gate, ASPP pooled branch); K, R <= 960, R % 4 == 0, N % 4 == 0
     PF_OP_FRONT2 = 26,  // f: out_t w_stem_u8 w_stem_f32 b_stem s_u8 s_f32 (float bits) act_stem w_dw b_dw w_pw b_pw: conv_stem + blocks.0.0 of the Student encoder
                         //    (3x3 s2 3 -> 16 + act, depthwise 3x3 + relu -> 1x1 16 -> 16 + x) in one launch on the program input (k_front2.h); split programs only
-    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1]) dw_v(lo, [4 row classes][9][C1]: vertical interpolation folded in)
+    PF_OP_SEPUP = 12,   // f: lo_t skip_t out_t dwE(lo) dw_b(zeros: folded into pw_bias) pw_wt pw_bias Cpad Npad N act acc_scale(float bits) dw_w(skip) skipx_buf dw_w(lo, plain [9][C1]) dw_v(lo, [4 row classes][9][C1]: vertical interpolation folded in) gap_parts_buf + 1 (0 = none: per-tile channel sums of the output)
                         //    fused bilinear-x2-upsample + concat + depthwise 3x3 + pointwise conv (split kernels)
 };
 

@@ -718,8 +718,15 @@ class ProgramBuilder:
         self._op(OP_UPCAT, [lo, skip, out], [self._tb(lo), self._tb(skip)], [self._tb(out)])
         return out
 
+    def sepconv_up_can_sum(self, lo: int, skip: int, n_out: int) -> bool:
+        """Will ``sepconv_up`` run as the pipelined kernel's 256-output instance (csrc/k_sepup.h, engine.cpp pipe_ok), whose consumers can
+        leave per-tile channel sums of the output behind (``gap_parts=True``)?"""
+        tl, ts = self.tensors[lo], self.tensors[skip]
+        return (self.split and n_out == 256 and ts.W in (16, 32, 64) and (ts.H * ts.W) % 128 == 0 and (ts.H * ts.W) // 128 >= 2
+                and tl.C % 32 == 0 and ts.C % 8 == 0 and ts.C <= 64 and _round_up(tl.C + ts.C, 32) <= 640)
+
     def sepconv_up(self, lo: int, skip: int, dw_weight: np.ndarray, dw_bias: np.ndarray, pw_weight: np.ndarray,
-                   pw_bias: np.ndarray, act: str, out_name: str = "") -> int:
+                   pw_bias: np.ndarray, act: str, out_name: str = "", gap_parts: bool = False):
         """Fused DecoderBlock front end: cat(bilinear_x2(lo), skip) -> depthwise 3x3 (+bias, BN folded) ->
         1x1 conv (+bias, BN folded) -> act, in one split-precision GEMM launch (f32s programs only)."""
         assert self.split
@@ -761,10 +768,14 @@ class ProgramBuilder:
         # V[cy][j][kx][c] = sum_ky A_cy[ky][j] * W[c][ky][kx]  (csrc/k_sepup.h, VCOL)
         V = np.stack([np.einsum("kj,ckl->jlc", ay[cy], wdw[:c1]) for cy in range(4)])
         dwv = self.const_f32(V.reshape(4 * 9, c1))
+        parts = -1
+        if gap_parts:       # per-tile (128 pixels) channel sums of the activated output: the squeeze of the SCSE block behind it, for fc_pair(nparts=...)
+            assert self.sepconv_up_can_sum(lo, skip, n) and n == npad
+            parts = self.buffer((ts.H * ts.W // 128) * n, ELEM_F32, "sepup.gap_parts")
         self._op(OP_SEPUP, [lo, skip, out, dwe, self.const_f32(dw_bias), woff, self.const_f32(b), cpad, npad, n, ACT[act],
-                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, skipx, dwl, dwv],
-                 [self._tb(lo), self._tb(skip)], [self._tb(out), skipx])
-        return out
+                            struct.unpack("<i", struct.pack("<f", acc_scale))[0], dws, skipx, dwl, dwv, parts + 1],
+                 [self._tb(lo), self._tb(skip)], [self._tb(out), skipx, parts])
+        return (out, parts) if gap_parts else out
 
     def add_up(self, a: int, b: int, shift: int, act: str, out_name: str = "") -> int:
         """out = act(a + nearest_upsample(b, 2**shift)) (HRNet fuse layers)."""
@@ -830,26 +841,32 @@ class ProgramBuilder:
         self._op(OP_FC, [xbuf, out, woff, boff, k, n, ACT[act], s2, t2, ACT[act2]], [xbuf], [out])
         return out
 
+    def fc_pair_fuses(self, k: int, r: int, n: int) -> bool:
+        # one launch streams BOTH matrices through every workgroup (4 faces each): a win while they are small -- 5.4 against 9.0 us for
+        # 72 -> 24 -> 72, 11.1 against 12.9 us for 480 -> 120 -> 480 -- and a loss once a compute unit's 64 B / clock from the L2 is the
+        # bound (960 -> 240 -> 960, 1.8 MB per workgroup: 23.7 against 20.6 us; profiles/r06_run10_ub_fc2.txt).
+        # f32s programs only: the exact-f32 programs keep the two-launch form and with it their bit pattern (the golden of
+        # tests/test_tracking_parity.py was produced by the f32 engine as the reference FaceAna's landmark session)
+        return bool(self.split and getattr(self, "fuse_fc_pairs", True) and r % 4 == 0 and n % 4 == 0 and max(k, r, n) <= 960 and k * r + r * n <= 131072)
+
     def fc_pair(self, xbuf: int, w1: np.ndarray, b1: Optional[np.ndarray], act1: str, w2: np.ndarray, b2: Optional[np.ndarray], act2: str,
-                scale2: Optional[np.ndarray] = None, shift2: Optional[np.ndarray] = None, act1b: str = "none") -> int:
+                scale2: Optional[np.ndarray] = None, shift2: Optional[np.ndarray] = None, act1b: str = "none", nparts: int = 1,
+                xscale: float = 1.0) -> int:
         """y = act2(W2 h + b2), h = act1b(scale2 * act1(W1 x + b1) + shift2): two dependent FCs on pooled vectors -- an SE gate, the
         cSE gate, the ASPP's pooled branch.  ONE launch (csrc/k_layers.h fc2_kernel) when ``self.fuse_fc_pairs`` and the shapes allow
         it (R, N multiples of 4, everything <= 960), two ``fc`` ops otherwise."""
         r, k = w1.shape
         n, r2 = w2.shape
-        assert r2 == r and self.bufs[xbuf].elems == k
-        # one launch streams BOTH matrices through every workgroup (4 faces each): a win while they are small -- 5.4 against 9.0 us for
-        # 72 -> 24 -> 72, 11.1 against 12.9 us for 480 -> 120 -> 480 -- and a loss once a compute unit's 64 B / clock from the L2 is the
-        # bound (960 -> 240 -> 960, 1.8 MB per workgroup: 23.7 against 20.6 us; profiles/r06_run10_ub_fc2.txt)
-        # f32s programs only: the exact-f32 programs keep the two-launch form and with it their bit pattern (the golden of
-        # tests/test_tracking_parity.py was produced by the f32 engine as the reference FaceAna's landmark session)
-        if not (self.split and getattr(self, "fuse_fc_pairs", True) and r % 4 == 0 and n % 4 == 0 and max(k, r, n) <= 960 and k * r + r * n <= 131072):
+        assert r2 == r and self.bufs[xbuf].elems == k * nparts
+        if not self.fc_pair_fuses(k, r, n):
+            assert nparts == 1, "partial-sum inputs need the fused launch"
             hid = self.fc(xbuf, w1, b1, act1, scale2=scale2, shift2=shift2, act2=act1b)
             return self.fc(hid, w2, b2, act2)
         out = self.buffer(n, ELEM_F32, "fc2")
         cf = lambda v: self.const_f32(v) if v is not None else -1
         self._op(OP_FC2, [xbuf, out, self.const_f32(np.transpose(w1.astype(np.float64), (1, 0))), cf(b1), k, r, ACT[act1],
-                          cf(scale2), cf(shift2), ACT[act1b], self.const_f32(np.transpose(w2.astype(np.float64), (1, 0))), cf(b2), n, ACT[act2]],
+                          cf(scale2), cf(shift2), ACT[act1b], self.const_f32(np.transpose(w2.astype(np.float64), (1, 0))), cf(b2), n, ACT[act2],
+                          nparts, struct.unpack("<i", struct.pack("<f", float(xscale)))[0]],
                  [xbuf], [out])
         return out
 

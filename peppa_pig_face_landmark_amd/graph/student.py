@@ -75,9 +75,17 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
         wd, bd = ir.fold_bn(w[f"{name}.conv1.0.conv_dw.0.weight"], w[f"{name}.conv1.0.conv_dw.0.bias"],
                             _bn(w, f"{name}.conv1.0.conv_dw.1"))
         wp, bp = ir.fold_bn(w[f"{name}.conv1.0.conv_pw.weight"], None, _bn(w, f"{name}.conv1.1"))
+        parts = -1
         if pb.split and not keep_all:
-            # one launch: upsample + concat + depthwise + pointwise (the 280/296-channel tensors never reach HBM)
-            x = pb.sepconv_up(lo, skip, wd, bd, wp, bp, "relu", out_name=f"{name}.pw")
+            # one launch: upsample + concat + depthwise + pointwise (the 280/296-channel tensors never reach HBM).  When the block ends in
+            # the SCSE attention, the same launch leaves the per-tile channel sums of its output behind: the squeeze pass (a 268 MB read
+            # per 256 faces) disappears and the cSE FC pair adds the partial sums up (round 6)
+            if att and not second:
+                w1 = w[f"{name}.attention2.cSE.1.weight"]
+                if pb.sepconv_up_can_sum(lo, skip, wp.shape[0]) and pb.fc_pair_fuses(wp.shape[0], w1.shape[0], wp.shape[0]):
+                    x, parts = pb.sepconv_up(lo, skip, wd, bd, wp, bp, "relu", out_name=f"{name}.pw", gap_parts=True)
+            if parts < 0:
+                x = pb.sepconv_up(lo, skip, wd, bd, wp, bp, "relu", out_name=f"{name}.pw")
         else:
             x = pb.upcat(lo, skip, out_name=f"{name}.cat")
             x = pb.dw(x, wd, bd, "none", pad=1, out_name=f"{name}.dw")
@@ -86,10 +94,11 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
             wt, b = ir.fold_bn(w[f"{name}.conv2.0.weight"], w[f"{name}.conv2.0.bias"], _bn(w, f"{name}.conv2.1"))
             x = pb.conv(x, wt, b, "relu", pad=1, out_name=f"{name}.conv2")
         if att:
-            pooled = pb.gap(x)
             w1, w2 = w[f"{name}.attention2.cSE.1.weight"], w[f"{name}.attention2.cSE.3.weight"]
+            tx = pb.tensors[x]
+            pooled, kw = (parts, {"nparts": tx.H * tx.W // 128, "xscale": 1.0 / (tx.H * tx.W)}) if parts >= 0 else (pb.gap(x), {})
             cse = pb.fc_pair(pooled, w1.reshape(w1.shape[0], -1), w[f"{name}.attention2.cSE.1.bias"], "relu",
-                             w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid")
+                             w2.reshape(w2.shape[0], -1), w[f"{name}.attention2.cSE.3.bias"], "sigmoid", **kw)
             x = pb.scse(x, cse, w[f"{name}.attention2.sSE.0.weight"], float(w[f"{name}.attention2.sSE.0.bias"][0]),
                         out_name=f"{name}.scse")
         return x

@@ -138,7 +138,9 @@ def test_fc_pair_launch_equals_two_fc_launches(emu_engine, student_weights):
         emu_engine.load_program(0, blob, 3)
         outs.append(emu_engine.landmark_forward(crops))
         nops.append(info["n_ops"])
-    assert nops[1] - nops[0] == 6                            # the pairs with small matrices (ir.fc_pair): three stage-2 SE blocks, blocks.4.0's, cSE, ASPP pool
+    # six pairs with small matrices (ir.fc_pair: three stage-2 SE blocks, blocks.4.0's, cSE, ASPP pool) + the cSE squeeze pass, whose sums
+    # the decoder front end leaves behind per tile (csrc/k_sepup.h gap_part)
+    assert nops[1] - nops[0] == 7
     assert np.abs(outs[0][0] - outs[1][0]).max() < 2e-6 and np.abs(outs[0][1] - outs[1][1]).max() < 2e-4      # (scores are logits of range ~ 20)
 
 

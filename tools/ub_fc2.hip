@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dh, (size_t)B * R * 4)); CK(hipMalloc(&dy, (size_t)B * N * 4)); CK(hipMalloc(&dy2, (size_t)B * N * 4));
         CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw1, w1.data(), w1.size() * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw2, w2.data(), w2.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db1, b1.data(), R * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(db2, b2.data(), N * 4, hipMemcpyHostToDevice));
-        Fc2Args a{}; a.x = dx; a.w1 = dw1; a.b1 = db1; a.w2 = dw2; a.b2 = db2; a.y = dy2; a.B = B; a.K = K; a.R = R; a.N = N; a.act1 = PF_ACT_RELU; a.act1b = 0; a.act2 = PF_ACT_HSIGMOID;
+        Fc2Args a{}; a.x = dx; a.w1 = dw1; a.b1 = db1; a.w2 = dw2; a.b2 = db2; a.y = dy2; a.B = B; a.K = K; a.R = R; a.N = N; a.act1 = PF_ACT_RELU; a.act1b = 0; a.act2 = PF_ACT_HSIGMOID; a.nparts = 1; a.xscale = 1.f;
         FcArgs f1{}; f1.x = dx; f1.wt = dw1; f1.bias = db1; f1.y = dh; f1.B = B; f1.K = K; f1.N = R; f1.act = PF_ACT_RELU;
         FcArgs f2{}; f2.x = dh; f2.wt = dw2; f2.bias = db2; f2.y = dy; f2.B = B; f2.K = R; f2.N = N; f2.act = PF_ACT_HSIGMOID;
         auto pair = [&]() {

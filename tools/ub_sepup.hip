@@ -133,8 +133,6 @@ int main(int argc, char** argv) {
         run("no deferred stores", sepup_pipe_kernel<128, 64, 3, false, false>);
         run("VCOL", sepup_pipe_kernel<128, 64, 3, false, true, false, false, true>);
         run("VCOL + D=4", sepup_pipe_kernel<128, 64, 4, false, true, false, true, true>);
-        run("UNI D=3 defer", sepup_uni_kernel<128, 64, 3, true>);
-        run("UNI D=3 no defer", sepup_uni_kernel<128, 64, 3, false>);
     });
     run_shape<256, 32>("up1 (296 -> 256 at 32 x 32)", Shape{32, 256, 40, 256}, B, [&](auto run) {
         run("shipped <256,32,D=2,W by producers>", sepup_pipe_kernel<256, 32, 2, true, false>);
@@ -142,8 +140,6 @@ int main(int argc, char** argv) {
         run("patch requests by consumers", sepup_pipe_kernel<256, 32, 2, true, false, true, false>);
         run("all requests by consumers", sepup_pipe_kernel<256, 32, 2, false, false, true, false>);
         run("VCOL", sepup_pipe_kernel<256, 32, 2, true, false, false, false, true>);
-        run("UNI D=2 defer", sepup_uni_kernel<256, 32, 2, true>);
-        run("UNI D=2 no defer", sepup_uni_kernel<256, 32, 2, false>);
     });
     return 0;
 }
