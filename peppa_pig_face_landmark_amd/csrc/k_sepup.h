@@ -165,13 +165,13 @@ __global__ __launch_bounds__(1024, 4) void sepup_pipe_kernel(SepupArgs a) {
     constexpr int GAP_BYTES = GAP_OK ? 4 * BN * 4 : 0;   // [pixel quarter wm][channel]
     static_assert(PATCH_SLOTS + FILT_SLOTS <= P_INSTR * 64 && 1024 <= P_INSTR * 64, "patch/filter stage");
     static_assert(D >= 2 && (D - 2) * (PI + WI) + 1 < 63, "ring depth");
-    static_assert(2 * X_BYTES + D * W_BYTES + D * P_BYTES + BN * 4 + GAP_BYTES <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + D * W_BYTES + D * P_BYTES + (BIAS_BYTES ? BIAS_BYTES : 16) + GAP_BYTES];
+    static_assert(2 * X_BYTES + D * W_BYTES + D * P_BYTES + BIAS_BYTES + GAP_BYTES <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X_BYTES + D * W_BYTES + D * P_BYTES + BIAS_BYTES + GAP_BYTES];
     unsigned char* const xbase = smem;
     unsigned char* const wbase = smem + 2 * X_BYTES;
     unsigned char* const pbase = wbase + D * W_BYTES;
     float* const sbias = reinterpret_cast<float*>(pbase + D * P_BYTES);
-    float* const gsum = reinterpret_cast<float*>(pbase + D * P_BYTES + (BIAS_BYTES ? BIAS_BYTES : 16));
+    float* const gsum = reinterpret_cast<float*>(pbase + D * P_BYTES + BIAS_BYTES);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
