@@ -28,7 +28,7 @@ def pipeline_available() -> bool:
 def build_programs(workload: str, dtype: str, model: str = "student", **student_kw) -> Dict[int, bytes]:
     if model == "teacher":
         from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program, random_teacher_weights
-        blobs = {_native.PF_NET_LANDMARK: build_teacher_program(random_teacher_weights(2), 256, dtype)[0]}
+        blobs = {_native.PF_NET_LANDMARK: build_teacher_program(random_teacher_weights(2), 256, dtype, **{k: v for k, v in student_kw.items() if k == "one_product"})[0]}
     else:
         blobs = {_native.PF_NET_LANDMARK: build_student_program(random_student_weights(0), 256, dtype, **student_kw)[0]}
     if workload == "pipeline":

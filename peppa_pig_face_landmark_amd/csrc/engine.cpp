@@ -283,6 +283,7 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
             // neighbouring bytes to the MFMAs and the range guard -- such a layer takes the masked halo kernel below
             const bool hero = a.Npad == 128 && a.Cpad == 128 && a.inC == 128 && (a.inLd & 3) == 0 && a.outW == 64;
             if (hero && (host_dbg(h) & 16384)) PF_LAUNCH((conv3x3_hero_kernel<4, false>), grid, dim3(512), h->stream, a);   // A/B aid (ablation build)
+            else if (hero && f[23] == 2) PF_LAUNCH((conv3x3_hero_kernel<4, true, true>), grid, dim3(512), h->stream, a);   // ONE f16 product (opt-in per conv)
             else if (hero && !(host_dbg(h) & 2048)) PF_LAUNCH((conv3x3_hero_kernel<4>), grid, dim3(512), h->stream, a);   // k_hero.h
             else if (a.Npad == 128) PF_LAUNCH((conv3x3_halo_split_kernel<128, 4, 2>), grid, dim3(512), h->stream, a);
             else if (a.Npad == 64 && big) PF_LAUNCH((conv3x3_halo_split_kernel<64, 4, 2, 256>), grid, dim3(512), h->stream, a);   // HRNet layer1's 64 -> 64
@@ -319,7 +320,8 @@ static int launch_conv(pf_handle* h, const Program& p, const PfOpRec& op, int B,
                     }
                 }
                 a.head_segs = segs;
-                PF_LAUNCH((pw_head_kernel<4>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);
+                if (f[23] == 2) PF_LAUNCH((pw_head_kernel<4, true>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);   // ONE f16 product (opt-in per conv)
+                else PF_LAUNCH((pw_head_kernel<4>), dim3(persistent_grid(B * segs, 1)), dim3(512), h->stream, a);
             }
             else if (a.Cpad == 128) PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1, 1, 0, 4>), grid, dim3(512), h->stream, a);   // K loop unrolled, two steps ahead
             else PF_LAUNCH((conv_gemm_split_kernel<128, 128, 4, 2, 1, 0, -1>), grid, dim3(512), h->stream, a);

@@ -15,7 +15,11 @@
 #pragma once
 #include "k_conv_gemm.h"
 
-template <int CB, bool LATE_DMA = true>
+// ONEPROD (round 6, opt-in per conv: ir.py conv(products=1), build_student_program(one_product=...)): ONE f16 product per 32 k -- both operands
+// rounded to f16, exact products, f32 accumulation -- instead of the three of the split: no lo planes, no lo weight rows in the stream,
+// a third of the MFMAs.  Which layers tolerate it is a property of the network: tools/teacher_precision_study.py --model student
+// (profiles/r06_student_precision_study.txt) puts this conv alone at 4.9e-5 of the oracle's landmarks (north star 1e-3).
+template <int CB, bool LATE_DMA = true, bool ONEPROD = false>
 __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
     constexpr int BN = 128, BM = 128, W = 64, TR = 2, WARPS_M = 4, WARPS_N = 2, NTHR = 512;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N, MT = WM / 16, NT = WN / 16;
@@ -24,9 +28,9 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
     constexpr int W_BYTES = BN * 128;
     constexpr int NSTG = 3, NKT = 9 * CB;
     constexpr int XU = XROWS * 4 / NTHR;                 // (pixel, 8-channel unit) pairs per thread: 2
-    constexpr int WCH = BN * 8 / NTHR;                   // 16-byte weight slots per thread and stage: 2
+    constexpr int WCH = (ONEPROD ? BN * 4 : BN * 8) / NTHR;      // 16-byte weight slots per thread and stage: 2 (hi rows, then lo rows); ONEPROD: the hi rows only
     constexpr int WMID = (NKT / 2) * 128;                // the weight pointers sit in the middle of a row: offsets of +-2304 bytes fit the instruction
-    static_assert(MT == 2 && NT == 4 && XU == 2 && WCH == 2 && 2 * PLANE_X + NSTG * W_BYTES <= 80 * 1024, "tile shape");
+    static_assert(MT == 2 && NT == 4 && XU == 2 && WCH == (ONEPROD ? 1 : 2) && 2 * PLANE_X + NSTG * W_BYTES <= 80 * 1024, "tile shape");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PLANE_X + NSTG * W_BYTES];
     unsigned char* xh = smem;
     unsigned char* xl = smem + PLANE_X;
@@ -82,12 +86,12 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
                 const float v = xok[u] ? xreg[u][e >> 2][e & 3] : 0.f;
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = pf_split_lo(v, hv);
+                if constexpr (!ONEPROD) lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             const int off = pf_lds_chunk_off((t >> 2) + (NTHR / 4) * u, xc);
             *reinterpret_cast<pf_half8*>(xh + off) = hi;
-            *reinterpret_cast<pf_half8*>(xl + off) = lo;
+            if constexpr (!ONEPROD) *reinterpret_cast<pf_half8*>(xl + off) = lo;
         }
     };
     // weights of step kt (chunk kt / 9, tap kt % 9; K index tap * CB + chunk) -> ring stage kt % NSTG
@@ -140,11 +144,11 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
                 const int r = row0[i] + ky * W + kx - 1;
                 const int off = pf_lds_chunk_off(min(max(r, 0), XROWS - 1), fchunk);
                 xhf[i] = *reinterpret_cast<const pf_half8*>(xh + off);
-                xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
+                if constexpr (!ONEPROD) xlf[i] = *reinterpret_cast<const pf_half8*>(xl + off);
                 if constexpr (kx != 1) {
                     if (kx == 0 ? edge0[i] : edge2[i]) {
                         xhf[i] = pf_half8{0, 0, 0, 0, 0, 0, 0, 0};
-                        xlf[i] = xhf[i];
+                        if constexpr (!ONEPROD) xlf[i] = xhf[i];
                     }
                 }
             }
@@ -154,20 +158,23 @@ __global__ __launch_bounds__(512, 4) void conv3x3_hero_kernel(ConvGemmArgs a) {
             {
                 const int off = pf_lds_chunk_off(wn * WN + frow, fchunk);
                 wq[0][0] = *reinterpret_cast<const pf_half8*>(wh + off);
-                wq[0][1] = *reinterpret_cast<const pf_half8*>(wl + off);
+                if constexpr (!ONEPROD) wq[0][1] = *reinterpret_cast<const pf_half8*>(wl + off);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 if (j + 1 < NT) {
                     const int off = pf_lds_chunk_off(wn * WN + (j + 1) * 16 + frow, fchunk);
                     wq[(j + 1) & 1][0] = *reinterpret_cast<const pf_half8*>(wh + off);
-                    wq[(j + 1) & 1][1] = *reinterpret_cast<const pf_half8*>(wl + off);
+                    if constexpr (!ONEPROD) wq[(j + 1) & 1][1] = *reinterpret_cast<const pf_half8*>(wl + off);
                 }
-                const pf_half8 whf = wq[j & 1][0], wlf = wq[j & 1][1];
+                const pf_half8 whf = wq[j & 1][0];
+                if constexpr (!ONEPROD) {
+                    const pf_half8 wlf = wq[j & 1][1];
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlf, xhf[i], acc[j][i]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xlf[i], acc[j][i]);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf, xhf[i], acc[j][i]);
                 asm volatile("" ::: "memory");

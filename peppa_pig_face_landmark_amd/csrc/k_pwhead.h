@@ -17,7 +17,8 @@
 #pragma once
 #include "k_conv_gemm.h"
 
-template <int NK>
+// ONEPROD (round 6, opt-in like conv3x3_hero_kernel's): one f16 product per 32 k -- no lo planes, no lo weight halves, a third of the MFMAs.
+template <int NK, bool ONEPROD = false>
 __global__ __launch_bounds__(512, 2) void pw_head_kernel(ConvGemmArgs a) {
     constexpr int BM = 128, BN = 128, WARPS_M = 4, WARPS_N = 2;
     constexpr int WM = BM / WARPS_M, WN = BN / WARPS_N, MT = WM / 16, NT = WN / 16;
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(512, 2) void pw_head_kernel(ConvGemmArgs a) {
                 const float v = xr[s][e >> 2][e & 3];
                 const pf_half hv = (pf_half)v;
                 hi[e] = hv;
-                lo[e] = pf_split_lo(v, hv);
+                if constexpr (!ONEPROD) lo[e] = pf_split_lo(v, hv);
                 amax = pf_amax(amax, v);
             }
             *reinterpret_cast<pf_half8*>(base + s * PLANE) = hi;
-            *reinterpret_cast<pf_half8*>(base + (NK + s) * PLANE) = lo;
+            if constexpr (!ONEPROD) *reinterpret_cast<pf_half8*>(base + (NK + s) * PLANE) = lo;
         }
     };
     pf_f32x4 acc[NT][MT];
@@ -102,15 +103,17 @@ __global__ __launch_bounds__(512, 2) void pw_head_kernel(ConvGemmArgs a) {
             for (int i = 0; i < MT; ++i) {
                 const int off = pf_lds_chunk_off(wm * WM + i * 16 + frow, fchunk);
                 xhf[i] = *reinterpret_cast<const pf_half8*>(base + s * PLANE + off);
-                xlf[i] = *reinterpret_cast<const pf_half8*>(base + (NK + s) * PLANE + off);
+                if constexpr (!ONEPROD) xlf[i] = *reinterpret_cast<const pf_half8*>(base + (NK + s) * PLANE + off);
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {          // small terms first, the dominant hi * hi term last (as conv_gemm_split_kernel)
-                const pf_half8 wlj = *reinterpret_cast<const pf_half8*>(s_wl + s * (MAXN * 64) + wloff[j]);
+                if constexpr (!ONEPROD) {
+                    const pf_half8 wlj = *reinterpret_cast<const pf_half8*>(s_wl + s * (MAXN * 64) + wloff[j]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlj, xhf[i], acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(wlj, xhf[i], acc[j][i]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf[j][s], xlf[i], acc[j][i]);
+                    for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf[j][s], xlf[i], acc[j][i]);
+                }
 #pragma unroll
                 for (int i = 0; i < MT; ++i) acc[j][i] = pf_mfma_16x16x32_f16(whf[j][s], xhf[i], acc[j][i]);
             }

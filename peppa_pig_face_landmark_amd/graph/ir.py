@@ -208,8 +208,10 @@ class ProgramBuilder:
     def conv(self, x: int, weight: np.ndarray, bias: np.ndarray, act: str, *, stride: int = 1, pad: int = 0,
              dil: int = 1, out: Optional[int] = None, res: int = -1, gate_buf: int = -1, fbias_buf: int = -1,
              out_cs: int = 1, amax: Optional[Tuple[int, int, int]] = None, store_out: bool = True,
-             cfg: int = -1, out_name: str = "") -> int:
-        """Dense conv as MFMA implicit GEMM.  weight [N,Cin,KH,KW] float (already BN-folded)."""
+             cfg: int = -1, out_name: str = "", products: int = 3) -> int:
+        """Dense conv as MFMA implicit GEMM.  weight [N,Cin,KH,KW] float (already BN-folded).
+        ``products=1`` (split programs, opt-in): ONE f16 product per 32 k instead of the split's three, where the engine has such a
+        kernel for the shape (csrc/k_hero.h; elsewhere the field is ignored and the conv runs at full precision)."""
         ti = self.tensors[x]
         n, cin, kh, kw = weight.shape
         assert cin == ti.real_c, (cin, ti.real_c)
@@ -227,7 +229,7 @@ class ProgramBuilder:
         av, ai, an = amax if amax is not None else (-1, -1, 0)
         self._op(OP_CONV, [x, out, woff, boff, res, gate_buf, fbias_buf, kh, kw, stride, pad, dil, cpad, npad, n,
                            ACT[act], out_cs, av, ai, an, 1 if store_out else 0, cfg,
-                           struct.unpack("<i", struct.pack("<f", acc_scale))[0], 1 if use_split else 0],
+                           struct.unpack("<i", struct.pack("<f", acc_scale))[0], (2 if products == 1 else 1) if use_split else 0],
                  [self._tb(x), self._tb(res), gate_buf, fbias_buf], [self._tb(out), av, ai])
         return out
 

@@ -48,7 +48,7 @@ def _bn(w: Dict[str, np.ndarray], prefix: str) -> Dict[str, np.ndarray]:
 
 
 def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], encx4: int, encx8: int, encx16: int,
-                           input_size: int, keep_all: bool, debug_full_hm: bool):
+                           input_size: int, keep_all: bool, debug_full_hm: bool, one_product=()):
     """Decoder (ASPP + two DecoderBlocks, model.py:212-244) + hm head + fused decode; shared by the
     Student (mobilenetv3 features 24/40/160 ch) and the Teacher (hrnet_w18 features 128/256/512 ch)."""
     h16 = input_size // 16
@@ -92,7 +92,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
             x = pb.conv(x, wp, bp, "relu", out_name=f"{name}.pw")
         if second:
             wt, b = ir.fold_bn(w[f"{name}.conv2.0.weight"], w[f"{name}.conv2.0.bias"], _bn(w, f"{name}.conv2.1"))
-            x = pb.conv(x, wt, b, "relu", pad=1, out_name=f"{name}.conv2")
+            x = pb.conv(x, wt, b, "relu", pad=1, out_name=f"{name}.conv2", products=1 if "hero" in one_product else 3)
         if att:
             w1, w2 = w[f"{name}.attention2.cSE.1.weight"], w[f"{name}.attention2.cSE.3.weight"]
             tx = pb.tensors[x]
@@ -123,7 +123,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
     dummy = pb.tensor(h4, h4, ir._round_up(NUM_POINTS, pb.ve), buf=pb.buffer(pb.ve, ir.ELEM_ACT, "hm.unused"),
                       coff=0, ld=ir._round_up(NUM_POINTS, pb.ve))
     pb.conv(decx4, hw[:NUM_POINTS], hb[:NUM_POINTS], "none", out=dummy, amax=(val, idx, NUM_POINTS),
-            store_out=False, cfg=0)
+            store_out=False, cfg=0, products=1 if "head" in one_product else 3)
     loc, score = pb.hmdec(val, idx, decx4, hw[NUM_POINTS:, :, 0, 0], hb[NUM_POINTS:], NUM_POINTS, nslots)
     return loc, score, info
 
@@ -131,7 +131,7 @@ def build_decoder_and_head(pb: "ir.ProgramBuilder", w: Dict[str, np.ndarray], en
 def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f16",
                           keep_all: bool = False, debug_full_hm: bool = False, fuse_mbconv: bool = True,
                           fuse_mbx: Optional[bool] = None, mbx_se: Optional[str] = None, mbx_waves: int = 16, fuse_fc_pairs: bool = True,
-                          fuse_front2: bool = True):
+                          fuse_front2: bool = True, one_product=()):
     """Returns (blob: bytes, info: dict).  ``info['tensors']`` maps layer names to tensor ids for
     ``pf_read_tensor`` (only meaningful with ``keep_all=True``)."""
     assert input_size % 64 == 0, "input size must be a multiple of 64 (heat-map tile = 128 pixels)"
@@ -225,7 +225,11 @@ def build_student_program(weights: Dict[str, np.ndarray], input_size: int = 256,
             cur_dil = next_dil
             cin = cout
         feats[si] = x
-    loc, score, info = build_decoder_and_head(pb, w, feats[1], feats[2], feats[5], input_size, keep_all, debug_full_hm)
+    # one_product (opt-in, f32s programs; NOT the parity-grade default): names of layers to run on ONE f16 product instead of the split's
+    # three -- "hero" = decoder.upsampler2.conv2 (42 % of the dense MACs; alone 4.9e-5 of the oracle's landmarks on the synthetic weights,
+    # profiles/r06_student_precision_study.txt), "head" = the 98 score channels of the heat-map conv (7.4e-5 alone; the offsets at the
+    # arg-max stay exact f32 in hm_decode)
+    loc, score, info = build_decoder_and_head(pb, w, feats[1], feats[2], feats[5], input_size, keep_all, debug_full_hm, tuple(one_product))
     blob = pb.finish([loc, score])
     info.update({"tensors": dict(pb.tensor_names), "input_size": input_size, "dtype": dtype,
                  "n_ops": len(pb.ops), "const_bytes": len(pb.consts)})

@@ -37,7 +37,9 @@ def _bn(w, prefix):
 
 
 def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256, dtype: str = "f32s",
-                          keep_all: bool = False, debug_full_hm: bool = False, fuse_chains: bool = True):
+                          keep_all: bool = False, debug_full_hm: bool = False, fuse_chains: bool = True, one_product=()):
+    """``one_product`` (opt-in, f32s): decoder layers on ONE f16 product, as in ``build_student_program`` -- "hero" and "head" are two of the
+    four groups the per-layer study found tolerant on the Teacher (profiles/r06_teacher_precision_study.txt: 1.2e-4 and 1.0e-4 alone)."""
     assert input_size % 64 == 0
     w = weights
     pb = ir.ProgramBuilder(dtype, input_size, input_size, keep_all=keep_all)
@@ -123,7 +125,7 @@ def build_teacher_program(weights: Dict[str, np.ndarray], input_size: int = 256,
                 fused.append(y)
             xs = fused
     feats = [bottleneck(xs[i], f"{e}.incre_modules.{i}.0", name=f"encoder.incre{i}") for i in range(3)]
-    loc, score, info = build_decoder_and_head(pb, w, feats[0], feats[1], feats[2], input_size, keep_all, debug_full_hm)
+    loc, score, info = build_decoder_and_head(pb, w, feats[0], feats[1], feats[2], input_size, keep_all, debug_full_hm, tuple(one_product))
     blob = pb.finish([loc, score])
     info.update({"tensors": dict(pb.tensor_names), "input_size": input_size, "dtype": dtype,
                  "n_ops": len(pb.ops), "const_bytes": len(pb.consts)})

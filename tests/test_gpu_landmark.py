@@ -55,6 +55,33 @@ def test_student_f32_matches_oracle(gpu_engine, student_weights, size, batch, dt
     assert flips <= 0.005 * safe.size + 1, (flips, safe.size)
 
 
+def test_student_one_product_hero_mix_stays_within_its_budget(gpu_engine, student_weights):
+    """Round 6, OPT-IN (bench.py --mix hero; never the parity-grade default): decoder.upsampler2.conv2 -- 42 % of the Student's dense
+    MACs -- on ONE f16 product per 32 k instead of the split's three (csrc/k_hero.h ONEPROD).  The oracle study
+    (tools/teacher_precision_study.py --model student, profiles/r06_student_precision_study.txt) puts this layer alone at 4.9e-5 of the
+    oracle's landmarks; the engine must stay within 2.5e-4 (north star: 1e-3) on the margin-safe landmarks, flip none of them, and
+    differ from the default program only behind that conv."""
+    size, batch = 256, 6
+    crops = sw.smooth_blob_images(batch, size, seed=4256)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    margins = helpers.heat_margins(taps)
+    safe = margins > 2e-3
+    res = {}
+    for mix in ((), ("hero",), ("hero", "head")):
+        blob, info = build_student_program(student_weights, size, "f32s", one_product=mix)
+        gpu_engine.load_program(0, blob, batch)
+        res[mix] = gpu_engine.landmark_forward(crops)
+    err = {mix: np.abs(r[0] - oloc).reshape(batch, 98, 2).max(2) for mix, r in res.items()}
+    print("max |loc - oracle| on the %d margin-safe landmarks of %d: " % (int(safe.sum()), safe.size) +
+          "; ".join("%s %.2e" % ("+".join(m) or "three products", e[safe].max()) for m, e in err.items()))
+    assert err[()][safe].max() < 1e-4
+    for mix in (("hero",), ("hero", "head")):
+        assert err[mix][safe].max() < 2.5e-4, mix                      # no margin-safe landmark moved to another cell either (a cell is 1.6e-2)
+        assert np.abs(res[mix][1] - oscore)[safe].max() < 3e-2, mix     # scores: heat-map logits of range ~ 20
+    assert not np.array_equal(res[()][0], res[("hero",)][0])           # the switches reached the kernels
+    assert not np.array_equal(res[("hero",)][1], res[("hero", "head")][1])
+
+
 def test_student_f32_production_program_equals_debug_program(gpu_engine, student_weights):
     """Arena reuse + fused 98-channel head give the same answers as the keep-all debug build."""
     size, batch = 256, 4
@@ -160,6 +187,33 @@ def test_teacher_256_matches_oracle(gpu_engine, dtype):
     gpu_engine.load_program(0, blob, batch)
     loc2, _ = gpu_engine.landmark_forward(crops)
     assert np.abs(loc2 - oloc.numpy()).reshape(batch, 98, 2).max(2)[safe].max() < 2e-4
+
+
+def test_teacher_one_product_hero_head_mix_stays_within_its_budget(gpu_engine):
+    """BASELINE config 5 names fp16 MFMA; round 5 asked for the mix of layers that tolerates ONE f16 product within 2.5e-4.  The oracle study
+    (profiles/r06_teacher_precision_study.txt) finds four groups -- 21.6 % of the Teacher's dense MACs -- of which the engine has
+    one-product kernels for two: the decoder's hero conv and the score head (opt-in: build_teacher_program(one_product=("hero", "head")))."""
+    import torch
+    from oracle import landmark_net as ln
+    from oracle import teacher_net as tn
+    from peppa_pig_face_landmark_amd.graph.teacher import build_teacher_program
+    weights = sw.teacher_weights()
+    size, batch = 256, 4
+    crops = sw.smooth_blob_images(batch, size, seed=77)
+    x = torch.from_numpy(crops.astype(np.float32) / np.float32(255.0)).permute(0, 3, 1, 2).contiguous()
+    taps = {}
+    with torch.no_grad():
+        oloc, oscore = tn.teacher_forward(ln.to_torch(weights), x, taps)
+    safe = helpers.heat_margins(taps) > 2e-3
+    errs = {}
+    for mix in ((), ("hero", "head")):
+        blob, _ = build_teacher_program(weights, size, "f32s", one_product=mix)
+        gpu_engine.load_program(0, blob, batch)
+        loc, score = gpu_engine.landmark_forward(crops)
+        errs[mix] = np.abs(loc - oloc.numpy()).reshape(batch, 98, 2).max(2)[safe].max()
+    print("teacher: three products %.2e; hero + head on one product %.2e (%d margin-safe landmarks of %d)" % (errs[()], errs[("hero", "head")], int(safe.sum()), safe.size))
+    assert errs[()] < 2e-4
+    assert errs[("hero", "head")] < 2.5e-4
 
 
 def test_teacher_f16_fast_mode_is_measured_not_claimed(gpu_engine):

@@ -30,7 +30,14 @@ from oracle import teacher_net as tn           # noqa: E402
 
 
 def group_of(name: str) -> str:
-    """Layer groups = the engine's kernels (graph/teacher.py): one switch per fused op family."""
+    """Layer groups = the engine's kernels (graph/teacher.py, graph/student.py): one switch per fused op family."""
+    if name.startswith("encoder.conv_stem"):
+        return "stem"
+    m = re.match(r"encoder\.blocks\.(\d)\.(\d)\.(conv_pwl|conv_pw|conv_dw)", name)
+    if m:           # Student: expand / project convs of a stage (the SE 1x1 convs run as f32 FCs on pooled vectors: never rounded)
+        return "stage%s.%s" % (m.group(1), {"conv_pw": "expand", "conv_pwl": "project", "conv_dw": "pointwise(ds)"}[m.group(3)])
+    if re.match(r"encoder\.blocks\.\d\.\d\.se", name):
+        return "skip"
     if name.startswith("encoder.conv1"):
         return "stem.conv1"
     if name.startswith("encoder.conv2"):
@@ -65,9 +72,10 @@ def main():
     ap.add_argument("--faces", type=int, default=4)
     ap.add_argument("--out", default="")
     ap.add_argument("--budget", type=float, default=2.5e-4)
+    ap.add_argument("--model", default="teacher", choices=["teacher", "student"])
     args = ap.parse_args()
     torch.set_num_threads(max(1, (os.cpu_count() or 2) - 1))
-    weights = sw.teacher_weights()
+    weights = sw.teacher_weights() if args.model == "teacher" else sw.student_weights()
     W = ln.to_torch(weights)
     name_of = {id(t): n for n, t in W.items()}
     crops = sw.smooth_blob_images(args.faces, 256, seed=77)
@@ -78,14 +86,14 @@ def main():
 
     def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         name = name_of.get(id(w))
-        if name is not None and groups == 1:
+        if name is not None and groups == 1 and group_of(name) != "skip":
             g = group_of(name)
             state["seen"].setdefault(g, set()).add(name)
             if g in state["round"]:
                 inp = inp.half().float()
                 w = w.half().float()
         y = real(inp, w, b, stride, padding, dilation, groups)
-        if name is not None and groups == 1:
+        if name is not None and groups == 1 and group_of(name) != "skip":
             g = group_of(name)
             state["macs"].setdefault(g, {})[name] = y.shape[2] * y.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
         return y
@@ -96,7 +104,7 @@ def main():
             state["round"] = set(groups)
             taps = {}
             with torch.no_grad():
-                loc, score = tn.teacher_forward(W, x, taps)
+                loc, score = (tn.teacher_forward if args.model == "teacher" else ln.student_forward)(W, x, taps)
             return loc.numpy(), score.numpy(), taps["hm"].numpy()
 
         t0 = time.time()
