@@ -160,3 +160,21 @@ def test_front2_launch_equals_stem_plus_block0(emu_engine, student_weights, size
     for k in range(2):          # uint8 input, float input
         assert np.abs(outs[0][k][0] - outs[1][k][0]).max() < 1e-5, k
         assert np.abs(outs[0][k][1] - outs[1][k][1]).max() < 1e-3, k
+
+
+def test_one_product_mix_stays_within_its_budget_emu(emu_engine, student_weights):
+    """Round 6, opt-in: decoder.upsampler2.conv2 and the score head on ONE f16 product (csrc/k_hero.h, k_pwhead.h ONEPROD; the emulator
+    implements the MFMA's f16 operands and f32 accumulation).  One 256 x 256 face: within 2.5e-4 of the oracle on the margin-safe
+    landmarks, the default program within 1e-5, and the two differ (the switch reaches the kernels)."""
+    from peppa_pig_face_landmark_amd.graph.student import build_student_program
+    crops = sw.smooth_blob_images(1, 256, seed=5)
+    oloc, oscore, taps = helpers.oracle_student(student_weights, crops)
+    safe = helpers.heat_margins(taps) > 2e-3
+    out = {}
+    for mix in ((), ("hero", "head")):
+        blob, _ = build_student_program(student_weights, 256, "f32s", one_product=mix)
+        emu_engine.load_program(0, blob, 1)
+        out[mix] = emu_engine.landmark_forward(crops)
+    d3 = np.abs(out[()][0] - oloc).reshape(1, 98, 2).max(2)[safe].max()
+    d1 = np.abs(out[("hero", "head")][0] - oloc).reshape(1, 98, 2).max(2)[safe].max()
+    assert d3 < 1e-5 and d3 < d1 < 2.5e-4, (d3, d1)
