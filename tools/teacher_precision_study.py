@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--budget", type=float, default=2.5e-4)
     ap.add_argument("--model", default="teacher", choices=["teacher", "student"])
+    ap.add_argument("--round", default="f16", choices=["f16", "bf16", "fp8"], help="operand format of the ONE product simulated: f16 (v_mfma_f32_16x16x32_f16), "
+                    "bf16, or fp8 e4m3 with a per-tensor power-of-two scale (v_mfma_f32_16x16x128_f8f6f4)")
     args = ap.parse_args()
     torch.set_num_threads(max(1, (os.cpu_count() or 2) - 1))
     weights = sw.teacher_weights() if args.model == "teacher" else sw.student_weights()
@@ -84,14 +86,22 @@ def main():
     real = F.conv2d
     state = {"round": set(), "seen": {}, "macs": {}}
 
+    def rnd(t):
+        if args.round == "f16":
+            return t.half().float()
+        if args.round == "bf16":
+            return t.bfloat16().float()
+        m = float(t.abs().max())                      # fp8 e4m3 (max 448): per-tensor power-of-two scale to use the range
+        sc = 2.0 ** np.floor(np.log2(224.0 / m)) if m > 0 else 1.0
+        return (t * sc).to(torch.float8_e4m3fn).float() / sc
+
     def conv(inp, w, b=None, stride=1, padding=0, dilation=1, groups=1):
         name = name_of.get(id(w))
         if name is not None and groups == 1 and group_of(name) != "skip":
             g = group_of(name)
             state["seen"].setdefault(g, set()).add(name)
             if g in state["round"]:
-                inp = inp.half().float()
-                w = w.half().float()
+                inp, w = rnd(inp), rnd(w)
         y = real(inp, w, b, stride, padding, dilation, groups)
         if name is not None and groups == 1 and group_of(name) != "skip":
             g = group_of(name)
